@@ -1,0 +1,443 @@
+"""Functional CPU restatement of the reference networks (TEST INFRASTRUCTURE).
+
+Every function cites the reference file:line (relative to /root/reference) whose
+arithmetic it restates.  The networks are expressed as plain functions over a
+flat ``{state_dict_key: tensor}`` mapping that uses the reference's key names, so
+a reference ``state_dict()`` can be fed in unchanged.
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, models/model.py:71-76 selects it
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------
+# primitive layers
+# ----------------------------------------------------------------------------
+class Run:
+    """Per-call switches: train/eval BN, dropout behaviour, optional activation taps."""
+
+    def __init__(self, training=False, dropout=True, taps=None, momentum=BN_MOMENTUM):
+        self.training = training
+        self.momentum = momentum        # BN running-stat momentum (1.0 only for calibrate_bn)
+        self.dropout = dropout          # False => dropout layers are identity even in training
+        self.taps = taps                # optional dict collecting named intermediates
+
+    def tap(self, name, t):
+        if self.taps is not None:
+            self.taps[name] = t
+        return t
+
+
+def _conv(sd, key, x, stride=1, padding=0, dilation=1, groups=1):
+    return F.conv2d(x, sd[key + '.weight'], sd.get(key + '.bias'), stride, padding, dilation, groups)
+
+
+def _bn(sd, key, x, run):
+    """torch.nn.BatchNorm2d semantics."""
+    if run.training:
+        sd[key + '.num_batches_tracked'] += 1
+    return F.batch_norm(x, sd[key + '.running_mean'], sd[key + '.running_var'],
+                        sd[key + '.weight'], sd[key + '.bias'],
+                        run.training, run.momentum, BN_EPS)
+
+
+def _drop(x, p, run):
+    if run.training and run.dropout and p:
+        return F.dropout(x, p, True)
+    return x
+
+
+def _up(x, size):
+    return F.interpolate(x, size=size, mode='bilinear', align_corners=True)
+
+
+# ----------------------------------------------------------------------------
+# ResNet-101 encoder  (models/backbone/resnet.py)
+# ----------------------------------------------------------------------------
+def _resnet_plan(output_stride=16):
+    """(prefix, inplanes, planes, stride, dilation, has_downsample) per Bottleneck.
+
+    resnet.py:60-69 strides/dilations, :88-103 _make_layer, :105-122 _make_MG_unit,
+    :161-168 layers [3, 4, 23, 3].
+    """
+    if output_stride == 16:
+        strides, dils = (1, 2, 2, 1), (1, 1, 1, 2)
+    elif output_stride == 8:
+        strides, dils = (1, 2, 1, 1), (1, 1, 2, 4)
+    else:
+        raise NotImplementedError
+    plan, inpl = [], 64
+    for li, (planes, n) in enumerate(((64, 3), (128, 4), (256, 23))):
+        for b in range(n):
+            s = strides[li] if b == 0 else 1
+            down = b == 0 and (s != 1 or inpl != planes * 4)
+            plan.append(('layer%d.%d' % (li + 1, b), inpl, planes, s, dils[li], down))
+            inpl = planes * 4
+    for b, mg in enumerate((1, 2, 4)):
+        s = strides[3] if b == 0 else 1
+        down = b == 0 and (s != 1 or inpl != 2048)
+        plan.append(('layer4.%d' % b, inpl, 512, s, mg * dils[3], down))
+        inpl = 2048
+    return plan
+
+
+def _bottleneck(sd, p, x, stride, dil, down, run):
+    """resnet.py:33-53."""
+    out = F.relu(_bn(sd, p + '.bn1', _conv(sd, p + '.conv1', x), run))
+    out = F.relu(_bn(sd, p + '.bn2', _conv(sd, p + '.conv2', out, stride, dil, dil), run))
+    out = _bn(sd, p + '.bn3', _conv(sd, p + '.conv3', out), run)
+    res = x
+    if down:
+        res = _bn(sd, p + '.downsample.1', _conv(sd, p + '.downsample.0', x, stride), run)
+    return run.tap(p, F.relu(out + res))
+
+
+def resnet_forward(sd, x, run, pre='backbone.', output_stride=16):
+    """resnet.py:124-135 -> (features [B,2048,H/16,W/16], low_level [B,256,H/4,W/4])."""
+    x = F.relu(_bn(sd, pre + 'bn1', _conv(sd, pre + 'conv1', x, 2, 3), run))
+    run.tap(pre + 'stem', x)
+    x = F.max_pool2d(x, 3, 2, 1)
+    low = None
+    for (name, _, _, s, d, down) in _resnet_plan(output_stride):
+        x = _bottleneck(sd, pre + name, x, s, d, down, run)
+        if name == 'layer1.2':
+            low = x
+    return x, low
+
+
+# ----------------------------------------------------------------------------
+# Aligned Xception encoder  (models/backbone/xception.py)
+# ----------------------------------------------------------------------------
+def _xc_block_layout(inpl, planes, reps, stride, dilation, start_with_relu, grow_first, is_last):
+    """List of ('relu',) / ('sep', cin, cout, stride, dil) / ('bn', c) in rep order, xception.py:52-85."""
+    rep, filters = [], inpl
+    if grow_first:
+        rep += [('relu',), ('sep', inpl, planes, 1, dilation), ('bn', planes)]
+        filters = planes
+    for _ in range(reps - 1):
+        rep += [('relu',), ('sep', filters, filters, 1, dilation), ('bn', filters)]
+    if not grow_first:
+        rep += [('relu',), ('sep', inpl, planes, 1, dilation), ('bn', planes)]
+    if stride != 1:
+        rep += [('relu',), ('sep', planes, planes, 2, 1), ('bn', planes)]
+    if stride == 1 and is_last:
+        rep += [('relu',), ('sep', planes, planes, 1, 1), ('bn', planes)]
+    if not start_with_relu:
+        rep = rep[1:]
+    return rep
+
+
+def _xc_plan(output_stride=16):
+    """(name, inpl, planes, reps, stride, dil, start_with_relu, grow_first, is_last), xception.py:107-163."""
+    if output_stride == 16:
+        b3s, mid_d, exit_d = 2, 1, (1, 2)
+    elif output_stride == 8:
+        b3s, mid_d, exit_d = 1, 2, (2, 4)
+    else:
+        raise NotImplementedError
+    plan = [('block1', 64, 128, 2, 2, 1, False, True, False),
+            ('block2', 128, 256, 2, 2, 1, False, True, False),
+            ('block3', 256, 728, 2, b3s, 1, True, True, True)]
+    for i in range(4, 20):
+        plan.append(('block%d' % i, 728, 728, 3, 1, mid_d, True, True, False))
+    plan.append(('block20', 728, 1024, 2, 1, exit_d[0], True, False, True))
+    return plan, exit_d
+
+
+def _fixed_pad(x, k, d):
+    """xception.py:16-22 (TF 'SAME'-style explicit zero padding)."""
+    total = (k + (k - 1) * (d - 1)) - 1
+    beg = total // 2
+    return F.pad(x, (beg, total - beg, beg, total - beg))
+
+
+def _sepconv(sd, p, x, stride, dil, run):
+    """xception.py:34-39: pad -> depthwise(p=0) -> BN -> pointwise."""
+    c = x.shape[1]
+    x = _fixed_pad(x, 3, dil)
+    x = _conv(sd, p + '.conv1', x, stride, 0, dil, groups=c)
+    x = _bn(sd, p + '.bn', x, run)
+    return _conv(sd, p + '.pointwise', x)
+
+
+def _xc_block(sd, p, inp, cfg, run):
+    """xception.py:88-99 including the in-place-ReLU aliasing quirk:
+    when rep starts with ReLU(inplace) the skip branch reads ReLU(inp)."""
+    _, inpl, planes, reps, stride, dil, swr, gf, last = cfg
+    layout = _xc_block_layout(inpl, planes, reps, stride, dil, swr, gf, last)
+    if swr:
+        inp = F.relu(inp)          # rep[0] is the shared in-place ReLU -> inp itself is overwritten
+    x = inp
+    for i, item in enumerate(layout):
+        if item[0] == 'relu':
+            if not (swr and i == 0):
+                x = F.relu(x)
+        elif item[0] == 'sep':
+            x = _sepconv(sd, '%s.rep.%d' % (p, i), x, item[3], item[4], run)
+        else:
+            x = _bn(sd, '%s.rep.%d' % (p, i), x, run)
+    if planes != inpl or stride != 1:
+        skip = _bn(sd, p + '.skipbn', _conv(sd, p + '.skip', inp, stride), run)
+    else:
+        skip = inp
+    return run.tap(p, x + skip)
+
+
+def xception_forward(sd, x, run, pre='backbone.', output_stride=16):
+    """xception.py:189-239 -> (features [B,2048,H/16,W/16], low_level [B,128,H/4,W/4])."""
+    plan, exit_d = _xc_plan(output_stride)
+    x = F.relu(_bn(sd, pre + 'bn1', _conv(sd, pre + 'conv1', x, 2, 1), run))
+    x = F.relu(_bn(sd, pre + 'bn2', _conv(sd, pre + 'conv2', x, 1, 1), run))
+    low = None
+    for cfg in plan:
+        x = _xc_block(sd, pre + cfg[0], x, cfg, run)
+        if cfg[0] == 'block1':
+            x = F.relu(x)          # xception.py:199-202: relu, then low_level_feat = x
+            low = x
+    x = F.relu(x)
+    for i in (3, 4, 5):
+        x = _sepconv(sd, pre + 'conv%d' % i, x, 1, exit_d[1], run)
+        x = F.relu(_bn(sd, pre + 'bn%d' % i, x, run))
+    return x, low
+
+
+# ----------------------------------------------------------------------------
+# ASPP / decoder / DeepLabV3+
+# ----------------------------------------------------------------------------
+def aspp_forward(sd, x, run, pre='aspp.', output_stride=16):
+    """models/modules/aspp.py:73-86."""
+    dil = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
+    outs = []
+    for i, d in enumerate(dil):
+        p = '%saspp%d' % (pre, i + 1)
+        pad = 0 if i == 0 else d
+        outs.append(F.relu(_bn(sd, p + '.bn', _conv(sd, p + '.atrous_conv', x, 1, pad, d), run)))
+    g = F.adaptive_avg_pool2d(x, 1)
+    g = F.relu(_bn(sd, pre + 'global_avg_pool.2', _conv(sd, pre + 'global_avg_pool.1', g), run))
+    outs.append(_up(g, x.shape[2:]))
+    y = torch.cat(outs, 1)
+    y = F.relu(_bn(sd, pre + 'bn1', _conv(sd, pre + 'conv1', y), run))
+    return run.tap('aspp', _drop(y, 0.5, run))
+
+
+def decoder_forward(sd, x, low, run, pre='decoder.'):
+    """models/decoder.py:41-50."""
+    low = F.relu(_bn(sd, pre + 'bn1', _conv(sd, pre + 'conv1', low), run))
+    x = torch.cat((_up(x, low.shape[2:]), low), 1)
+    x = F.relu(_bn(sd, pre + 'last_conv.1', _conv(sd, pre + 'last_conv.0', x, 1, 1), run))
+    x = _drop(x, 0.5, run)
+    x = F.relu(_bn(sd, pre + 'last_conv.5', _conv(sd, pre + 'last_conv.4', x, 1, 1), run))
+    x = _drop(x, 0.1, run)
+    return run.tap('decoder', _conv(sd, pre + 'last_conv.8', x))
+
+
+def deeplab_forward(sd, x, backbone='resnet', training=False, dropout=True, taps=None, output_stride=16,
+                    momentum=BN_MOMENTUM):
+    """models/architectures/deeplab.py:34-39: logits [B,n_cls,H,W] (NCHW, fp32)."""
+    run = Run(training, dropout, taps, momentum)
+    if backbone == 'resnet':
+        f, low = resnet_forward(sd, x, run, output_stride=output_stride)
+    elif backbone == 'xception':
+        f, low = xception_forward(sd, x, run, output_stride=output_stride)
+    else:
+        raise ValueError(backbone)
+    run.tap('backbone', f)
+    run.tap('low', low)
+    y = decoder_forward(sd, aspp_forward(sd, f, run, output_stride=output_stride), low, run)
+    return _up(y, x.shape[2:])
+
+
+# ----------------------------------------------------------------------------
+# U-Net  (models/architectures/unet.py)
+# ----------------------------------------------------------------------------
+def _unet_block(sd, p, x, run, drop_p):
+    """unet.py:107-126: conv3x3 valid -> BN -> ReLU -> conv3x3 valid -> BN -> ReLU -> Dropout."""
+    x = F.relu(_bn(sd, p + '.block.1', _conv(sd, p + '.block.0', x), run))
+    x = F.relu(_bn(sd, p + '.block.4', _conv(sd, p + '.block.3', x), run))
+    return _drop(x, drop_p, run)
+
+
+def unet_forward(sd, x, training=False, dropout=True, taps=None, depth=5, drop_p=0.5, momentum=BN_MOMENTUM):
+    """unet.py:91-104 with up_mode='upsample', padding=False (config.py:231; model.py:140-147)."""
+    run = Run(training, dropout, taps, momentum)
+    skips = []
+    for i in range(depth):
+        x = _unet_block(sd, 'encoder.%d' % i, x, run, drop_p)
+        run.tap('enc%d' % i, x)
+        if i != depth - 1:
+            skips.append(x)
+            x = F.max_pool2d(x, 2)
+    for i in range(depth - 1):
+        p = 'decoder.%d' % i
+        # unet.py:135-138: Upsample(x2 bilinear, align_corners=True) then 1x1 conv
+        up = _conv(sd, p + '.up.1', F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True))
+        br = skips[-i - 1]
+        th, tw = up.shape[2:]
+        dy, dx = (br.shape[2] - th) // 2, (br.shape[3] - tw) // 2      # unet.py:142-148 center_crop
+        x = torch.cat([up, br[:, :, dy:dy + th, dx:dx + tw]], 1)
+        x = _unet_block(sd, p + '.conv_block', x, run, drop_p)
+        run.tap('dec%d' % i, x)
+    return _conv(sd, 'last', x)
+
+
+# ----------------------------------------------------------------------------
+# state-dict specs, reference init laws and formula weights
+# ----------------------------------------------------------------------------
+def _bn_spec(spec, p, c):
+    spec[p + '.weight'] = ((c,), 'bn_w')
+    spec[p + '.bias'] = ((c,), 'bn_b')
+    spec[p + '.running_mean'] = ((c,), 'bn_rm')
+    spec[p + '.running_var'] = ((c,), 'bn_rv')
+    spec[p + '.num_batches_tracked'] = ((), 'bn_nbt')
+
+
+def _conv_spec(spec, p, cin, cout, k, bias=False, groups=1, law='resnet'):
+    spec[p + '.weight'] = ((cout, cin // groups, k, k), 'conv_w:' + law)
+    if bias:
+        spec[p + '.bias'] = ((cout,), 'conv_b:' + law)
+
+
+def state_spec(arch='deeplab', backbone='resnet', n_classes=9, in_channels=3, output_stride=16):
+    """Ordered {key: (shape, kind)} in the reference's state_dict order."""
+    s = OrderedDict()
+    if arch == 'unet':
+        prev = in_channels
+        for i in range(5):
+            c = 2 ** (6 + i)
+            p = 'encoder.%d.block' % i
+            _conv_spec(s, p + '.0', prev, c, 3, True, law='torch'); _bn_spec(s, p + '.1', c)
+            _conv_spec(s, p + '.3', c, c, 3, True, law='torch'); _bn_spec(s, p + '.4', c)
+            prev = c
+        for j, i in enumerate(reversed(range(4))):
+            c = 2 ** (6 + i)
+            p = 'decoder.%d' % j
+            _conv_spec(s, p + '.up.1', prev, c, 1, True, law='torch')
+            _conv_spec(s, p + '.conv_block.block.0', prev, c, 3, True, law='torch'); _bn_spec(s, p + '.conv_block.block.1', c)
+            _conv_spec(s, p + '.conv_block.block.3', c, c, 3, True, law='torch'); _bn_spec(s, p + '.conv_block.block.4', c)
+            prev = c
+        _conv_spec(s, 'last', prev, n_classes, 1, True, law='torch')
+        return s
+    if arch != 'deeplab':
+        raise ValueError(arch)
+    b = 'backbone.'
+    if backbone == 'resnet':
+        _conv_spec(s, b + 'conv1', 3, 64, 7); _bn_spec(s, b + 'bn1', 64)
+        for (name, inpl, planes, _, _, down) in _resnet_plan(output_stride):
+            p = b + name
+            _conv_spec(s, p + '.conv1', inpl, planes, 1); _bn_spec(s, p + '.bn1', planes)
+            _conv_spec(s, p + '.conv2', planes, planes, 3); _bn_spec(s, p + '.bn2', planes)
+            _conv_spec(s, p + '.conv3', planes, planes * 4, 1); _bn_spec(s, p + '.bn3', planes * 4)
+            if down:
+                _conv_spec(s, p + '.downsample.0', inpl, planes * 4, 1); _bn_spec(s, p + '.downsample.1', planes * 4)
+        low_c = 256
+    else:
+        plan, _ = _xc_plan(output_stride)
+        _conv_spec(s, b + 'conv1', 3, 32, 3); _bn_spec(s, b + 'bn1', 32)
+        _conv_spec(s, b + 'conv2', 32, 64, 3); _bn_spec(s, b + 'bn2', 64)
+
+        def sep(p, cin, cout):
+            _conv_spec(s, p + '.conv1', cin, cin, 3, groups=cin); _bn_spec(s, p + '.bn', cin)
+            _conv_spec(s, p + '.pointwise', cin, cout, 1)
+        for cfg in plan:
+            name, inpl, planes, reps, stride, dil, swr, gf, last = cfg
+            p = b + name
+            if planes != inpl or stride != 1:
+                _conv_spec(s, p + '.skip', inpl, planes, 1); _bn_spec(s, p + '.skipbn', planes)
+            for i, item in enumerate(_xc_block_layout(inpl, planes, reps, stride, dil, swr, gf, last)):
+                if item[0] == 'sep':
+                    sep('%s.rep.%d' % (p, i), item[1], item[2])
+                elif item[0] == 'bn':
+                    _bn_spec(s, '%s.rep.%d' % (p, i), item[1])
+        sep(b + 'conv3', 1024, 1536); _bn_spec(s, b + 'bn3', 1536)
+        sep(b + 'conv4', 1536, 1536); _bn_spec(s, b + 'bn4', 1536)
+        sep(b + 'conv5', 1536, 2048); _bn_spec(s, b + 'bn5', 2048)
+        low_c = 128
+    for i in range(4):
+        p = 'aspp.aspp%d' % (i + 1)
+        _conv_spec(s, p + '.atrous_conv', 2048, 256, 1 if i == 0 else 3, law='kaiming'); _bn_spec(s, p + '.bn', 256)
+    _conv_spec(s, 'aspp.global_avg_pool.1', 2048, 256, 1, law='kaiming'); _bn_spec(s, 'aspp.global_avg_pool.2', 256)
+    _conv_spec(s, 'aspp.conv1', 1280, 256, 1, law='kaiming'); _bn_spec(s, 'aspp.bn1', 256)
+    _conv_spec(s, 'decoder.conv1', low_c, 48, 1, law='kaiming'); _bn_spec(s, 'decoder.bn1', 48)
+    _conv_spec(s, 'decoder.last_conv.0', 304, 256, 3, law='kaiming'); _bn_spec(s, 'decoder.last_conv.1', 256)
+    _conv_spec(s, 'decoder.last_conv.4', 256, 256, 3, law='kaiming'); _bn_spec(s, 'decoder.last_conv.5', 256)
+    _conv_spec(s, 'decoder.last_conv.8', 256, n_classes, 1, True, law='kaiming')
+    return s
+
+
+def _seed(name, salt):
+    return (zlib.crc32(name.encode()) ^ (salt * 0x9E3779B1)) & 0xFFFFFFFF
+
+
+def formula_state(spec, salt=0, dtype=torch.float32):
+    """Deterministic, name-keyed weights from numpy's frozen MT19937 stream.
+
+    Regenerable anywhere (no reference needed): conv weights ~ N(0, 2/fan_in) so activations
+    stay O(1) through 100+ layers; BN affine / running stats are perturbed away from (1, 0, 0, 1)
+    so every term of the BN arithmetic is exercised.
+    """
+    sd = OrderedDict()
+    for name, (shape, kind) in spec.items():
+        rs = np.random.RandomState(_seed(name, salt))
+        if kind.startswith('conv_w'):
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+        elif kind.startswith('conv_b'):
+            v = rs.standard_normal(shape) * 0.05
+        elif kind == 'bn_w':
+            v = 1.0 + 0.1 * rs.standard_normal(shape)
+        elif kind == 'bn_b':
+            v = 0.05 * rs.standard_normal(shape)
+        elif kind == 'bn_rm':
+            v = 0.05 * rs.standard_normal(shape)
+        elif kind == 'bn_rv':
+            v = 1.0 + 0.1 * np.abs(rs.standard_normal(shape))
+        elif kind == 'bn_nbt':
+            sd[name] = torch.zeros((), dtype=torch.int64)
+            continue
+        else:
+            raise ValueError(kind)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v)).to(dtype)
+    return sd
+
+
+def init_state(spec, seed=0):
+    """Reference init laws (SURVEY.md appendix C 'Init'): resnet/xception convs N(0, sqrt(2/(k*k*cout)))
+    (resnet.py:139-141, xception.py:243-245); ASPP/decoder kaiming_normal_ fan_in gain sqrt(2)
+    (aspp.py:34,93; decoder.py:55); U-Net + biased heads keep torch's default Conv2d init
+    (kaiming_uniform_(a=sqrt(5)) -> U(+-1/sqrt(fan_in)) for weight and bias); BN gamma=1, beta=0."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    fan_of = {}
+    for name, (shape, kind) in spec.items():
+        if kind.startswith('conv_w'):
+            law = kind.split(':')[1]
+            cout, cin, k, _ = shape
+            fan_in = cin * k * k
+            fan_of[name[:-len('.weight')]] = fan_in
+            if law == 'resnet':
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / (k * k * cout))
+            elif law == 'kaiming' and not name.endswith('last_conv.8.weight'):
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            elif law == 'kaiming':
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+            else:
+                bound = 1.0 / math.sqrt(fan_in)
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind.startswith('conv_b'):
+            bound = 1.0 / math.sqrt(fan_of[name[:-len('.bias')]])
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind in ('bn_w', 'bn_rv'):
+            t = torch.ones(shape)
+        elif kind in ('bn_b', 'bn_rm'):
+            t = torch.zeros(shape)
+        else:
+            t = torch.zeros((), dtype=torch.int64)
+        sd[name] = t
+    return sd

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).
+Recipe = SURVEY.md section 8c: scratch cwd with a `schemas` symlink, stub modules for the
+absent cv2 / h5py / seaborn, no bytecode written into the reference tree, and the shims for
+the reference's own bugs (U-Net `normalizer.evaluate`, list-typed `meta.weights`, U-Net crop).
+
+For every network it (1) checks the oracle's key/shape spec against the reference
+state_dict, (2) loads name-keyed formula weights into the reference, (3) asserts the oracle
+reproduces the reference (eval logits, train-step losses, gradients, post-AdamW parameters,
+BN running stats), and (4) writes small fixtures holding OUTPUTS only -- inputs and weights
+are regenerated from seeds by tests/_data.py and oracle.formula_state.
+
+    python tests/golden/make_golden.py            # all fixtures
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def enter_reference():
+    scratch = tempfile.mkdtemp(prefix='pylc_ref_')
+    os.symlink(os.path.join(REF, 'schemas'), os.path.join(scratch, 'schemas'))
+    os.chdir(scratch)
+    cv2 = types.ModuleType('cv2')
+    for i, n in enumerate(('INTER_NEAREST', 'INTER_LINEAR', 'INTER_CUBIC', 'INTER_AREA', 'INTER_LANCZOS4',
+                           'IMREAD_COLOR', 'IMREAD_GRAYSCALE', 'COLOR_BGR2RGB', 'COLOR_RGB2BGR',
+                           'COLOR_BGR2GRAY', 'BORDER_REFLECT', 'BORDER_CONSTANT', 'BORDER_REFLECT_101')):
+        setattr(cv2, n, i)
+    cv2.resize = lambda img, *a, **k: img
+    sys.modules['cv2'] = cv2
+    sys.modules['h5py'] = types.ModuleType('h5py')
+    sns = types.ModuleType('seaborn')
+    sns.heatmap = lambda *a, **k: None
+    sns.set = lambda *a, **k: None
+    sys.modules['seaborn'] = sns
+    sys.path.insert(0, REF)
+    return scratch
+
+
+def build_reference_model(arch, backbone, n_classes, ch, px_mean, px_std, class_weights, weighted,
+                          loss_weights=(0.5, 0.5, 0.5), tile=512):
+    from config import defaults
+    from models.model import Model
+    from torch import nn
+    m = Model()
+    meta = m.meta
+    meta.arch, meta.backbone, meta.ch, meta.n_classes = arch, backbone, ch, n_classes
+    meta.pretrained = False
+    meta.px_mean, meta.px_std = list(px_mean), list(px_std)
+    if ch == 1:
+        # shim 6: model.py:433-435 computes (float32 array - np.mean(list)) -- a float64 scalar, which
+        # NumPy >= 2 (NEP 50) promotes to float64 and the fp32 conv then rejects.  float32 statistics
+        # reproduce what NumPy 1.x (value-based casting) computed.
+        meta.px_mean, meta.px_std = np.asarray(px_mean, np.float32), np.asarray(px_std, np.float32)
+    meta.weights = [float(w) for w in class_weights]
+    meta.weighted = weighted
+    meta.ce_weight, meta.dice_weight, meta.focal_weight = loss_weights
+    meta.id = None
+    if arch == 'unet':
+        class BN(nn.BatchNorm2d):           # shim 1: unet.py:113,117 call normalizer.evaluate(c)
+            @classmethod
+            def evaluate(cls, c):
+                return cls(c)
+        m.normalizers['batch'] = BN
+        out = tile - 188                     # shim 3: crop hard-wired to 512 px (config.py:228-236)
+        meta.crop_left = meta.crop_up = 94
+        meta.crop_right = meta.crop_down = 94 + out
+    m.build()
+    for mod in m.net.modules():              # parity runs: dropout off (RNG streams differ)
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    assert defaults is meta
+    return m
+
+
+def tensor_digests(named):
+    from tests._data import digest
+    return {k: digest(v) for k, v in named}
+
+
+def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
+    import oracle
+    from oracle import step as ostep
+    from tests import _data as D
+    print('==', tag)
+    cw = D.class_weights(n_classes)
+    px_mean, px_std = ostep.PX_RGB_MEAN, ostep.PX_RGB_STD
+    ref = build_reference_model(arch, backbone, n_classes, ch, px_mean, px_std, cw, False, tile=hw)
+    ref_sd = ref.net.state_dict()
+    spec = oracle.state_spec(arch, backbone, n_classes, 3 if arch == 'deeplab' else ch)
+    ref_keys = [(k, list(v.shape)) for k, v in ref_sd.items()]
+    my_keys = [(k, list(s)) for k, (s, _) in spec.items()]
+    assert ref_keys == my_keys, 'state_dict spec mismatch'
+    x = D.tiles(100, b, ch, hw, hw)
+    y = D.blob_masks(101, b, hw, hw, n_classes, cell=8)
+    cfg = ostep.StepConfig(arch, backbone, n_classes, ch, px_mean, px_std, dropout=False)
+    w = ostep.calibrate_bn(oracle.formula_state(spec, salt=1), cfg, x.clone())
+    ref.net.load_state_dict(w)
+
+    # ---- eval forward (Model.test semantics) ------------------------------------------------
+    ref.net.eval()
+    ref_logits = ref.test(x.clone())[0]
+    sd = {k: v.clone() for k, v in w.items()}
+    taps = {}
+    xin, _ = ostep._prep(cfg, x.clone())
+    with torch.no_grad():
+        my_logits = ostep.forward(sd, cfg, xin, False, taps)
+    err = (ref_logits - my_logits).abs().max().item()
+    print('  eval logits max|diff| = %.3g  (|logits| max %.3g)' % (err, ref_logits.abs().max().item()))
+    assert err <= 2e-5 * max(1.0, ref_logits.abs().max().item())
+    top2 = ref_logits.topk(2, dim=1).values
+    fix = {
+        'eval_logits': ref_logits.numpy().astype(np.float32),
+        'eval_argmax': ref_logits.argmax(1).numpy().astype(np.uint8),
+        'eval_margin': (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32),
+    }
+    _, rce, rdice, rfl = None, None, None, None
+    ref_eval = ref.eval(x.clone(), y.clone())
+    e_ce, e_dice, e_fl = [float(v) for v in ref.loss.intv[-1]]
+    ref.loss.intv = []
+    _, o_ce, o_dice, o_fl = ostep.eval_step(sd, cfg, x.clone(), y.clone())
+    assert max(abs(e_ce - o_ce), abs(e_dice - o_dice), abs(e_fl - o_fl)) < 2e-6, (e_ce, o_ce, e_dice, o_dice, e_fl, o_fl)
+    meta = {'eval_losses': [e_ce, e_dice, e_fl]}
+    meta['taps'] = {k: [float(v.mean()), float(v.std()), float(v.abs().max())] for k, v in taps.items()}
+
+    # ---- two training steps (Model.train semantics) -----------------------------------------
+    ref.net.train()
+    opt = ostep.make_optimizer(sd, cfg)
+    steps = []
+    for it in range(2):
+        ref.train(x.clone(), y.clone())
+        r = [float(v) for v in ref.loss.intv[-1]] if ref.loss.intv else None
+        if r is None:                                   # log() at iter%report==0 clears intv
+            r = [float(ref.crit.ce), float(ref.crit.dsc), float(ref.crit.fl)]
+        o = ostep.train_step(sd, opt, cfg, x.clone(), y.clone())
+        d = max(abs(r[i] - o[i]) for i in range(3))
+        print('  step %d  ref (ce,dice,focal)=%s  max|diff|=%.3g  gnorm=%.5g' % (it, r, d, o[5]))
+        assert d < (5e-6 if it == 0 else 2e-4)      # step 1 inherits the AdamW |g|~eps sensitivity noted below
+        steps.append({'ce': r[0], 'dice': r[1], 'focal': r[2], 'grad_norm_preclip': o[5]})
+        if it == 0:
+            gref = {k: p.grad for k, p in ref.net.named_parameters()}
+            worst = 0.0
+            gmax = max(g.abs().max().item() for g in gref.values())
+            # parameters whose true gradient is identically 0 (an additive bias that a train-mode
+            # BatchNorm removes again): both sides hold pure summation noise there
+            zero_keys = [k for k in gref if (arch == 'unet' and (k.endswith('block.0.bias') or k.endswith('block.3.bias')))
+                         or (backbone == 'xception' and k.startswith('backbone.') and k.endswith('.bn.bias'))]
+            meta['zero_grad_keys'] = zero_keys
+            for k, g in gref.items():
+                if k in zero_keys:
+                    continue
+                og = sd[k].grad
+                rel = (g - og).abs().max().item() / (g.abs().max().item() + 1e-3 * gmax)   # some true grads are 0 (a bias ahead of a train-mode BN): pure summation noise
+                if rel > 1e-3:
+                    print('    grad mismatch %-50s rel %.3g  |g|max %.3g' % (k, rel, g.abs().max().item()))
+                worst = max(worst, rel)
+            print('  step 0  worst relative grad diff = %.3g' % worst)
+            assert worst < 2e-3
+            meta['grad_digest_step0'] = tensor_digests(gref.items())
+            new_sd = ref.net.state_dict()
+            pw, pk = 0.0, None
+            for k, v in new_sd.items():
+                if v.is_floating_point():
+                    e = (v - sd[k].detach()).abs().max().item()
+                    if e > pw:
+                        pw, pk = e, k
+            # the first AdamW update is lr * g/(|g| + 1e-8): for |g| ~ 1e-8 an fp32-rounding-level
+            # gradient difference moves the update by a fraction of lr (1e-4), hence the loose bound
+            print('  step 0  worst post-AdamW/BN-stat diff = %.3g (%s)' % (pw, pk))
+            assert pw < 2.5e-4
+            meta['state_digest_step0'] = tensor_digests((k, v) for k, v in new_sd.items() if v.is_floating_point())
+    meta['train_steps'] = steps
+    meta['keys'] = ref_keys
+    meta['config'] = {'arch': arch, 'backbone': backbone, 'b': b, 'ch': ch, 'hw': hw, 'n_classes': n_classes,
+                      'tile_seed': 100, 'mask_seed': 101, 'mask_cell': 8, 'weight_salt': 1,
+                      'torch': torch.__version__}
+    np.savez_compressed(os.path.join(out_dir, tag + '.npz'), **fix)
+    with open(os.path.join(out_dir, tag + '.json'), 'w') as f:
+        json.dump(meta, f)
+
+
+def golden_multiloss(out_dir):
+    import oracle
+    from tests import _data as D
+    from models.modules.loss import MultiLoss
+    print('== multiloss')
+    out = {}
+    arrays = {}
+    for n_cls in (9, 11):
+        rs = np.random.RandomState(300 + n_cls)
+        z = torch.from_numpy((rs.standard_normal((2, n_cls, 40, 36)) * 3).astype(np.float32))
+        t = D.blob_masks(301 + n_cls, 2, 40, 36, n_cls, cell=4)
+        cw = D.class_weights(n_cls)
+        for weighted in (False, True):
+            crit = MultiLoss({'weighted': weighted, 'weights': [float(v) for v in cw], 'ce': 0.5, 'dice': 0.5, 'focal': 0.5},
+                             {'n_classes': n_cls, 'class_codes': ['c%d' % i for i in range(n_cls)],
+                              'class_labels': ['l%d' % i for i in range(n_cls)]})
+            zr = z.clone().requires_grad_(True)
+            tot = crit.forward(zr, t)
+            tot.backward()
+            zo = z.clone().requires_grad_(True)
+            o_tot, o_ce, o_d, o_f = oracle.multiloss(zo, t, (0.5, 0.5, 0.5), torch.from_numpy(cw), weighted)
+            o_tot.backward()
+            assert abs(float(tot) - float(o_tot)) < 1e-6
+            assert (zr.grad - zo.grad).abs().max().item() < 1e-9 + 1e-4 * zr.grad.abs().max().item()
+            key = 'c%d_%s' % (n_cls, 'w' if weighted else 'u')
+            out[key] = {'total': float(tot), 'ce': float(crit.ce), 'dice': float(crit.dsc), 'focal': float(crit.fl)}
+            arrays[key + '_grad'] = zr.grad.numpy()
+            print('  %s: %s' % (key, out[key]))
+    out['config'] = {'shape': [2, 'n_cls', 40, 36], 'logit_seed': '300+n_cls', 'logit_scale': 3,
+                     'mask_seed': '301+n_cls', 'mask_cell': 4}
+    np.savez_compressed(os.path.join(out_dir, 'multiloss.npz'), **arrays)
+    with open(os.path.join(out_dir, 'multiloss.json'), 'w') as f:
+        json.dump(out, f)
+
+
+def main():
+    torch.set_num_threads(8)
+    enter_reference()
+    which = sys.argv[1:] or ['multiloss', 'deeplab_resnet', 'deeplab_xception', 'unet']
+    if 'multiloss' in which:
+        golden_multiloss(HERE)
+    if 'deeplab_resnet' in which:
+        golden_net('deeplab_resnet', 'deeplab', 'resnet', 2, 3, 96, 9, HERE)
+    if 'deeplab_xception' in which:
+        golden_net('deeplab_xception', 'deeplab', 'xception', 2, 1, 96, 11, HERE)
+    if 'unet' in which:
+        golden_net('unet', 'unet', 'resnet', 2, 3, 256, 9, HERE)
+
+
+if __name__ == '__main__':
+    main()
