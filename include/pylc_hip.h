@@ -1,0 +1,206 @@
+/*
+ * pylc_hip.h -- C ABI of libpylc_hip.so: the MI355X (gfx950) kernels behind PyLC's
+ * segmentation training / inference step.
+ *
+ * The reference (scrose/pylc) has no FFI or plugin API: its hot path calls PyTorch ATen ops
+ * from Python.  Each entry point below therefore replaces one ATen op
+ * family at the call sites cited next to it (paths relative to the reference root).  A binding
+ * is a ctypes stub; no torch types appear in any signature.
+ *
+ * Conventions
+ *   - All tensors are fp32, device memory, NHWC ("channels_last"): element (b,h,w,c) lives at
+ *     ((b*H + h)*W + w)*pitch + c, where `pitch` (>= C, in floats) lets a tensor be a channel
+ *     slice of a wider concat buffer.  Conv weights are KRSC = [Cout][kh][kw][Cin] (the
+ *     channels_last memory of a [Cout,Cin,kh,kw] tensor).  Channel counts and pitches must be
+ *     multiples of 4 unless stated otherwise (16-byte vector access).
+ *   - The caller owns every buffer, including workspaces; no entry point allocates, frees or
+ *     synchronises.  All work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - Return value: 0 on success, non-zero on error; pylc_last_error() returns a message for
+ *     the calling thread.  Shapes are validated on the host before anything is launched.
+ */
+#ifndef PYLC_HIP_H
+#define PYLC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYLC_OK 0
+#define PYLC_ERR_ARG 1
+#define PYLC_ERR_HIP 2
+#define PYLC_ERR_WORKSPACE 3
+
+const char* pylc_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int pylc_abi_version(void);
+/* One-time per-process kernel attribute setup (dynamic LDS opt-in). Idempotent. */
+int pylc_init(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution (dense, groups = 1): replaces nn.Conv2d at models/backbone/resnet.py:21-26,72,92;
+ * models/modules/aspp.py:18,64,67; models/decoder.py:27,30,34,38; models/backbone/xception.py:32,
+ * 48,122,126; models/architectures/unet.py:78,112,116,137 -- and their autograd backward.
+ * Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged NHWC / KRSC tiles.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct PylcConvDesc {
+    int B, H, W;            /* input batch / height / width                                  */
+    int Cin, Cout;          /* Cin % 4 == 0 (pad 3-channel images to 4, see pylc_image_pack)  */
+    int R, S;               /* kernel height / width                                         */
+    int stride, pad, dil;   /* symmetric stride / zero padding / dilation                    */
+    int OH, OW;             /* output height / width = floor((H + 2*pad - dil*(R-1) - 1)/stride) + 1 */
+    int x_pitch;            /* floats between input pixels  (>= Cin)                          */
+    int y_pitch;            /* floats between output pixels (>= Cout)                         */
+} PylcConvDesc;
+
+/* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
+ * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */
+int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
+                    float* y, void* stream);
+/* dx = conv_transpose(dy, w).  w_crsk = weights re-laid-out as [Cin][R][S][Cout] by
+ * pylc_weight_transpose.  accumulate != 0 adds into dx instead of overwriting it. */
+int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx,
+                      int accumulate, void* stream);
+/* dw (KRSC) = sum over pixels of dy (x) x.  workspace: pylc_conv2d_wgrad_workspace(d) bytes
+ * (deterministic split-K slabs, reduced in a fixed order).  dbias (may be NULL) = sum_pixels dy. */
+size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d);
+int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const float* dy, float* dw_krsc,
+                      float* dbias /* must be NULL: take sums[0:C] of pylc_bn_stats(dy) */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* [K][R*S][C] -> [C][R*S][Kp], Kp = roundup4(K), zero-filled pad columns */
+int pylc_weight_transpose(const float* w_krsc, float* w_crsk, int K, int RS, int C, void* stream);
+
+/* Depthwise 3x3 (groups = C) with the explicit TF-'SAME' padding of fixed_padding folded into the
+ * index math: replaces F.pad + nn.Conv2d(groups=C) at models/backbone/xception.py:16-22,29-31,35-36.
+ * w is [C][3][3] (the memory of a [C,1,3,3] tensor).  pad_beg = ((3-1)*dil)/2. */
+typedef struct PylcDwDesc {
+    int B, H, W, C;
+    int stride, dil;
+    int OH, OW;
+    int x_pitch, y_pitch;
+} PylcDwDesc;
+int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const float* w, float* y, void* stream);
+int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream);
+size_t pylc_dwconv3x3_wgrad_workspace(const PylcDwDesc* d);
+int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const float* dy, float* dw,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ fused ReLU / residual add): replaces torch.nn.BatchNorm2d (selected at
+ * models/model.py:71-76) and the ReLU / `out += residual` that follow it (resnet.py:36-51,
+ * aspp.py:28-31, decoder.py:42-44, unet.py:113-118, xception.py:37,60-97).
+ * ------------------------------------------------------------------------------------------- */
+/* Number of floats of workspace needed by the two reductions below for M rows x C channels. */
+size_t pylc_bn_workspace_floats(long long M, int C);
+/* Per-channel sums of y[M][C] (dense rows of pitch y_pitch): sums[0:C] = sum y, sums[C:2C] = sum y*y
+ * (fp64-combined, deterministic).  With `count`: the SyncBN wire format of
+ * models/sync_batchnorm/batchnorm.py:66-68 (sum, ssum, size). */
+int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, float* sums /*[2C]*/,
+                  float* workspace, void* stream);
+/* From (possibly all-reduced) sums and the GLOBAL row count n: mean, invstd = 1/sqrt(var_biased + eps)
+ * (clamp_eps != 0 selects batchnorm.py:125's clamp(var, eps)^-1/2 instead), running stats update with
+ * the unbiased variance (momentum), and the fused affine scale = gamma*invstd, shift = beta - mean*scale. */
+int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, const float* beta,
+                     float eps, float momentum, int clamp_eps,
+                     float* running_mean, float* running_var,      /* may be NULL (no update) */
+                     float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Eval mode: scale/shift from running statistics. */
+int pylc_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma,
+                        const float* beta, float eps, int C, float* scale, float* shift, void* stream);
+/* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out. */
+int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift,
+                  const float* residual, int res_pitch, float* out, int out_pitch,
+                  long long M, int C, int relu, void* stream);
+/* Backward, training mode.  g = dout * (out > 0 if relu).  sums[0:C] = sum g (= dbeta),
+ * sums[C:2C] = sum g * xhat (= dgamma), xhat = (y - mean) * invstd. */
+int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch,
+                       const float* y, int y_pitch, const float* mean, const float* invstd,
+                       long long M, int C, int relu, float* sums /*[2C]*/, float* workspace, void* stream);
+/* dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) with the (all-reduced) sums and GLOBAL n.
+ * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout. */
+int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch,
+                      const float* y, int y_pitch, const float* mean, const float* invstd,
+                      const float* gamma, const float* sums, double n,
+                      long long M, int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch,
+                      void* stream);
+/* Plain ReLU forward / backward on [M][C] (Xception's stand-alone ReLUs, xception.py:83-84,199-232). */
+int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream);
+int pylc_relu_bwd(const float* dout, int dout_pitch, const float* out, int out_pitch, float* dx, int dx_pitch,
+                  long long M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling / resize: nn.MaxPool2d(3,2,1) resnet.py:76, F.max_pool2d(x,2) unet.py:98,
+ * F.interpolate(bilinear, align_corners=True) deeplab.py:38 / decoder.py:46 / aspp.py:79 /
+ * nn.Upsample unet.py:136, nn.AdaptiveAvgPool2d(1) aspp.py:63.
+ * ------------------------------------------------------------------------------------------- */
+/* idx (may be NULL for inference) receives, per output element, the window position kh*k + kw of the
+ * FIRST maximum in scan order (PyTorch's convention); the backward routes dy through it (a gather over
+ * the <= 4 windows covering each input element: deterministic, no atomics). */
+int pylc_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, int k, int stride,
+                     int pad, int OH, int OW, void* stream);
+int pylc_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int k,
+                     int stride, int pad, int OH, int OW, void* stream);
+int pylc_bilinear_fwd(const float* x, int x_pitch, float* y, int y_pitch, int B, int H, int W, int C,
+                      int OH, int OW, void* stream);
+int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C,
+                      int OH, int OW, void* stream);
+int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
+int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream);
+
+/* Image ingest: Model.normalize_image models/model.py:416-445 + the 1->3 channel stack model.py:310-311
+ * + NCHW->NHWC, zero-padded to 4 channels.  img is [B][Cimg][H][W] raw 0..255 floats (Cimg = 1 or 3);
+ * out is [B][H][W][4]: out[..., c] = ((img[c or 0] - mean[c]) / std[c]) / 255, out[..., 3] = 0.
+ * mean3 / std3 are HOST arrays of 3 floats. */
+int pylc_image_pack(const float* img_nchw, int B, int Cimg, int H, int W, const float* mean3,
+                    const float* std3, float* out_nhwc4, void* stream);
+/* Layout converters for module-boundary tensors (logits): [B][H][W][pitch] <-> [B][C][H][W]. */
+int pylc_nhwc_to_nchw(const float* x, int x_pitch, float* y, int B, int H, int W, int C, void* stream);
+int pylc_nchw_to_nhwc(const float* x, float* y, int y_pitch, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MultiLoss: models/modules/loss.py:66-69 (CE), :137-146 (Dice), :174-189 (Focal), :107-112
+ * (weighted sum) as ONE per-pixel pass forward and ONE backward.
+ * logits: NHWC [N][pitch] (N = B*H*W pixels), target: int64 [N].
+ * ------------------------------------------------------------------------------------------- */
+#define PYLC_MAX_CLASSES 16
+size_t pylc_multiloss_workspace_floats(long long N, int C);
+/* stats[0] = sum_n w_t * (-log p_t), stats[1] = sum_n w_t, stats[2] = sum_n focal_n,
+ * stats[3 + c] = I_c, stats[3 + C + c] = sum_n p_c, stats[3 + 2C + c] = count_c   (3 + 3C floats).
+ * These are the quantities a data-parallel run all-reduces before the non-linear Dice / weighted-CE
+ * finalisation.  class_weights may be NULL (unweighted CE). */
+int pylc_multiloss_stats(const float* logits, int pitch, const int64_t* target, long long N, int C,
+                         const float* class_weights, float* stats, float* workspace, void* stream);
+/* losses[0..3] = total, ce, dice, focal from (all-reduced) stats and the GLOBAL pixel count. */
+int pylc_multiloss_finalize(const float* stats, double n_global, int C, float w_ce, float w_dice, float w_focal,
+                            float* losses, void* stream);
+/* dlogits = grad_scale[0] * d(total)/d(logits), using the same (global) stats. */
+int pylc_multiloss_bwd(const float* logits, int pitch, const int64_t* target, long long N, int C,
+                       const float* class_weights, const float* stats, double n_global,
+                       float w_ce, float w_dice, float w_focal, const float* grad_scale,
+                       float* dlogits, int dpitch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser: torch.nn.utils.clip_grad_norm_(params, 0.5) models/model.py:326 + torch.optim.AdamW
+ * models/model.py:240-245 over ONE flat fp32 arena holding every parameter.
+ * ------------------------------------------------------------------------------------------- */
+size_t pylc_sqnorm_workspace_floats(long long n);
+/* out[0] = ||g||_2, out[1] = clip coefficient min(1, max_norm / (||g|| + 1e-6)). */
+int pylc_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, float* workspace, void* stream);
+/* p,m,v updated in place; g is read as g * coef[1] (coef = out2 of pylc_grad_norm_clip, or NULL for 1). */
+int pylc_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* coef,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* SGD with momentum (models/model.py:246-251): buf = mu*buf + g ; p -= lr*buf. */
+int pylc_sgd_step(float* p, const float* g, float* buf, long long n, const float* coef, float lr, float momentum,
+                  int step, void* stream);
+
+/* Dropout (aspp.py:70, decoder.py:33,37, unet.py:120): mask from a counter-based hash of
+ * (seed, element index); out = x * keep / (1 - p).  The same call with dy regenerates the mask. */
+int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, float p,
+                 uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLC_HIP_H */

@@ -1,0 +1,325 @@
+// BatchNorm2d forward / backward with fused ReLU and residual add, NHWC fp32 (HBM-bound kernels).
+//
+// Every kernel walks a [M rows][C channels] matrix in row slabs.  A thread owns ONE float4 channel vector
+// (so gamma/beta/scale/shift live in registers, no per-element division) and strides over rows; consecutive
+// threads read consecutive 16-byte vectors of a row, so every wave instruction touches whole contiguous rows.
+// Reductions are two-level: per-slab fp32 partials -> one fp64 combine per channel (deterministic order).
+//
+// Replaces torch.nn.BatchNorm2d (models/model.py:71-76) + ReLU + residual add at resnet.py:36-51,
+// aspp.py:28-31,81-84, decoder.py:42-44 and last_conv, unet.py:113-118, xception.py:37,60-97; the
+// synchronized variant's wire format follows models/sync_batchnorm/batchnorm.py:48-125.
+#include "common.h"
+#include "slab.h"
+
+namespace pylc {
+
+__device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 o) {
+    f32x4 r;
+    r.x = o.x > 0.f ? g.x : 0.f; r.y = o.y > 0.f ? g.y : 0.f; r.z = o.z > 0.f ? g.z : 0.f; r.w = o.w > 0.f ? g.w : 0.f;
+    return r;
+}
+
+// ---- reductions --------------------------------------------------------------------------------
+// MODE 0: (sum y, sum y^2).  MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a, int a_pitch,
+                                                        const float* __restrict__ out, int out_pitch,
+                                                        const float* __restrict__ y, int y_pitch,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int relu, Slab g, int C, float* __restrict__ partial) {
+    __shared__ f32x4 red[2][256];
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cb = 0; cb < g.CV; cb += g.cols) {
+        const int cv = cb + tx;
+        const bool active = ty < g.RL && cv < g.CV;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+            if (MODE == 1) { mu = ld4(mean + 4 * cv); is = ld4(invstd + 4 * cv); }
+            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+                if (MODE == 0) {
+                    const f32x4 v = ld4(a + r * a_pitch + 4 * cv);
+                    s0 += v;
+                    s1 += v * v;
+                } else {
+                    f32x4 gg = ld4(a + r * a_pitch + 4 * cv);
+                    if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
+                    const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
+                    s0 += gg;
+                    s1 += gg * xh;
+                }
+            }
+        }
+        red[0][threadIdx.x] = s0;
+        red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (ty == 0 && cv < g.CV) {
+            for (int k = 1; k < g.RL; ++k) { s0 += red[0][k * g.cols + tx]; s1 += red[1][k * g.cols + tx]; }
+            float* p = partial + (size_t)blockIdx.x * 2 * C;
+            st4(p + 4 * cv, s0);
+            st4(p + C + 4 * cv, s1);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 2C
+    if (i >= 2 * C) return;
+    double acc = 0.0;
+    for (int s = 0; s < nslab; ++s) acc += (double)partial[(size_t)s * 2 * C + i];
+    sums[i] = (float)acc;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
+                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                   float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = (double)sums[c] / n;
+    double var = (double)sums[C + c] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    // torch.nn.BatchNorm2d: 1/sqrt(var + eps); vendored SyncBN (batchnorm.py:125): clamp(var, eps)^-1/2
+    const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
+    const float mu_f = (float)mu, is_f = (float)is;
+    mean[c] = mu_f;
+    invstd[c] = is_f;
+    const float sc = gamma[c] * is_f;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu_f * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu_f;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
+                                      int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- elementwise -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_pitch,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, int res_pitch, float* __restrict__ out,
+                                                       int out_pitch, int relu, Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        const f32x4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            f32x4 v = ld4(y + r * y_pitch + 4 * cv) * sc + sh;
+            if (res != nullptr) v += ld4(res + r * res_pitch + 4 * cv);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            st4(out + r * out_pitch + 4 * cv, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
+                                                           const float* __restrict__ out, int out_pitch,
+                                                           const float* __restrict__ y, int y_pitch,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           float inv_n, int C, int relu, float* __restrict__ dy, int dy_pitch,
+                                                           float* __restrict__ g_out, int g_pitch, Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
+        const f32x4 k = ld4(gamma + 4 * cv) * is;
+        const f32x4 sg = ld4(sums + 4 * cv) * inv_n, sgx = ld4(sums + C + 4 * cv) * inv_n;
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
+            if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
+            const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
+            if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, gg);
+            st4(dy + r * dy_pitch + 4 * cv, k * (gg - sg - xh * sgx));
+        }
+    }
+}
+
+// MODE 0: out = max(x, 0).  MODE 1: dx = dout * (out > 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ a, int a_pitch, const float* __restrict__ o, int o_pitch,
+                                                   float* __restrict__ dst, int dst_pitch, Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            f32x4 v = ld4(a + r * a_pitch + 4 * cv);
+            if (MODE == 0) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else v = relu_mask(v, ld4(o + r * o_pitch + 4 * cv));
+            st4(dst + r * dst_pitch + 4 * cv, v);
+        }
+    }
+}
+
+// counter-based hash RNG: one 64-bit mix per float4 -> 4 x 16-bit uniform thresholds
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ out, int out_pitch,
+                                                      unsigned thresh16, float keep_scale, unsigned long long seed, Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            const unsigned long long h = mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r * g.CV + cv + 1));
+            f32x4 v = ld4(x + r * x_pitch + 4 * cv);
+            v.x = ((h & 0xFFFF) >= thresh16) ? v.x * keep_scale : 0.f;
+            v.y = (((h >> 16) & 0xFFFF) >= thresh16) ? v.y * keep_scale : 0.f;
+            v.z = (((h >> 32) & 0xFFFF) >= thresh16) ? v.z * keep_scale : 0.f;
+            v.w = (((h >> 48) & 0xFFFF) >= thresh16) ? v.w * keep_scale : 0.f;
+            st4(out + r * out_pitch + 4 * cv, v);
+        }
+    }
+}
+
+static int check_mc(long long M, int C, int pitch, const char* what) {
+    PYLC_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "%s: need M > 0 and C %% 4 == 0 (M=%lld C=%d)", what, M, C);
+    PYLC_REQUIRE(pitch >= C && pitch % 4 == 0, "%s: pitch %d invalid for C=%d", what, pitch, C);
+    return PYLC_OK;
+}
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" size_t pylc_bn_workspace_floats(long long M, int C) {
+    (void)M;
+    return (size_t)kMaxSlabs * 2 * (size_t)C;
+}
+
+extern "C" int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, float* sums, float* workspace, void* stream) {
+    if (int rc = check_mc(M, C, y_pitch, "bn_stats")) return rc;
+    PYLC_REQUIRE(y && sums && workspace, "bn_stats: null pointer");
+    const Slab g = make_slab(M, C);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nslab), dim3(256), 0, st, y, y_pitch, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, g, C,
+                       workspace);
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, g.nslab, C, sums);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                float* shift, void* stream) {
+    PYLC_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize: bad arguments");
+    PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be set or both NULL");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums, n, C, gamma, beta, eps, momentum,
+                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,
+                                   float* shift, void* stream) {
+    PYLC_REQUIRE(rm && rv && gamma && beta && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), rm, rv, gamma, beta, eps, C, scale, shift);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
+                             float* out, int out_pitch, long long M, int C, int relu, void* stream) {
+    if (int rc = check_mc(M, C, y_pitch, "bn_apply")) return rc;
+    if (int rc = check_mc(M, C, out_pitch, "bn_apply(out)")) return rc;
+    PYLC_REQUIRE(y && scale && shift && out, "bn_apply: null pointer");
+    PYLC_REQUIRE(residual == nullptr || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
+    const Slab g = make_slab(M, C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch, out,
+                       out_pitch, relu, g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                                  const float* mean, const float* invstd, long long M, int C, int relu, float* sums, float* workspace,
+                                  void* stream) {
+    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_reduce")) return rc;
+    if (int rc = check_mc(M, C, y_pitch, "bn_bwd_reduce(y)")) return rc;
+    PYLC_REQUIRE(dout && y && mean && invstd && sums && workspace, "bn_bwd_reduce: null pointer");
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C && out_pitch % 4 == 0), "bn_bwd_reduce: relu needs `out`");
+    const Slab g = make_slab(M, C);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
+                       relu, g, C, workspace);
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, g.nslab, C, sums);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                                 const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
+                                 int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, void* stream) {
+    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_apply")) return rc;
+    if (int rc = check_mc(M, C, dy_pitch, "bn_bwd_apply(dy)")) return rc;
+    PYLC_REQUIRE(dout && y && mean && invstd && gamma && sums && dy && n > 0, "bn_bwd_apply: bad arguments");
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C), "bn_bwd_apply: relu needs `out`");
+    PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
+    const Slab g = make_slab(M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
+                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream) {
+    if (int rc = check_mc(M, C, x_pitch, "relu_fwd")) return rc;
+    if (int rc = check_mc(M, C, out_pitch, "relu_fwd(out)")) return rc;
+    const Slab g = make_slab(M, C);
+    hipLaunchKernelGGL((relu_kernel<0>), dim3(g.nslab), dim3(256), 0, as_stream(stream), x, x_pitch, nullptr, 0, out, out_pitch, g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_relu_bwd(const float* dout, int dout_pitch, const float* out, int out_pitch, float* dx, int dx_pitch, long long M,
+                             int C, void* stream) {
+    if (int rc = check_mc(M, C, dout_pitch, "relu_bwd")) return rc;
+    if (int rc = check_mc(M, C, out_pitch, "relu_bwd(out)")) return rc;
+    if (int rc = check_mc(M, C, dx_pitch, "relu_bwd(dx)")) return rc;
+    const Slab g = make_slab(M, C);
+    hipLaunchKernelGGL((relu_kernel<1>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, dx, dx_pitch, g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, float p, uint64_t seed,
+                            void* stream) {
+    if (int rc = check_mc(M, C, x_pitch, "dropout")) return rc;
+    if (int rc = check_mc(M, C, out_pitch, "dropout(out)")) return rc;
+    PYLC_REQUIRE(p >= 0.f && p < 1.f, "dropout: p must be in [0,1)");
+    const Slab g = make_slab(M, C);
+    const unsigned thresh = (unsigned)(p * 65536.0f + 0.5f);
+    hipLaunchKernelGGL(dropout_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), x, x_pitch, out, out_pitch, thresh,
+                       1.0f / (1.0f - p), (unsigned long long)seed, g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

@@ -1,0 +1,54 @@
+// Shared host/device helpers for libpylc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/pylc_hip.h"
+
+namespace pylc {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PYLC_REQUIRE(cond, ...)                                     \
+    do {                                                            \
+        if (!(cond)) return ::pylc::fail(PYLC_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define PYLC_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return ::pylc::fail(PYLC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));  \
+    } while (0)
+
+#define PYLC_LAUNCH_CHECK() PYLC_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T>
+__host__ __device__ inline T cdiv(T a, T b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+// Block-wide sum of `v` over 256 threads; result valid in thread 0. `red` needs >= 4 floats.
+__device__ inline float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace pylc

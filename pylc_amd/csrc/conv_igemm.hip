@@ -1,0 +1,651 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   forward / dgrad : "gather GEMM"  Y[m][n] = sum_{tap, c} X[gather(m, tap)][c] * Wt[n][tap][c]
+//                     m = output pixel (b,p,q), n = output channel.  The same kernel serves the forward
+//                     pass (taps = kernel window), stride-1 dgrad (flipped taps, CRSK weights) and
+//                     stride-2 dgrad (one launch per output parity class with that class's tap subset),
+//                     because the tap set is an arithmetic progression described by scalars.
+//   wgrad           : dW[n][tap][c] = sum_m dY[m][n] * X[gather(m, tap)][c], split-K over pixels with
+//                     deterministic slab reduction.
+//
+// Data layout: activations NHWC with a channel pitch (so producers can write straight into concat
+// buffers), weights KRSC.  Tiles are staged global -> VGPR -> LDS (register staging lets rows be padded to
+// 36 floats, which makes the ds_read_b128 fragment reads bank-conflict free) and double-buffered: the
+// global loads of step s+1 are in flight while the 64 MFMAs of step s issue.
+//
+// Reference call sites replaced: nn.Conv2d in models/backbone/resnet.py:21-26,72,92,
+// models/modules/aspp.py:18,64,67, models/decoder.py:27-38, models/architectures/unet.py:78,112,116,137,
+// models/backbone/xception.py:32,48,122,126 and their autograd backward.
+#include "common.h"
+
+namespace pylc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;    // reduction depth per LDS stage
+constexpr int LDT = 36;   // padded LDS row (floats): 144 B rows -> conflict-free ds_read_b128 of k-slices
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (observed round-robin dispatch), so give every
+// XCD a contiguous range of logical tiles -> neighbouring tiles (which share halos / weight panels) share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct GatherGemmArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int M, P, Q;            // M = B*P*Q logical output pixels
+    int IH, IW, Cin, x_pitch;
+    int in_sh, in_sw;       // input coordinate of pixel (p,q), tap (r,s): (p*in_sh + dh0 + r*dh_step, ...)
+    int TR, TS;
+    int dh0, dh_step, dw0, dw_step;
+    int w_off0, w_step_r, w_step_s, w_row_stride;
+    int N, N_store;         // valid output channels / channels written (N rounded up to 4 inside the pitch)
+    int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
+    int accumulate;
+    int tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN, bool CIN4>
+__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArgs a) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                    // [2][BM][LDT]
+    float* sB = smem + 2 * BM * LDT;     // [2][BN][LDT]
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int v = tid & 7, r0 = tid >> 3;
+
+    // ---- per-row gather bases (fixed for the whole K loop) ----
+    int rowh[A_IT], roww[A_IT], rowpix[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int q = mm % a.Q, t = mm / a.Q;
+        const int p = t % a.P, b = t / a.P;
+        rowh[i] = ok ? p * a.in_sh : -(1 << 28);     // invalid rows fail every bounds check
+        roww[i] = q * a.in_sw;
+        rowpix[i] = b * a.IH * a.IW;
+    }
+
+    const int T = a.TR * a.TS;
+    const int nchunks = CIN4 ? (T + 7) / 8 : (a.Cin + BK - 1) / BK;
+    // ---- tap skipping: a tap whose window is out of bounds for every row of this tile is never loaded ----
+    unsigned long long tapmask = ~0ull;
+    if (!CIN4 && T > 1) {
+        tapmask = 0;
+        for (int t = 0; t < T; ++t) {
+            const int dh = a.dh0 + (t / a.TS) * a.dh_step, dw = a.dw0 + (t % a.TS) * a.dw_step;
+            int any = 0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                any |= ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);
+            if (__syncthreads_or(any)) tapmask |= 1ull << t;
+        }
+    }
+    const int ntaps = CIN4 ? 1 : __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
+    const int S = ntaps * nchunks;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[A_IT], rb[B_IT];
+    int ld_tap = -1, ld_chunk = nchunks - 1;     // position of the NEXT tile to load (advanced before use)
+
+    auto advance = [&]() {
+        if (++ld_chunk == nchunks) {
+            ld_chunk = 0;
+            if (!CIN4) {
+                do { ++ld_tap; } while (!((tapmask >> ld_tap) & 1ull));
+            }
+        }
+    };
+    auto load_tile = [&]() {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (CIN4) {
+            const int tap = ld_chunk * 8 + v;
+            const bool tok = tap < T;
+            const int dh = a.dh0 + (tap / a.TS) * a.dh_step, dw = a.dw0 + (tap % a.TS) * a.dw_step;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int hi = rowh[i] + dh, wi = roww[i] + dw;
+                const bool ok = tok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (size_t)(rowpix[i] + hi * a.IW + wi) * a.x_pitch) : zero;
+            }
+            const int kk = ld_chunk * 32 + 4 * v;
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                const bool ok = tok && n < a.N;
+                rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.w + (size_t)n * a.w_row_stride + a.w_off0 + kk) : zero;
+            }
+        } else {
+            const int tr = ld_tap / a.TS, ts = ld_tap % a.TS;
+            const int dh = a.dh0 + tr * a.dh_step, dw = a.dw0 + ts * a.dw_step;
+            const int woff = a.w_off0 + tr * a.w_step_r + ts * a.w_step_s;
+            const int c = ld_chunk * BK + 4 * v;
+            const bool cok = c < a.Cin;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int hi = rowh[i] + dh, wi = roww[i] + dw;
+                const bool ok = cok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (size_t)(rowpix[i] + hi * a.IW + wi) * a.x_pitch + c) : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                const bool ok = cok && n < a.N;
+                rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.w + (size_t)n * a.w_row_stride + woff + c) : zero;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* pa = sA + buf * BM * LDT + r0 * LDT + 4 * v;
+        float* pb = sB + buf * BN * LDT + r0 * LDT + 4 * v;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(pa + 32 * i * LDT) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(pb + 32 * i * LDT) = rb[i];
+    };
+
+    if (S > 0) {
+        advance();
+        load_tile();
+        store_tile(0);
+        __syncthreads();
+        for (int s = 0; s < S; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < S) {
+                advance();
+                load_tile();            // global loads in flight during the MFMAs below
+            }
+            // lane l supplies A[row = l&31][k = 8g + 4(l>>5) + j] to MFMA (g, j): one ds_read_b128 feeds 4 MFMAs
+            const float* pa = sA + buf * BM * LDT + (wave_m * WM + (lane & 31)) * LDT + 4 * (lane >> 5);
+            const float* pb = sB + buf * BN * LDT + (wave_n * WN + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(pa + i * 32 * LDT + 8 * g);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(pb + j * 32 * LDT + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
+            if (s + 1 < S) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: per-row output offsets through LDS, then 128-B coalesced row segments per half-wave ----
+    long long* rowoff = reinterpret_cast<long long*>(smem);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < a.M) {
+            const int q = m % a.Q, t = m / a.Q;
+            const int p = t % a.P, b = t / a.P;
+            off = ((long long)(b * a.OH + p * a.out_sh + a.oh0) * a.OW + q * a.out_sw + a.ow0) * a.y_pitch;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
+        if (n >= a.N_store) continue;
+        const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long off = rowoff[row];
+                if (off >= 0) {
+                    float val = acc[i][j][r] + bv;
+                    float* dst = a.y + off + n;
+                    if (a.accumulate) val += *dst;
+                    *dst = val;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// wgrad
+// -------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* out;             // dw, or split-K slab base
+    int M, P, Q;            // pixels of dy (dense, pitch dy_pitch)
+    int IH, IW, Cin, x_pitch, in_sh, in_sw;
+    int TR, TS, dh0, dh_step, dw0, dw_step;
+    int N, N_ld, dy_pitch;  // N valid couts; N_ld = couts readable from dy (rounded up to 4)
+    int out_row_stride;     // floats between couts in dw = T*Cin
+    int tiles_n, tiles_c;   // tiles over cout / (cin or taps*4)
+    int splits, m_per_split;
+    long long slab_stride;
+};
+
+template <int BN, int BC, int WN, int WC, bool CIN4>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int WAVES_C = BC / WC;
+    constexpr int NT = WN / 32, CT = WC / 32;
+    constexpr int VA = BN / 4, RA = 256 / VA, IA = 32 / RA;      // dy tile loader geometry
+    constexpr int VB = BC / 4, RB = 256 / VB, IB = 32 / RB;      // x tile loader geometry
+    static_assert((BN / WN) * (BC / WC) == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                  // [2][32][BN]  dy tile, pixel-major
+    float* sB = smem + 2 * 32 * BN;    // [2][32][BC]  gathered x tile, pixel-major
+
+    const int T = a.TR * a.TS;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = id % a.tiles_c; id /= a.tiles_c;
+    const int tn = id % a.tiles_n; id /= a.tiles_n;
+    int tap = 0;
+    if (!CIN4) { tap = id % T; id /= T; }
+    const int split = id;
+    const int n0 = tn * BN, c0 = tc * BC;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const int S = (m_end - m_begin + 31) / 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int va = tid % VA, pra = tid / VA;
+    const int vb = tid % VB, prb = tid / VB;
+
+    int dh = 0, dw = 0;
+    if (!CIN4) {
+        dh = a.dh0 + (tap / a.TS) * a.dh_step;
+        dw = a.dw0 + (tap % a.TS) * a.dw_step;
+    } else {
+        const int t = c0 / 4 + vb;           // CIN4: tile columns are (tap, 4 channels)
+        dh = a.dh0 + (t / a.TS) * a.dh_step;
+        dw = a.dw0 + (t % a.TS) * a.dw_step;
+    }
+    const bool b_col_ok = CIN4 ? (c0 / 4 + vb < T) : (c0 + 4 * vb < a.Cin);
+    const bool a_col_ok = n0 + 4 * va < a.N_ld;
+
+    f32x16 acc[NT][CT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[IA], rb[IB];
+    auto load_tile = [&](int s) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const int mb = m_begin + s * 32;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int m = mb + pra + RA * i;
+            const bool ok = a_col_ok && m < m_end;
+            ra[i] = ok ? *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.dy_pitch + n0 + 4 * va) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int m = mb + prb + RB * i;
+            bool ok = b_col_ok && m < m_end;
+            const int mm = ok ? m : 0;
+            const int q = mm % a.Q, t = mm / a.Q;
+            const int p = t % a.P, b = t / a.P;
+            const int hi = p * a.in_sh + dh, wi = q * a.in_sw + dw;
+            ok = ok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+            const size_t off = (size_t)((b * a.IH + hi) * a.IW + wi) * a.x_pitch + (CIN4 ? 0 : c0 + 4 * vb);
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + off) : zero;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) *reinterpret_cast<f32x4*>(sA + buf * 32 * BN + (pra + RA * i) * BN + 4 * va) = ra[i];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) *reinterpret_cast<f32x4*>(sB + buf * 32 * BC + (prb + RB * i) * BC + 4 * vb) = rb[i];
+    };
+
+    if (S > 0) {
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int s = 0; s < S; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < S) load_tile(s + 1);
+            // A[i = cout][k = pixel], B[k = pixel][j = cin]: lane l reads pixel row k = 2*ks + (l>>5), column l&31
+            const float* pa = sA + buf * 32 * BN + (lane >> 5) * BN + wave_n * WN + (lane & 31);
+            const float* pb = sB + buf * 32 * BC + (lane >> 5) * BC + wave_c * WC + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                float fa[NT], fb[CT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) fa[i] = pa[2 * ks * BN + 32 * i];
+#pragma unroll
+                for (int j = 0; j < CT; ++j) fb[j] = pb[2 * ks * BC + 32 * j];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (s + 1 < S) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float* out = a.out + (size_t)split * a.slab_stride;
+    const int col_limit = CIN4 ? T * 4 : a.Cin;
+    const int col_base = CIN4 ? 0 : tap * a.Cin;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int c = c0 + wave_c * WC + j * 32 + (lane & 31);
+        if (c >= col_limit) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wave_n * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// dw[i] = sum_s slab[s][i] in a fixed order (deterministic).
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n4,
+                                     int splits, long long slab_stride) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
+        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_stride + 4 * i);
+        *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
+    }
+}
+
+// [K][RS][C] -> [C][RS][Kp] with Kp = roundup4(K), zero-filled pad (dgrad reads Kp-wide vectors).
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C, int Kp) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        tile[i][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (c < C && k < Kp) wt[((size_t)c * RS + rs) * Kp + k] = tile[tx][i];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+constexpr size_t gg_smem() { return (size_t)2 * (BM + BN) * LDT * sizeof(float); }
+template <int BN, int BC>
+constexpr size_t wg_smem() { return (size_t)2 * 32 * (BN + BC) * sizeof(float); }
+
+template <int BM, int BN, int WM, int WN, bool CIN4>
+static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
+    const int tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.N_store, BN);
+    const long long grid = (long long)tiles_m * a.tiles_n;
+    PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
+    const size_t lds = gg_smem<BM, BN>();
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+static int dispatch_gg(GatherGemmArgs& a, bool cin4, hipStream_t st) {
+    if (cin4) {
+        if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, true>(a, st);
+        if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, true>(a, st);
+        return launch_gg<128, 128, 64, 64, true>(a, st);
+    }
+    if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false>(a, st);
+    if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false>(a, st);
+    return launch_gg<128, 128, 64, 64, false>(a, st);
+}
+
+template <typename K>
+static hipError_t opt_in_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int conv_init() {
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 128, 64, 64, false>, gg_smem<128, 128>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 128, 64, 64, true>, gg_smem<128, 128>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 64, 64, 64, false>, gg_smem<256, 64>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 64, 64, 64, true>, gg_smem<256, 64>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 32, 32, 32, false>, gg_smem<128, 32>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 32, 32, 32, true>, gg_smem<128, 32>()));
+    PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
+    PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
+    PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
+    PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, true>, wg_smem<64, 64>()));
+    return PYLC_OK;
+}
+
+static int check_desc(const PylcConvDesc* d) {
+    PYLC_REQUIRE(d != nullptr, "null conv descriptor");
+    PYLC_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "non-positive conv dims");
+    PYLC_REQUIRE(d->R > 0 && d->S > 0 && d->R * d->S <= 64, "kernel window %dx%d unsupported (<= 64 taps)", d->R, d->S);
+    PYLC_REQUIRE(d->stride == 1 || d->stride == 2, "stride %d unsupported (1 or 2)", d->stride);
+    PYLC_REQUIRE(d->dil >= 1 && d->pad >= 0, "bad dilation/padding");
+    PYLC_REQUIRE(d->Cin % 4 == 0, "Cin=%d must be a multiple of 4 (pad images with pylc_image_pack)", d->Cin);
+    PYLC_REQUIRE(d->x_pitch >= d->Cin && d->x_pitch % 4 == 0, "x_pitch=%d invalid for Cin=%d", d->x_pitch, d->Cin);
+    PYLC_REQUIRE(d->y_pitch >= d->Cout && d->y_pitch % 4 == 0, "y_pitch=%d invalid for Cout=%d", d->y_pitch, d->Cout);
+    const int oh = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    const int ow = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    PYLC_REQUIRE(oh == d->OH && ow == d->OW && oh > 0 && ow > 0, "OH/OW (%d,%d) inconsistent with geometry (%d,%d)", d->OH, d->OW, oh, ow);
+    PYLC_REQUIRE((long long)d->B * d->H * d->W * d->x_pitch < (1ll << 31) && (long long)d->B * d->OH * d->OW * d->y_pitch < (1ll << 31),
+                 "tensor exceeds 2^31 elements");
+    return PYLC_OK;
+}
+
+static inline int roundup4(int v) { return (v + 3) & ~3; }
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    PYLC_REQUIRE(x && w && y, "null pointer");
+    GatherGemmArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
+    a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
+    a.in_sh = a.in_sw = d->stride;
+    a.TR = d->R; a.TS = d->S;
+    a.dh0 = -d->pad; a.dh_step = d->dil; a.dw0 = -d->pad; a.dw_step = d->dil;
+    a.w_off0 = 0; a.w_step_r = d->S * d->Cin; a.w_step_s = d->Cin; a.w_row_stride = d->R * d->S * d->Cin;
+    a.N = d->Cout; a.N_store = roundup4(d->Cout) <= d->y_pitch ? roundup4(d->Cout) : d->Cout;
+    a.OH = d->OH; a.OW = d->OW; a.out_sh = a.out_sw = 1; a.oh0 = a.ow0 = 0; a.y_pitch = d->y_pitch;
+    a.accumulate = 0;
+    const bool cin4 = d->Cin == 4 && d->R * d->S > 1;
+    return dispatch_gg(a, cin4, as_stream(stream));
+}
+
+extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    PYLC_REQUIRE(dy && w_crsk && dx, "null pointer");
+    hipStream_t st = as_stream(stream);
+    const int Kp = roundup4(d->Cout);       // reduction runs over output channels, padded to 4 (zero weights / zero dy)
+    PYLC_REQUIRE(Kp <= d->y_pitch, "dy pitch %d must cover roundup4(Cout)=%d", d->y_pitch, Kp);
+    GatherGemmArgs a{};
+    a.x = dy; a.w = w_crsk; a.bias = nullptr; a.y = dx;
+    a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
+    a.N = d->Cin; a.N_store = d->Cin;
+    a.OH = d->H; a.OW = d->W; a.y_pitch = d->x_pitch;
+    a.w_row_stride = d->R * d->S * Kp;
+    a.accumulate = accumulate;
+    if (d->stride == 1) {
+        a.P = d->H; a.Q = d->W; a.M = d->B * d->H * d->W;
+        a.in_sh = a.in_sw = 1;
+        a.TR = d->R; a.TS = d->S;
+        a.dh0 = d->pad; a.dh_step = -d->dil; a.dw0 = d->pad; a.dw_step = -d->dil;     // ho = hi + pad - r*dil
+        a.w_off0 = 0; a.w_step_r = d->S * Kp; a.w_step_s = Kp;
+        a.out_sh = a.out_sw = 1; a.oh0 = a.ow0 = 0;
+        return dispatch_gg(a, false, st);
+    }
+    // stride 2: dx pixels of parity class (ph, pw) receive only taps with (ph + pad - r*dil) even.
+    // Each class is a dense gather-GEMM over its own tap progression; classes with no taps are zero.
+    bool need_zero = false;
+    int cnt_r[2] = {0, 0}, first_r[2] = {-1, -1}, cnt_s[2] = {0, 0}, first_s[2] = {-1, -1};
+    for (int ph = 0; ph < 2; ++ph) {
+        for (int r = 0; r < d->R; ++r)
+            if (((ph + d->pad - r * d->dil) & 1) == 0) { if (first_r[ph] < 0) first_r[ph] = r; ++cnt_r[ph]; }
+        for (int s = 0; s < d->S; ++s)
+            if (((ph + d->pad - s * d->dil) & 1) == 0) { if (first_s[ph] < 0) first_s[ph] = s; ++cnt_s[ph]; }
+    }
+    const int step = (d->dil & 1) ? 2 : 1;      // valid taps are every 2nd (odd dilation) or all/none (even dilation)
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw)
+            if (cnt_r[ph] == 0 || cnt_s[pw] == 0) need_zero = true;
+    PYLC_REQUIRE(!(need_zero && !accumulate) || d->x_pitch == d->Cin, "strided dgrad with empty parity classes needs a dense dx");
+    if (need_zero && !accumulate)
+        PYLC_HIP(hipMemsetAsync(dx, 0, (size_t)d->B * d->H * d->W * d->x_pitch * sizeof(float), st));
+    for (int ph = 0; ph < 2; ++ph) {
+        for (int pw = 0; pw < 2; ++pw) {
+            if (cnt_r[ph] == 0 || cnt_s[pw] == 0) continue;
+            GatherGemmArgs c = a;
+            c.P = (d->H - ph + 1) / 2; c.Q = (d->W - pw + 1) / 2;
+            if (c.P <= 0 || c.Q <= 0) continue;
+            c.M = d->B * c.P * c.Q;
+            c.in_sh = c.in_sw = 1;
+            c.TR = cnt_r[ph]; c.TS = cnt_s[pw];
+            // ho = (2*hq + ph + pad - r*dil)/2 = hq + (ph + pad - r*dil)/2, r = first + step*i
+            c.dh0 = (ph + d->pad - first_r[ph] * d->dil) / 2; c.dh_step = -(step * d->dil) / 2;
+            c.dw0 = (pw + d->pad - first_s[pw] * d->dil) / 2; c.dw_step = -(step * d->dil) / 2;
+            c.w_off0 = (first_r[ph] * d->S + first_s[pw]) * Kp; c.w_step_r = step * d->S * Kp; c.w_step_s = step * Kp;
+            c.out_sh = c.out_sw = 2; c.oh0 = ph; c.ow0 = pw;
+            if (int rc = dispatch_gg(c, false, st)) return rc;
+        }
+    }
+    return PYLC_OK;
+}
+
+namespace {
+struct WgradPlan { int cfg; int tiles_n, tiles_c, splits, m_per_split; long long slab; bool cin4; };
+// cfg 0: 128x128, 1: 64x64, 2: 32(cout)x128(cin), 3: cin4 64x64
+WgradPlan plan_wgrad(const PylcConvDesc* d) {
+    WgradPlan p{};
+    const int T = d->R * d->S;
+    const long long M = (long long)d->B * d->OH * d->OW;
+    p.cin4 = d->Cin == 4 && T > 1;
+    int bn, bc;
+    if (p.cin4) { p.cfg = 3; bn = 64; bc = 64; }
+    else if (d->Cout <= 32) { p.cfg = 2; bn = 32; bc = 128; }
+    else if (d->Cout <= 64 || d->Cin <= 64) { p.cfg = 1; bn = 64; bc = 64; }
+    else { p.cfg = 0; bn = 128; bc = 128; }
+    p.tiles_n = cdiv(d->Cout, bn);
+    p.tiles_c = p.cin4 ? cdiv(T * 4, bc) : cdiv(d->Cin, bc);
+    const long long tiles = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T);
+    // enough blocks for ~3 per CU, at least 16 K-steps (512 pixels) per block
+    long long want = cdiv<long long>(3 * kNumCU, tiles);
+    long long max_splits = cdiv<long long>(M, 512);
+    long long s = want < 1 ? 1 : want;
+    if (s > max_splits) s = max_splits;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    long long mps = cdiv<long long>(cdiv<long long>(M, s), 32) * 32;
+    s = cdiv<long long>(M, mps);
+    p.splits = (int)s; p.m_per_split = (int)mps;
+    p.slab = (long long)d->Cout * T * d->Cin;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d) {
+    if (check_desc(d)) return 0;
+    WgradPlan p = plan_wgrad(d);
+    return p.splits > 1 ? (size_t)p.splits * p.slab * sizeof(float) : 0;
+}
+
+template <int BN, int BC, int WN, int WC, bool CIN4>
+static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
+    PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
+    const size_t lds = wg_smem<BN, BC>();
+    hipLaunchKernelGGL((wgrad_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    PYLC_REQUIRE(x && dy && dw, "null pointer");
+    PYLC_REQUIRE(dbias == nullptr, "dbias: use pylc_bn_stats on dy (column sums)");
+    hipStream_t st = as_stream(stream);
+    const WgradPlan p = plan_wgrad(d);
+    const size_t need = p.splits > 1 ? (size_t)p.splits * p.slab * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace))
+        return fail(PYLC_ERR_WORKSPACE, "wgrad workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    PYLC_REQUIRE(p.slab % 4 == 0, "dw size must be a multiple of 4");
+    const int T = d->R * d->S;
+    WgradArgs a{};
+    a.x = x; a.dy = dy; a.out = p.splits > 1 ? static_cast<float*>(workspace) : dw;
+    a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
+    a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch; a.in_sh = a.in_sw = d->stride;
+    a.TR = d->R; a.TS = d->S; a.dh0 = -d->pad; a.dh_step = d->dil; a.dw0 = -d->pad; a.dw_step = d->dil;
+    a.N = d->Cout; a.N_ld = roundup4(d->Cout); a.dy_pitch = d->y_pitch;
+    PYLC_REQUIRE(a.N_ld <= d->y_pitch, "dy pitch must cover roundup4(Cout)");
+    a.out_row_stride = T * d->Cin;
+    a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c; a.splits = p.splits; a.m_per_split = p.m_per_split;
+    a.slab_stride = p.slab;
+    const long long grid = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T) * p.splits;
+    int rc;
+    switch (p.cfg) {
+        case 0: rc = launch_wg<128, 128, 64, 64, false>(a, grid, st); break;
+        case 1: rc = launch_wg<64, 64, 32, 32, false>(a, grid, st); break;
+        case 2: rc = launch_wg<32, 128, 32, 32, false>(a, grid, st); break;
+        default: rc = launch_wg<64, 64, 32, 32, true>(a, grid, st); break;
+    }
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const long long n4 = p.slab / 4;
+        const int blocks = (int)(cdiv<long long>(n4, 256) < 2048 ? cdiv<long long>(n4, 256) : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4,
+                           p.splits, p.slab);
+        PYLC_LAUNCH_CHECK();
+    }
+    return PYLC_OK;
+}
+
+extern "C" int pylc_weight_transpose(const float* w, float* wt, int K, int RS, int C, void* stream) {
+    PYLC_REQUIRE(w && wt && K > 0 && RS > 0 && C > 0, "bad weight_transpose arguments");
+    const int Kp = roundup4(K);
+    dim3 grid(cdiv(C, 32), cdiv(Kp, 32), RS);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, as_stream(stream), w, wt, K, RS, C, Kp);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

@@ -1,0 +1,197 @@
+// Depthwise 3x3 convolution (groups = C) for the Aligned-Xception separable convs, NHWC fp32.
+// HBM-bound (9 MACs per element): no MFMA.  A thread owns one float4 channel vector, keeps its 36 filter
+// taps in registers and walks output pixels of a row slab; the explicit TF-'SAME' padding of
+// fixed_padding (models/backbone/xception.py:16-22; for k = 3: pad_beg = pad_end = dilation) is folded
+// into the index math instead of materialising a padded tensor.
+// Replaces F.pad + nn.Conv2d(groups=C) at xception.py:29-31,35-36 and their backward.
+#include "common.h"
+#include "slab.h"
+
+namespace pylc {
+
+struct DwGeom { int B, H, W, C, stride, dil, OH, OW, x_pitch, y_pitch; };
+
+// w is [C][9]; gather the 9 taps of channels 4cv..4cv+3 into 9 float4 registers
+__device__ __forceinline__ void load_taps(const float* __restrict__ w, int cv, f32x4 (&k)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        k[t].x = w[(4 * cv + 0) * 9 + t]; k[t].y = w[(4 * cv + 1) * 9 + t];
+        k[t].z = w[(4 * cv + 2) * 9 + t]; k[t].w = w[(4 * cv + 3) * 9 + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, DwGeom d,
+                                                     Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        f32x4 k[9];
+        load_taps(w, cv, k);
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            const int ow = (int)(r % d.OW);
+            const long long t = r / d.OW;
+            const int oh = (int)(t % d.OH), b = (int)(t / d.OH);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kr = 0; kr < 3; ++kr) {
+                const int h = oh * d.stride + (kr - 1) * d.dil;
+                if ((unsigned)h >= (unsigned)d.H) continue;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int ww = ow * d.stride + (ks - 1) * d.dil;
+                    if ((unsigned)ww >= (unsigned)d.W) continue;
+                    acc += k[kr * 3 + ks] * ld4(x + ((size_t)(b * d.H + h) * d.W + ww) * d.x_pitch + 4 * cv);
+                }
+            }
+            st4(y + r * d.y_pitch + 4 * cv, acc);
+        }
+    }
+}
+
+// dx[b,h,w,c] = sum_{r,s} dy[b, (h + dil - r*dil)/stride, (w + dil - s*dil)/stride, c] * k[c][r][s]   (where divisible)
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, DwGeom d,
+                                                       Slab g) {
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    if (ty >= g.RL) return;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cv = tx; cv < g.CV; cv += g.cols) {
+        f32x4 k[9];
+        load_taps(w, cv, k);
+        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+            const int wi = (int)(r % d.W);
+            const long long t = r / d.W;
+            const int hi = (int)(t % d.H), b = (int)(t / d.H);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kr = 0; kr < 3; ++kr) {
+                const int hn = hi - (kr - 1) * d.dil;
+                if (hn < 0 || hn % d.stride != 0) continue;
+                const int oh = hn / d.stride;
+                if (oh >= d.OH) continue;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int wn = wi - (ks - 1) * d.dil;
+                    if (wn < 0 || wn % d.stride != 0) continue;
+                    const int ow = wn / d.stride;
+                    if (ow >= d.OW) continue;
+                    acc += k[kr * 3 + ks] * ld4(dy + ((size_t)(b * d.OH + oh) * d.OW + ow) * d.y_pitch + 4 * cv);
+                }
+            }
+            st4(dx + r * d.x_pitch + 4 * cv, acc);
+        }
+    }
+}
+
+// partial[slab][9][C]
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                       DwGeom d, Slab g) {
+    __shared__ f32x4 red[256];
+    const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
+    const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
+    long long r_end = r_begin + g.rows_per_slab;
+    if (r_end > g.M) r_end = g.M;
+    for (int cb = 0; cb < g.CV; cb += g.cols) {
+        const int cv = cb + tx;
+        const bool active = ty < g.RL && cv < g.CV;
+        f32x4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+                const int ow = (int)(r % d.OW);
+                const long long t = r / d.OW;
+                const int oh = (int)(t % d.OH), b = (int)(t / d.OH);
+                const f32x4 gy = ld4(dy + r * d.y_pitch + 4 * cv);
+#pragma unroll
+                for (int kr = 0; kr < 3; ++kr) {
+                    const int h = oh * d.stride + (kr - 1) * d.dil;
+                    if ((unsigned)h >= (unsigned)d.H) continue;
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const int ww = ow * d.stride + (ks - 1) * d.dil;
+                        if ((unsigned)ww >= (unsigned)d.W) continue;
+                        acc[kr * 3 + ks] += gy * ld4(x + ((size_t)(b * d.H + h) * d.W + ww) * d.x_pitch + 4 * cv);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            red[threadIdx.x] = acc[t];
+            __syncthreads();
+            if (ty == 0 && cv < g.CV) {
+                f32x4 s = acc[t];
+                for (int k = 1; k < g.RL; ++k) s += red[k * g.cols + tx];
+                st4(partial + ((size_t)blockIdx.x * 9 + t) * d.C + 4 * cv, s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// dw[c][t] = sum_slab partial[slab][t][c]
+__global__ void dw_wgrad_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 9*C, i = t*C + c
+    if (i >= 9 * C) return;
+    double acc = 0.0;
+    for (int s = 0; s < nslab; ++s) acc += (double)partial[(size_t)s * 9 * C + i];
+    const int t = i / C, c = i % C;
+    dw[c * 9 + t] = (float)acc;
+}
+
+static int check_dw(const PylcDwDesc* d) {
+    PYLC_REQUIRE(d != nullptr, "null depthwise descriptor");
+    PYLC_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 4 == 0, "dwconv: bad dims");
+    PYLC_REQUIRE((d->stride == 1 || d->stride == 2) && d->dil >= 1, "dwconv: stride 1|2, dil >= 1");
+    PYLC_REQUIRE(d->OH == (d->H - 1) / d->stride + 1 && d->OW == (d->W - 1) / d->stride + 1, "dwconv: OH/OW must be (H-1)/stride+1");
+    PYLC_REQUIRE(d->x_pitch >= d->C && d->y_pitch >= d->C && d->x_pitch % 4 == 0 && d->y_pitch % 4 == 0, "dwconv: bad pitch");
+    return PYLC_OK;
+}
+static DwGeom geom(const PylcDwDesc* d) { return DwGeom{d->B, d->H, d->W, d->C, d->stride, d->dil, d->OH, d->OW, d->x_pitch, d->y_pitch}; }
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const float* w, float* y, void* stream) {
+    if (int rc = check_dw(d)) return rc;
+    PYLC_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
+    const Slab g = make_slab((long long)d->B * d->OH * d->OW, d->C);
+    hipLaunchKernelGGL(dw_fwd_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), x, w, y, geom(d), g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream) {
+    if (int rc = check_dw(d)) return rc;
+    PYLC_REQUIRE(dy && w && dx, "dwconv_dgrad: null pointer");
+    const Slab g = make_slab((long long)d->B * d->H * d->W, d->C);
+    hipLaunchKernelGGL(dw_dgrad_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" size_t pylc_dwconv3x3_wgrad_workspace(const PylcDwDesc* d) {
+    if (check_dw(d)) return 0;
+    return (size_t)kMaxSlabs * 9 * (size_t)d->C * sizeof(float);
+}
+
+extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    if (int rc = check_dw(d)) return rc;
+    PYLC_REQUIRE(x && dy && dw && workspace, "dwconv_wgrad: null pointer");
+    const Slab g = make_slab((long long)d->B * d->OH * d->OW, d->C);
+    if ((size_t)g.nslab * 9 * d->C * sizeof(float) > workspace_bytes)
+        return fail(PYLC_ERR_WORKSPACE, "dwconv_wgrad workspace too small");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(g.nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), g);
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dw_wgrad_combine_kernel, dim3(cdiv(9 * d->C, 256)), dim3(256), 0, st, static_cast<const float*>(workspace), g.nslab, d->C, dw);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

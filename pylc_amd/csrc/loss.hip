@@ -1,0 +1,202 @@
+// Fused MultiLoss head: weighted/unweighted cross-entropy + Dice + Focal in ONE per-pixel pass forward
+// (3 + 3C partial sums) and ONE per-pixel pass backward (closed form).
+//
+// Replaces models/modules/loss.py: ce_loss :66-69, dice_loss :137-146, focal_loss :174-189, forward :107-112
+// (the reference runs 3 softmaxes + 2 one-hots + ~20 elementwise passes over B*C*H*W).
+// logits are NHWC [N pixels][pitch]; one thread owns one pixel (its C logits are contiguous).
+#include "common.h"
+
+namespace pylc {
+
+constexpr int MAXC = PYLC_MAX_CLASSES;
+constexpr float kFlAlpha = 0.25f;   // config.py:207
+constexpr float kFlEps = 1e-8f;     // loss.py:50
+constexpr float kDiceSmooth = 1.f;  // config.py:204
+constexpr int kLossBlocks = 1024;
+
+template <int C>
+__device__ __forceinline__ void softmax_px(const float* __restrict__ z, float (&p)[C], float& lse) {
+    float zmax = z[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) zmax = fmaxf(zmax, z[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - zmax); sum += p[c]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+    lse = zmax + logf(sum);
+}
+
+// partial[block][3 + 3C]
+template <int C>
+__global__ __launch_bounds__(256) void multiloss_stats_kernel(const float* __restrict__ logits, int pitch, const long long* __restrict__ target,
+                                                              long long N, const float* __restrict__ cw, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc[3 + 3 * C];
+#pragma unroll
+    for (int k = 0; k < 3 + 3 * C; ++k) acc[k] = 0.f;
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+        float z[C], p[C], lse;
+        const float* src = logits + n * pitch;
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = src[c];
+        softmax_px<C>(z, p, lse);
+        const int t = (int)target[n];
+        float zt = 0.f, pt = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const bool is = (c == t);
+            zt = is ? z[c] : zt;
+            pt = is ? p[c] : pt;
+            acc[3 + c] += is ? p[c] : 0.f;        // I_c
+            acc[3 + C + c] += p[c];               // sum p_c
+            acc[3 + 2 * C + c] += is ? 1.f : 0.f; // count_c
+        }
+        const float w = cw != nullptr ? cw[t] : 1.f;
+        acc[0] += w * (lse - zt);                 // -log p_t via log-sum-exp (exact for saturated pixels)
+        acc[1] += w;
+        const float q = pt + kFlEps;
+        const float omq = 1.f - q;
+        acc[2] += -kFlAlpha * omq * omq * logf(q);
+    }
+    float* dst = partial + (size_t)blockIdx.x * (3 + 3 * C);
+#pragma unroll
+    for (int k = 0; k < 3 + 3 * C; ++k) {
+        const float s = block_sum_256(acc[k], red);
+        if (threadIdx.x == 0) dst[k] = s;
+    }
+}
+
+__global__ void multiloss_combine_kernel(const float* __restrict__ partial, int nblocks, int K, float* __restrict__ stats) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double acc = 0.0;
+    for (int b = 0; b < nblocks; ++b) acc += (double)partial[(size_t)b * K + k];
+    stats[k] = (float)acc;
+}
+
+__global__ void multiloss_finalize_kernel(const float* __restrict__ stats, double n, int C, float w_ce, float w_d, float w_f,
+                                          float* __restrict__ losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double ce = (double)stats[0] / (double)stats[1];
+    const double fl = (double)stats[2] / n;
+    double dsc = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const double I = stats[3 + c], K = (double)stats[3 + C + c] + (double)stats[3 + 2 * C + c];
+        dsc += 1.0 - (2.0 * I + kDiceSmooth) / (K + kDiceSmooth);
+    }
+    dsc /= C;
+    losses[0] = (float)(w_ce * ce + w_d * dsc + w_f * fl);
+    losses[1] = (float)ce;
+    losses[2] = (float)dsc;
+    losses[3] = (float)fl;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void multiloss_bwd_kernel(const float* __restrict__ logits, int pitch, const long long* __restrict__ target,
+                                                            long long N, const float* __restrict__ cw, const float* __restrict__ stats,
+                                                            float inv_n, float w_ce, float w_d, float w_f,
+                                                            const float* __restrict__ grad_scale, float* __restrict__ dlogits, int dpitch,
+                                                            int Cstore) {
+    // per-class Dice coefficients: dL_d/dp_c(n) = -[2 o_c (K_c + s) - (2 I_c + s)] / (K_c + s)^2 / C = o_c * A_c + B_c
+    float dA[C], dB[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float I = stats[3 + c], K = stats[3 + C + c] + stats[3 + 2 * C + c];
+        const float den = K + kDiceSmooth;
+        dA[c] = -2.f / den / (float)C;
+        dB[c] = (2.f * I + kDiceSmooth) / (den * den) / (float)C;
+    }
+    const float gs = grad_scale != nullptr ? grad_scale[0] : 1.f;
+    const float ce_norm = w_ce / stats[1];     // unweighted: stats[1] = N
+    for (long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long long)gridDim.x * blockDim.x) {
+        float z[C], p[C], lse;
+        const float* src = logits + n * pitch;
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = src[c];
+        softmax_px<C>(z, p, lse);
+        const int t = (int)target[n];
+        float pt = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) pt = (c == t) ? p[c] : pt;
+        const float w = cw != nullptr ? cw[t] : 1.f;
+        // focal: f'(q) = alpha*gamma*(1-q)*log q - alpha*(1-q)^2/q, dq/dz_c = p_t (o_c - p_c)
+        const float q = pt + kFlEps, omq = 1.f - q;
+        const float fprime = kFlAlpha * 2.f * omq * logf(q) - kFlAlpha * omq * omq / q;
+        const float fcoef = w_f * inv_n * fprime * pt;
+        // dice through softmax: p_c (g_c - sum_k g_k p_k)
+        float gdot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) gdot += ((c == t ? dA[c] : 0.f) + dB[c]) * p[c];
+        float* dst = dlogits + n * dpitch;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float o = (c == t) ? 1.f : 0.f;
+            const float gc = (c == t ? dA[c] : 0.f) + dB[c];
+            const float d = ce_norm * w * (p[c] - o) + w_d * p[c] * (gc - gdot) + fcoef * (o - p[c]);
+            dst[c] = gs * d;
+        }
+        for (int c = C; c < Cstore; ++c) dst[c] = 0.f;     // channel padding up to the pitch stays zero
+    }
+}
+
+#define PYLC_FOR_C(MACRO)                                                                                              \
+    switch (C) {                                                                                                       \
+        case 2: MACRO(2); break; case 3: MACRO(3); break; case 4: MACRO(4); break; case 5: MACRO(5); break;           \
+        case 6: MACRO(6); break; case 7: MACRO(7); break; case 8: MACRO(8); break; case 9: MACRO(9); break;           \
+        case 10: MACRO(10); break; case 11: MACRO(11); break; case 12: MACRO(12); break; case 13: MACRO(13); break;   \
+        case 14: MACRO(14); break; case 15: MACRO(15); break; case 16: MACRO(16); break;                              \
+        default: return fail(PYLC_ERR_ARG, "multiloss: n_classes=%d unsupported (2..%d)", C, MAXC);                   \
+    }
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" size_t pylc_multiloss_workspace_floats(long long N, int C) {
+    (void)N;
+    return (size_t)kLossBlocks * (3 + 3 * (size_t)C);
+}
+
+extern "C" int pylc_multiloss_stats(const float* logits, int pitch, const int64_t* target, long long N, int C, const float* cw, float* stats,
+                                    float* workspace, void* stream) {
+    PYLC_REQUIRE(logits && target && stats && workspace && N > 0 && pitch >= C, "multiloss_stats: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const int blocks = (int)(cdiv<long long>(N, 256) < kLossBlocks ? cdiv<long long>(N, 256) : kLossBlocks);
+    const long long* tgt = reinterpret_cast<const long long*>(target);
+#define LAUNCH_STATS(CC) hipLaunchKernelGGL((multiloss_stats_kernel<CC>), dim3(blocks), dim3(256), 0, st, logits, pitch, tgt, N, cw, workspace)
+    PYLC_FOR_C(LAUNCH_STATS)
+#undef LAUNCH_STATS
+    PYLC_LAUNCH_CHECK();
+    const int K = 3 + 3 * C;
+    hipLaunchKernelGGL(multiloss_combine_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, K, stats);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_multiloss_finalize(const float* stats, double n_global, int C, float w_ce, float w_dice, float w_focal, float* losses,
+                                       void* stream) {
+    PYLC_REQUIRE(stats && losses && n_global > 0 && C >= 2 && C <= MAXC, "multiloss_finalize: bad arguments");
+    hipLaunchKernelGGL(multiloss_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), stats, n_global, C, w_ce, w_dice, w_focal, losses);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_multiloss_bwd(const float* logits, int pitch, const int64_t* target, long long N, int C, const float* cw,
+                                  const float* stats, double n_global, float w_ce, float w_dice, float w_focal, const float* grad_scale,
+                                  float* dlogits, int dpitch, void* stream) {
+    PYLC_REQUIRE(logits && target && stats && dlogits && N > 0 && pitch >= C && dpitch >= C && n_global > 0, "multiloss_bwd: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const int blocks = (int)(cdiv<long long>(N, 256) < 4096 ? cdiv<long long>(N, 256) : 4096);
+    const long long* tgt = reinterpret_cast<const long long*>(target);
+    const int Cstore = ((C + 3) & ~3) <= dpitch ? ((C + 3) & ~3) : C;
+    const float inv_n = (float)(1.0 / n_global);
+#define LAUNCH_BWD(CC)                                                                                                                    \
+    hipLaunchKernelGGL((multiloss_bwd_kernel<CC>), dim3(blocks), dim3(256), 0, st, logits, pitch, tgt, N, cw, stats, inv_n, w_ce, w_dice, \
+                       w_focal, grad_scale, dlogits, dpitch, Cstore)
+    PYLC_FOR_C(LAUNCH_BWD)
+#undef LAUNCH_BWD
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

@@ -1,0 +1,127 @@
+// Global-norm gradient clipping + AdamW / SGD over ONE flat fp32 parameter arena (HBM-bound, 16-B vectors).
+// Replaces torch.nn.utils.clip_grad_norm_(net.parameters(), 0.5) models/model.py:326 and
+// torch.optim.AdamW / SGD models/model.py:240-251 (341 small per-tensor launches -> 3 launches).
+#include "common.h"
+
+namespace pylc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kNormBlocks = 1024;
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const long long n4 = n / 4;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) { const float v = g[4 * n4 + threadIdx.x]; s += v * v; }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void norm_clip_finalize_kernel(const float* __restrict__ partial, int nblocks, float max_norm, float* __restrict__ out2) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0]);
+        float coef = max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_: clamp(max_norm/(total+1e-6), max=1)
+        out2[0] = total;
+        out2[1] = coef < 1.f ? coef : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, const float* __restrict__ coef, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const float c = coef != nullptr ? coef[1] : 1.f;
+    const long long n4 = n / 4;
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i) * c;
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + 4 * i), vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+        pp *= (1.f - lr * wd);                         // decoupled weight decay
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+        f32x4 den;
+        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+        pp -= step_size * (mm / den);
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+        const long long i = 4 * n4 + threadIdx.x;
+        const float gg = g[i] * c;
+        float pp = p[i] * (1.f - lr * wd);
+        const float mm = b1 * m[i] + (1.f - b1) * gg;
+        const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        pp -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
+                                                  const float* __restrict__ coef, float lr, float mu, int first) {
+    const float c = coef != nullptr ? coef[1] : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * c;
+        const float b = first ? gg : mu * buf[i] + gg;     // torch SGD: buf = g on the first step
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" size_t pylc_sqnorm_workspace_floats(long long n) {
+    (void)n;
+    return kNormBlocks;
+}
+
+extern "C" int pylc_grad_norm_clip(const float* g, long long n, float max_norm, float* out2, float* workspace, void* stream) {
+    PYLC_REQUIRE(g && out2 && workspace && n > 0, "grad_norm_clip: bad arguments");
+    PYLC_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "grad_norm_clip: arena must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const int blocks = (int)(cdiv<long long>(n / 4 + 1, 256) < kNormBlocks ? cdiv<long long>(n / 4 + 1, 256) : kNormBlocks);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(256), 0, st, g, n, workspace);
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_clip_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, blocks, max_norm, out2);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_adamw_step(float* p, const float* g, float* m, float* v, long long n, const float* coef, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, void* stream) {
+    PYLC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments");
+    PYLC_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adamw_step: arenas must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int blocks = (int)(cdiv<long long>(n / 4 + 1, 256) < 4096 ? cdiv<long long>(n / 4 + 1, 256) : 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, coef, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2));
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_sgd_step(float* p, const float* g, float* buf, long long n, const float* coef, float lr, float momentum, int step,
+                             void* stream) {
+    PYLC_REQUIRE(p && g && buf && n > 0 && step >= 1, "sgd_step: bad arguments");
+    const int blocks = (int)(cdiv<long long>(n, 256) < 4096 ? cdiv<long long>(n, 256) : 4096);
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, buf, n, coef, lr, momentum, step == 1 ? 1 : 0);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

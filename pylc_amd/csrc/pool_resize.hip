@@ -1,0 +1,317 @@
+// Pooling, bilinear resize (align_corners=True), global average pool and image ingest, NHWC fp32.
+// All HBM-bound; every thread moves 16-byte channel vectors.  Backward passes are written as gathers
+// (each input element sums the outputs that reference it) so results are deterministic -- no float atomics.
+//
+// Replaces nn.MaxPool2d(3,2,1) resnet.py:76; F.max_pool2d(x,2) unet.py:98; F.interpolate(bilinear,
+// align_corners=True) deeplab.py:38, decoder.py:46, aspp.py:79; nn.Upsample unet.py:136;
+// nn.AdaptiveAvgPool2d(1) aspp.py:63; Model.normalize_image model.py:416-445 (+ the x3 stack :310-311).
+#include "common.h"
+
+namespace pylc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+static inline int grid_for(long long n, int cap = 8192) {
+    long long b = cdiv<long long>(n, 256);
+    return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+// ---- max pool ----------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int B, int H, int W,
+                                   int C, int k, int s, int pad, int OH, int OW) {
+    const int CV = C / 4;
+    const long long total = (long long)B * OH * OW * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int b = (int)(t / OH);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int kh = 0; kh < k; ++kh) {
+            const int h = oh * s - pad + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int w = ow * s - pad + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const f32x4 v = ld4(x + ((size_t)(b * H + h) * W + w) * C + 4 * cv);
+                const int code = kh * k + kw;
+                // first maximum in scan order wins (PyTorch: val > maxval); the first valid element seeds it
+                if (first || v.x > best.x) { best.x = v.x; bi[0] = code; }
+                if (first || v.y > best.y) { best.y = v.y; bi[1] = code; }
+                if (first || v.z > best.z) { best.z = v.z; bi[2] = code; }
+                if (first || v.w > best.w) { best.w = v.w; bi[3] = code; }
+                first = false;
+            }
+        }
+        st4(y + 4 * i, best);
+        if (idx != nullptr) {
+            uchar4 c4 = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+            *reinterpret_cast<uchar4*>(idx + 4 * i) = c4;
+        }
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx, int B, int H,
+                                   int W, int C, int k, int s, int pad, int OH, int OW) {
+    const int CV = C / 4;
+    const long long total = (long long)B * H * W * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows covering (h,w): oh*s - pad <= h <= oh*s - pad + k - 1
+        int oh_lo = (h + pad - k + 1 + s - 1); oh_lo = oh_lo < 0 ? 0 : oh_lo / s;
+        int oh_hi = (h + pad) / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = (w + pad - k + 1 + s - 1); ow_lo = ow_lo < 0 ? 0 : ow_lo / s;
+        int ow_hi = (w + pad) / s; if (ow_hi > OW - 1) ow_hi = OW - 1;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const int kh = h - (oh * s - pad);
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int code = kh * k + (w - (ow * s - pad));
+                const size_t o = ((size_t)(b * OH + oh) * OW + ow) * C + 4 * cv;
+                const uchar4 c4 = *reinterpret_cast<const uchar4*>(idx + o);
+                const f32x4 g = ld4(dy + o);
+                if (c4.x == code) acc.x += g.x;
+                if (c4.y == code) acc.y += g.y;
+                if (c4.z == code) acc.z += g.z;
+                if (c4.w == code) acc.w += g.w;
+            }
+        }
+        st4(dx + 4 * i, acc);
+    }
+}
+
+// ---- bilinear, align_corners=True --------------------------------------------------------------
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
+    // PyTorch: src = scale * dst (scale = (in-1)/(out-1), 0 if out == 1); i0 = floor(src); i1 = i0 + (i0 < in-1)
+    const float src = scale * (float)dst;
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+    l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ y, int y_pitch, int B, int H, int W, int C,
+                                    int OH, int OW, float sh, float sw) {
+    const int CV = C / 4;
+    const long long total = (long long)B * OH * OW * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const Lerp lh = lerp_of(oh, sh, H), lw = lerp_of(ow, sw, W);
+        const float* base = x + (size_t)b * H * W * x_pitch + 4 * cv;
+        const f32x4 v00 = ld4(base + ((size_t)lh.i0 * W + lw.i0) * x_pitch), v01 = ld4(base + ((size_t)lh.i0 * W + lw.i1) * x_pitch);
+        const f32x4 v10 = ld4(base + ((size_t)lh.i1 * W + lw.i0) * x_pitch), v11 = ld4(base + ((size_t)lh.i1 * W + lw.i1) * x_pitch);
+        const f32x4 r = lh.w0 * (lw.w0 * v00 + lw.w1 * v01) + lh.w1 * (lw.w0 * v10 + lw.w1 * v11);
+        st4(y + ((size_t)(b * OH + oh) * OW + ow) * y_pitch + 4 * cv, r);
+    }
+}
+
+__device__ __forceinline__ void cand_range(int i, float scale, int out_size, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int dy_pitch, float* __restrict__ dx, int dx_pitch, int B, int H, int W,
+                                    int C, int OH, int OW, float sh, float sw) {
+    const int CV = C / 4;
+    const long long total = (long long)B * H * W * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        int oh_lo, oh_hi, ow_lo, ow_hi;
+        cand_range(h, sh, OH, oh_lo, oh_hi);
+        cand_range(w, sw, OW, ow_lo, ow_hi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const Lerp lh = lerp_of(oh, sh, H);
+            float wh = 0.f;
+            if (lh.i0 == h) wh += lh.w0;
+            if (lh.i1 == h) wh += lh.w1;      // i1 == i0 at the border: both weights land on the same pixel
+            if (lh.i0 != h && lh.i1 != h) continue;
+            const float* row = dy + (size_t)(b * OH + oh) * OW * dy_pitch + 4 * cv;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const Lerp lw = lerp_of(ow, sw, W);
+                if (lw.i0 != w && lw.i1 != w) continue;
+                float ww = 0.f;
+                if (lw.i0 == w) ww += lw.w0;
+                if (lw.i1 == w) ww += lw.w1;
+                acc += (wh * ww) * ld4(row + (size_t)ow * dy_pitch);
+            }
+        }
+        st4(dx + ((size_t)(b * H + h) * W + w) * dx_pitch + 4 * cv, acc);
+    }
+}
+
+// ---- global average pool -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
+    __shared__ f32x4 red[256];
+    const int CV = C / 4;
+    const int b = blockIdx.y;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int cv = blockIdx.x * 64 + tx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (cv < CV)
+        for (int r = ty; r < HW; r += 4) s += ld4(x + ((size_t)b * HW + r) * C + 4 * cv);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && cv < CV) {
+        s += red[64 + tx] + red[128 + tx] + red[192 + tx];
+        st4(y + (size_t)b * C + 4 * cv, s * (1.f / (float)HW));
+    }
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int HW, int C) {
+    const int CV = C / 4;
+    const long long total = (long long)B * HW * CV;
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const int b = (int)(i / ((long long)HW * CV));
+        st4(dx + 4 * i, ld4(dy + (size_t)b * C + 4 * cv) * inv);
+    }
+}
+
+// ---- image ingest / layout ---------------------------------------------------------------------
+__global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg, int HW, f32x4 mean, f32x4 istd, float* __restrict__ out) {
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, p = i % HW;
+        const float* src = img + b * Cimg * HW + p;
+        f32x4 v;
+        v.x = src[0];
+        v.y = Cimg == 3 ? src[HW] : v.x;
+        v.z = Cimg == 3 ? src[2 * (long long)HW] : v.x;
+        v.w = 0.f;
+        // ((x - mean) / std) / 255, evaluated in the reference's operation order (model.py:444-445)
+        f32x4 r;
+        r.x = ((v.x - mean.x) / istd.x) / 255.f;
+        r.y = ((v.y - mean.y) / istd.y) / 255.f;
+        r.z = ((v.z - mean.z) / istd.z) / 255.f;
+        r.w = 0.f;
+        st4(out + 4 * i, r);
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ y, int B, int HW, int C) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % HW;
+        const long long t = i / HW;
+        const int c = (int)(t % C);
+        const long long b = t / C;
+        y[i] = x[(b * HW + p) * x_pitch + c];
+    }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int y_pitch, int B, int HW, int C) {
+    const long long total = (long long)B * HW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long t = i / C;
+        const long long p = t % HW, b = t / HW;
+        y[(b * HW + p) * y_pitch + c] = x[(b * C + c) * HW + p];
+    }
+}
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" int pylc_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, int k, int stride, int pad, int OH,
+                                int OW, void* stream) {
+    PYLC_REQUIRE(x && y && B > 0 && C > 0 && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1 && pad >= 0 && pad <= k / 2, "maxpool_fwd: bad arguments");
+    PYLC_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1 && OH > 0 && OW > 0, "maxpool_fwd: bad output size");
+    const long long total = (long long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, idx, B, H, W, C, k, stride, pad, OH, OW);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int k, int stride, int pad,
+                                int OH, int OW, void* stream) {
+    PYLC_REQUIRE(dy && idx && dx && B > 0 && C > 0 && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "maxpool_bwd: bad arguments");
+    const long long total = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, idx, dx, B, H, W, C, k, stride, pad, OH, OW);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int pylc_bilinear_fwd(const float* x, int x_pitch, float* y, int y_pitch, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    PYLC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
+    PYLC_REQUIRE(x_pitch >= C && y_pitch >= C && x_pitch % 4 == 0 && y_pitch % 4 == 0, "bilinear_fwd: bad pitch");
+    const long long total = (long long)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, x_pitch, y, y_pitch, B, H, W, C, OH, OW,
+                       ac_scale(H, OH), ac_scale(W, OW));
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C, int OH, int OW, void* stream) {
+    PYLC_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "bilinear_bwd: bad arguments");
+    PYLC_REQUIRE(dy_pitch >= C && dx_pitch >= C && dy_pitch % 4 == 0 && dx_pitch % 4 == 0, "bilinear_bwd: bad pitch");
+    const long long total = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_pitch, dx, dx_pitch, B, H, W, C, OH, OW,
+                       ac_scale(H, OH), ac_scale(W, OW));
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void* stream) {
+    PYLC_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "gap_fwd: bad arguments");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(cdiv(C / 4, 64), B), dim3(256), 0, as_stream(stream), x, y, HW, C);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream) {
+    PYLC_REQUIRE(dy && dx && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "gap_bwd: bad arguments");
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((long long)B * HW * (C / 4))), dim3(256), 0, as_stream(stream), dy, dx, B, HW, C);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_image_pack(const float* img, int B, int Cimg, int H, int W, const float* mean3, const float* std3, float* out, void* stream) {
+    PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3), "image_pack: bad arguments");
+    f32x4 mean = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+    hipLaunchKernelGGL(image_pack_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream), img, B, Cimg, H * W, mean, sd, out);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_nhwc_to_nchw(const float* x, int x_pitch, float* y, int B, int H, int W, int C, void* stream) {
+    PYLC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && x_pitch >= C, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, as_stream(stream), x, x_pitch, y, B, H * W, C);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_nchw_to_nhwc(const float* x, float* y, int y_pitch, int B, int H, int W, int C, void* stream) {
+    PYLC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && y_pitch >= C, "nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, as_stream(stream), x, y, y_pitch, B, H * W, C);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

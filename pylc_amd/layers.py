@@ -1,0 +1,103 @@
+"""Layer modules of the HIP path: parameter containers with the reference's state_dict names/shapes whose
+forward is a HIP kernel launch (pylc_amd.ops).  Replaces nn.Conv2d / nn.BatchNorm2d / nn.ReLU / nn.Dropout
+as used by models/backbone/*.py, models/modules/aspp.py, models/decoder.py, models/architectures/unet.py."""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .runtime import runtime
+
+
+class Conv2d(nn.Module):
+    """Dense conv; weight is logical [Cout, Cin, k, k] with KRSC memory (what the MFMA kernel streams)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False, init='resnet'):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        w = torch.empty(cout, k, k, cin)
+        fan_in = cin * k * k
+        if init == 'resnet':        # N(0, sqrt(2/(k*k*cout))): resnet.py:139-141, xception.py:243-245
+            w.normal_(0, math.sqrt(2.0 / (k * k * cout)))
+        elif init == 'kaiming':     # kaiming_normal_ fan_in, gain sqrt(2): aspp.py:34,93, decoder.py:55
+            w.normal_(0, math.sqrt(2.0 / fan_in))
+        else:                       # torch Conv2d default (kaiming_uniform_(a=sqrt(5))): U-Net never calls initialize(), unet.py:81
+            w.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+        self.weight = nn.Parameter(w.permute(0, 3, 1, 2))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in)))
+        else:
+            self.register_parameter('bias', None)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+
+    def extra_repr(self):
+        return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,
+                                                      '' if self.bias is None else ', bias')
+
+
+class DepthwiseConv3x3(nn.Module):
+    """groups=C 3x3 conv with xception.py's fixed_padding folded in; weight [C,1,3,3]."""
+
+    def __init__(self, c, stride=1, dilation=1):
+        super().__init__()
+        self.c, self.stride, self.dilation = c, stride, dilation
+        self.weight = nn.Parameter(torch.empty(c, 1, 3, 3).normal_(0, math.sqrt(2.0 / (9 * c))))
+
+    def forward(self, x):
+        return ops.dwconv3x3(x, self.weight, self.stride, self.dilation)
+
+
+class BatchNorm2d(nn.Module):
+    """BatchNorm2d with the following ReLU / residual add fused into the same pass.  Synchronises its statistics
+    over runtime.sync_group when one is set (the RCCL replacement of models/sync_batchnorm)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.zeros((), dtype=torch.long))
+
+    @classmethod
+    def evaluate(cls, c):          # the reference's U-Net calls normalizer.evaluate(out_size) (unet.py:113,117)
+        return cls(c)
+
+    def forward(self, y, residual=None, relu=False):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, residual, relu,
+                          self.training, self.eps, self.momentum, runtime.sync_group if self.training else None,
+                          runtime.bn_clamp_eps)
+
+    def extra_repr(self):
+        return '%d' % self.num_features
+
+
+class Dropout(nn.Module):
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if self.training and runtime.dropout_enabled and self.p > 0:
+            return ops.dropout(x, self.p, runtime.next_seed())
+        return x
+
+
+class Named(nn.Module):
+    """A container whose children carry explicit (numeric-string) names, to reproduce the reference's
+    nn.Sequential state_dict keys (e.g. decoder.last_conv.4.weight) without its parameter-free members."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, m in children.items():
+            self.add_module(k.lstrip('_'), m)
+
+    def child(self, name):
+        return self._modules[str(name)]

@@ -1,0 +1,123 @@
+"""ctypes binding of libpylc_hip.so (the C ABI declared in include/pylc_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  Importing this module
+without the built library raises, and every op raises if it is handed a non-HIP tensor.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpylc_hip.so')
+
+ABI_VERSION = 1
+
+
+class PylcError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'dil',
+                                       'OH', 'OW', 'x_pitch', 'y_pitch')]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'C', 'stride', 'dil', 'OH', 'OW', 'x_pitch', 'y_pitch')]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_LL = C.c_longlong
+_F = C.c_float
+_D = C.c_double
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/pylc_hip.h (tests check this)
+SIGNATURES = {
+    'pylc_last_error': (C.c_char_p, []),
+    'pylc_abi_version': (_I, []),
+    'pylc_init': (_I, []),
+    'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    'pylc_conv2d_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
+    'pylc_conv2d_wgrad_workspace': (_SZ, [C.POINTER(ConvDesc)]),
+    'pylc_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    'pylc_weight_transpose': (_I, [_P, _P, _I, _I, _I, _P]),
+    'pylc_dwconv3x3_fwd': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
+    'pylc_dwconv3x3_dgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
+    'pylc_dwconv3x3_wgrad_workspace': (_SZ, [C.POINTER(DwDesc)]),
+    'pylc_dwconv3x3_wgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _SZ, _P]),
+    'pylc_bn_workspace_floats': (_SZ, [_LL, _I]),
+    'pylc_bn_stats': (_I, [_P, _LL, _I, _I, _P, _P, _P]),
+    'pylc_bn_finalize': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'pylc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'pylc_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P]),
+    'pylc_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _LL, _I, _I, _P, _P, _P]),
+    'pylc_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _D, _LL, _I, _I, _P, _I, _P, _I, _P]),
+    'pylc_relu_fwd': (_I, [_P, _I, _P, _I, _LL, _I, _P]),
+    'pylc_relu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _LL, _I, _P]),
+    'pylc_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'pylc_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'pylc_image_pack': (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
+    'pylc_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    'pylc_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'pylc_multiloss_workspace_floats': (_SZ, [_LL, _I]),
+    'pylc_multiloss_stats': (_I, [_P, _I, _P, _LL, _I, _P, _P, _P, _P]),
+    'pylc_multiloss_finalize': (_I, [_P, _D, _I, _F, _F, _F, _P, _P]),
+    'pylc_multiloss_bwd': (_I, [_P, _I, _P, _LL, _I, _P, _P, _D, _F, _F, _F, _P, _P, _I, _P]),
+    'pylc_sqnorm_workspace_floats': (_SZ, [_LL]),
+    'pylc_grad_norm_clip': (_I, [_P, _LL, _F, _P, _P, _P]),
+    'pylc_adamw_step': (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _I, _P]),
+    'pylc_sgd_step': (_I, [_P, _P, _P, _LL, _P, _F, _F, _I, _P]),
+    'pylc_dropout': (_I, [_P, _I, _P, _I, _LL, _I, _F, C.c_uint64, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise PylcError(
+            'libpylc_hip.so is not built (%s). Build it with `python __graft_entry__.py` or '
+            '`make -C pylc_amd/csrc`; there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError => header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pylc_abi_version() != ABI_VERSION:
+        raise PylcError('libpylc_hip.so ABI %d != binding ABI %d' % (lib.pylc_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+_initialised = False
+
+
+def check(rc):
+    if rc != 0:
+        raise PylcError('libpylc_hip: %s (code %d)' % (lib.pylc_last_error().decode(), rc))
+
+
+def init():
+    """Per-process kernel attribute setup; needs a visible GPU."""
+    global _initialised
+    if not _initialised:
+        check(lib.pylc_init())
+        _initialised = True
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Refuses host tensors: the HIP path is the only path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PylcError('pylc_amd ops need HIP device tensors (got %s); there is no CPU fallback' % t.device)
+    return t.data_ptr()

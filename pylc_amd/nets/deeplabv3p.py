@@ -1,0 +1,98 @@
+"""DeepLabV3+ (ASPP + decoder) assembly on the HIP kernels.
+
+Mirrors models/architectures/deeplab.py:17-39, models/modules/aspp.py:15-100, models/decoder.py:15-62.
+Constructor signature and state_dict keys are the reference's, so models/model.py:165-174 can build it and
+reference checkpoints load unchanged."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import Conv2d, BatchNorm2d, Dropout, Named
+from .encoder_resnet import ResNet101
+from .encoder_xception import AlignedXception
+
+
+class _ASPPBranch(nn.Module):
+    def __init__(self, cin, cout, k, dilation):
+        super().__init__()
+        self.atrous_conv = Conv2d(cin, cout, k, 1, 0 if k == 1 else dilation, dilation, init='kaiming')
+        self.bn = BatchNorm2d(cout)
+
+    def forward(self, x):
+        return self.bn(self.atrous_conv(x), relu=True)
+
+
+class ASPP(nn.Module):
+    def __init__(self, output_stride=16, inplanes=2048):
+        super().__init__()
+        dil = (1, 6, 12, 18) if output_stride == 16 else (1, 12, 24, 36)
+        self.aspp1 = _ASPPBranch(inplanes, 256, 1, dil[0])
+        self.aspp2 = _ASPPBranch(inplanes, 256, 3, dil[1])
+        self.aspp3 = _ASPPBranch(inplanes, 256, 3, dil[2])
+        self.aspp4 = _ASPPBranch(inplanes, 256, 3, dil[3])
+        self.global_avg_pool = Named(_1=Conv2d(inplanes, 256, 1, init='kaiming'), _2=BatchNorm2d(256))
+        self.conv1 = Conv2d(1280, 256, 1, init='kaiming')
+        self.bn1 = BatchNorm2d(256)
+        self.dropout = Dropout(0.5)
+
+    def forward(self, x):
+        h, w = x.shape[2:]
+        g = ops.global_avg_pool(x)
+        g = self.global_avg_pool.child(2)(self.global_avg_pool.child(1)(g), relu=True)
+        branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), ops.bilinear(g, h, w)]
+        y = torch.cat(branches, 1)               # channel concat of NHWC tensors (plumbing)
+        return self.dropout(self.bn1(self.conv1(y), relu=True))
+
+
+class Decoder(nn.Module):
+    def __init__(self, n_classes, low_level_inplanes):
+        super().__init__()
+        self.conv1 = Conv2d(low_level_inplanes, 48, 1, init='kaiming')
+        self.bn1 = BatchNorm2d(48)
+        self.last_conv = Named(_0=Conv2d(304, 256, 3, 1, 1, init='kaiming'), _1=BatchNorm2d(256),
+                               _4=Conv2d(256, 256, 3, 1, 1, init='kaiming'), _5=BatchNorm2d(256),
+                               _8=Conv2d(256, n_classes, 1, bias=True, init='kaiming'))
+        self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
+
+    def forward(self, x, low):
+        low = self.bn1(self.conv1(low), relu=True)
+        x = torch.cat((ops.bilinear(x, low.shape[2], low.shape[3]), low), 1)
+        lc = self.last_conv
+        x = self.drop3(lc.child(1)(lc.child(0)(x), relu=True))
+        x = self.drop7(lc.child(5)(lc.child(4)(x), relu=True))
+        return lc.child(8)(x)
+
+
+class DeepLab(nn.Module):
+    """DeepLab(activ_func=, normalizer=, backbone=, output_stride=16, n_classes=, in_channels=, freeze_bn=, pretrained=)
+    -- the call made at models/model.py:166-173.  activ_func / normalizer are accepted for signature
+    compatibility; the HIP path always runs ReLU and (Sync)BatchNorm, which is also all the reference can select
+    (SURVEY.md section 5 'Config / flag system')."""
+
+    def __init__(self, activ_func=None, normalizer=None, backbone='resnet', output_stride=16, n_classes=9, in_channels=3,
+                 freeze_bn=False, pretrained=False):
+        super().__init__()
+        if backbone == 'resnet':
+            self.backbone = ResNet101(output_stride)
+            low_c = 256
+        elif backbone == 'xception':
+            self.backbone = AlignedXception(output_stride)
+            low_c = 128
+        else:
+            raise ValueError('backbone %r not available (resnet | xception)' % backbone)
+        self.aspp = ASPP(output_stride)
+        self.decoder = Decoder(n_classes, low_c)
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        if pretrained:
+            raise ValueError('pretrained=True needs ./data/models/resnet101-5d3b4d8f.pth (resnet.py:149-158); '
+                             'load it with load_state_dict(strict=False) on .backbone instead')
+
+    def forward(self, x):
+        """x: normalised fp32 [B,3,H,W] (any layout), or the 4-channel NHWC pack made by ops.image_pack.
+        Returns logits [B,n_classes,H,W] (NHWC memory)."""
+        h, w = x.shape[2:]
+        x4 = x if x.shape[1] == 4 else ops.pack_nchw(x, 4)
+        f, low = self.backbone(x4)
+        y = self.decoder(self.aspp(f), low)
+        return ops.bilinear(y, h, w)

@@ -1,0 +1,72 @@
+"""ResNet-101 encoder (output stride 16/8, multi-grid layer4) on the HIP kernels.
+
+Mirrors models/backbone/resnet.py: Bottleneck :16-53, strides/dilations :60-69, _make_layer :88-103,
+_make_MG_unit :105-122, forward :124-135, init :137-147.  Each conv -> BN -> ReLU triple is two launches
+(implicit-GEMM conv, fused BN-apply+ReLU[+residual]) plus the BN statistics reduction."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import Conv2d, BatchNorm2d, Named
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, dilation, project):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride, dilation, dilation)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        if project:
+            self.downsample = Named(_0=Conv2d(inplanes, planes * 4, 1, stride), _1=BatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.conv3(out)
+        res = x
+        if self.downsample is not None:
+            res = self.downsample.child(1)(self.downsample.child(0)(x))
+        return self.bn3(out, residual=res, relu=True)      # relu(bn3(.) + residual) in one pass
+
+
+class ResNet101(nn.Module):
+    LAYERS = ((64, 3), (128, 4), (256, 23))
+    MULTI_GRID = (1, 2, 4)
+
+    def __init__(self, output_stride=16):
+        super().__init__()
+        if output_stride == 16:
+            strides, dils = (1, 2, 2, 1), (1, 1, 1, 2)
+        elif output_stride == 8:
+            strides, dils = (1, 2, 1, 1), (1, 1, 2, 4)
+        else:
+            raise NotImplementedError(output_stride)
+        self.conv1 = Conv2d(3, 64, 7, 2, 3)
+        self.bn1 = BatchNorm2d(64)
+        inpl = 64
+        for li, (planes, n) in enumerate(self.LAYERS):
+            blocks = []
+            for b in range(n):
+                s = strides[li] if b == 0 else 1
+                blocks.append(Bottleneck(inpl, planes, s, dils[li], b == 0 and (s != 1 or inpl != planes * 4)))
+                inpl = planes * 4
+            setattr(self, 'layer%d' % (li + 1), nn.Sequential(*blocks))
+        blocks = []
+        for b, mg in enumerate(self.MULTI_GRID):
+            s = strides[3] if b == 0 else 1
+            blocks.append(Bottleneck(inpl, 512, s, mg * dils[3], b == 0 and (s != 1 or inpl != 2048)))
+            inpl = 2048
+        self.layer4 = nn.Sequential(*blocks)
+
+    def forward(self, x4):
+        """x4: normalised image packed to 4 NHWC channels. Returns (features/16, low-level features/4)."""
+        x = self.bn1(self.conv1(x4), relu=True)
+        x = ops.maxpool(x, 3, 2, 1)
+        low = self.layer1(x)
+        x = self.layer4(self.layer3(self.layer2(low)))
+        return x, low

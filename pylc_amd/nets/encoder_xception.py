@@ -1,0 +1,120 @@
+"""Modified Aligned Xception encoder on the HIP kernels.
+
+Mirrors models/backbone/xception.py: fixed_padding :16-22, SeparableConv2d :25-39, Block :42-99,
+AlignedXception :102-239.  The reference's in-place-ReLU aliasing (Block.relu is ReLU(inplace=True) and is
+rep[0] when start_with_relu, so the skip branch reads ReLU(inp): SURVEY.md appendix D.1) is reproduced
+explicitly: `inp` is replaced by relu(inp) before BOTH branches."""
+from torch import nn
+
+from .. import ops
+from ..layers import Conv2d, DepthwiseConv3x3, BatchNorm2d
+
+
+class SeparableConv2d(nn.Module):
+    """depthwise 3x3 ('SAME' padding folded in) -> BN -> pointwise 1x1 (xception.py:34-39)."""
+
+    def __init__(self, cin, cout, stride=1, dilation=1):
+        super().__init__()
+        self.conv1 = DepthwiseConv3x3(cin, stride, dilation)
+        self.bn = BatchNorm2d(cin)
+        self.pointwise = Conv2d(cin, cout, 1)
+
+    def forward(self, x):
+        return self.pointwise(self.bn(self.conv1(x)))
+
+
+class Block(nn.Module):
+    def __init__(self, inpl, planes, reps, stride=1, dilation=1, start_with_relu=True, grow_first=True, is_last=False):
+        super().__init__()
+        if planes != inpl or stride != 1:
+            self.skip = Conv2d(inpl, planes, 1, stride)
+            self.skipbn = BatchNorm2d(planes)
+        else:
+            self.skip = None
+        seq, filters = [], inpl
+        if grow_first:
+            seq += ['relu', SeparableConv2d(inpl, planes, 1, dilation), BatchNorm2d(planes)]
+            filters = planes
+        for _ in range(reps - 1):
+            seq += ['relu', SeparableConv2d(filters, filters, 1, dilation), BatchNorm2d(filters)]
+        if not grow_first:
+            seq += ['relu', SeparableConv2d(inpl, planes, 1, dilation), BatchNorm2d(planes)]
+        if stride != 1:
+            seq += ['relu', SeparableConv2d(planes, planes, 2, 1), BatchNorm2d(planes)]
+        if stride == 1 and is_last:
+            seq += ['relu', SeparableConv2d(planes, planes, 1, 1), BatchNorm2d(planes)]
+        if not start_with_relu:
+            seq = seq[1:]
+        self.start_with_relu = start_with_relu
+        self.rep = nn.Module()                    # children named by their index in the reference's nn.Sequential
+        self.plan = []
+        for i, item in enumerate(seq):
+            if item == 'relu':
+                self.plan.append(('relu', None))
+            else:
+                self.rep.add_module(str(i), item)
+                self.plan.append(('bn' if isinstance(item, BatchNorm2d) else 'sep', str(i)))
+
+    def forward(self, inp):
+        if self.start_with_relu:
+            inp = ops.relu(inp)                   # aliasing quirk: both branches see relu(inp)
+        x = inp
+        n = len(self.plan)
+        i = 1 if self.start_with_relu else 0
+        while i < n:
+            kind, name = self.plan[i]
+            if kind == 'sep':
+                x = getattr(self.rep, name)(x)
+            elif kind == 'bn':
+                fuse = i + 1 < n and self.plan[i + 1][0] == 'relu'     # BN followed by the shared ReLU -> one pass
+                x = getattr(self.rep, name)(x, relu=fuse)
+                if fuse:
+                    i += 1
+            else:
+                x = ops.relu(x)
+            i += 1
+        if self.skip is not None:
+            skip = self.skipbn(self.skip(inp))
+        else:
+            skip = inp
+        return x + skip
+
+
+class AlignedXception(nn.Module):
+    def __init__(self, output_stride=16):
+        super().__init__()
+        if output_stride == 16:
+            b3s, mid_d, exit_d = 2, 1, (1, 2)
+        elif output_stride == 8:
+            b3s, mid_d, exit_d = 1, 2, (2, 4)
+        else:
+            raise NotImplementedError(output_stride)
+        self.conv1 = Conv2d(3, 32, 3, 2, 1)
+        self.bn1 = BatchNorm2d(32)
+        self.conv2 = Conv2d(32, 64, 3, 1, 1)
+        self.bn2 = BatchNorm2d(64)
+        self.block1 = Block(64, 128, 2, 2, 1, start_with_relu=False)
+        self.block2 = Block(128, 256, 2, 2, 1, start_with_relu=False)
+        self.block3 = Block(256, 728, 2, b3s, 1, is_last=True)
+        for i in range(4, 20):
+            setattr(self, 'block%d' % i, Block(728, 728, 3, 1, mid_d))
+        self.block20 = Block(728, 1024, 2, 1, exit_d[0], grow_first=False, is_last=True)
+        self.conv3 = SeparableConv2d(1024, 1536, 1, exit_d[1])
+        self.bn3 = BatchNorm2d(1536)
+        self.conv4 = SeparableConv2d(1536, 1536, 1, exit_d[1])
+        self.bn4 = BatchNorm2d(1536)
+        self.conv5 = SeparableConv2d(1536, 2048, 1, exit_d[1])
+        self.bn5 = BatchNorm2d(2048)
+
+    def forward(self, x4):
+        x = self.bn1(self.conv1(x4), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        low = ops.relu(self.block1(x))            # xception.py:199-202
+        x = self.block3(self.block2(low))
+        for i in range(4, 21):
+            x = getattr(self, 'block%d' % i)(x)
+        x = ops.relu(x)
+        x = self.bn3(self.conv3(x), relu=True)
+        x = self.bn4(self.conv4(x), relu=True)
+        x = self.bn5(self.conv5(x), relu=True)
+        return x, low

@@ -1,0 +1,563 @@
+"""torch.autograd bindings of the HIP kernels (host-side plumbing only: shapes, buffers, streams).
+
+Tensor convention: every activation is a 4-D tensor of logical shape [B, C, H, W] whose MEMORY is
+NHWC (``channels_last``), possibly a channel slice of a wider buffer (pitch > C).  Conv weights are
+logical [Cout, Cin, kh, kw] with KRSC memory.  Nothing here computes on the CPU or through ATen math
+kernels; if libpylc_hip.so is missing, importing ``pylc_amd.lib`` already failed.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from .lib import lib, check, ptr, stream, ConvDesc, DwDesc
+
+
+# ----------------------------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------------------------
+def empty_nhwc(b, c, h, w, device, pitch=None, dtype=torch.float32):
+    pitch = c if pitch is None else pitch
+    t = torch.empty((b, h, w, pitch), device=device, dtype=dtype).permute(0, 3, 1, 2)
+    return t if pitch == c else t[:, :c]
+
+
+def zeros_nhwc(b, c, h, w, device, pitch=None):
+    pitch = c if pitch is None else pitch
+    t = torch.zeros((b, h, w, pitch), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+    return t if pitch == c else t[:, :c]
+
+
+def pitch_of(t):
+    """Channel pitch (floats between pixels) of an NHWC-memory tensor; raises if the layout is anything else."""
+    b, c, h, w = t.shape
+    if w > 1:
+        p = t.stride(3)
+    elif h > 1:
+        p = t.stride(2)
+    elif b > 1:
+        p = t.stride(0)
+    else:
+        p = c
+    ok = (c == 1 or t.stride(1) == 1) and (h == 1 or t.stride(2) == w * p) and (b == 1 or t.stride(0) == h * w * p) and p >= c
+    if not ok:
+        raise L.PylcError('tensor is not NHWC-in-memory: shape %s strides %s' % (tuple(t.shape), t.stride()))
+    return p
+
+
+def as_nhwc(t):
+    """Return `t` with NHWC memory (copying through torch only if an upstream op handed us another layout)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    try:
+        pitch_of(t)
+        return t
+    except L.PylcError:
+        out = empty_nhwc(*t.shape, device=t.device)
+        out.copy_(t)
+        return out
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, device=device, dtype=torch.float32)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _r4(c):
+    return (c + 3) & ~3
+
+
+# ----------------------------------------------------------------------------------------------
+# dense convolution
+# ----------------------------------------------------------------------------------------------
+def _conv_desc(x, cin, cout, r, s, stride, pad, dil, x_pitch, y_pitch):
+    b, _, h, w = x.shape
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S = b, h, w, cin, cout, r, s
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.OH, d.OW = conv_out_size(h, r, stride, pad, dil), conv_out_size(w, s, stride, pad, dil)
+    d.x_pitch, d.y_pitch = x_pitch, y_pitch
+    return d
+
+
+def _grad_target(param):
+    """Arena-backed gradient view for `param` if the optimiser registered one, else None."""
+    return getattr(param, '_pylc_grad', None)
+
+
+def _deliver_grad(param, g):
+    """Hand a parameter gradient back.  With an arena view registered the kernel already wrote into it:
+    publish it as .grad and tell autograd there is nothing to accumulate."""
+    if _grad_target(param) is not None:
+        if param.grad is None or param.grad.data_ptr() != g.data_ptr():
+            param.grad = g
+        return None
+    return g
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        L.init()
+        x = as_nhwc(x)
+        cout, cin_w, r, s = w.shape
+        cin = x.shape[1]
+        xp = pitch_of(x)
+        w_k = w
+        if cin_w % 4 != 0:
+            # thin-input stem (Cin=3): zero-pad the KRSC rows to 4 channels; x must already be the 4-channel pack
+            if cin != _r4(cin_w):
+                raise L.PylcError('conv expects the %d-channel packed input for a %d-channel filter' % (_r4(cin_w), cin_w))
+            w_k = torch.zeros((cout, r, s, cin), device=w.device, dtype=torch.float32)
+            w_k[..., :cin_w] = w.detach().permute(0, 2, 3, 1)
+        elif cin != cin_w:
+            raise L.PylcError('conv: input has %d channels, filter expects %d' % (cin, cin_w))
+        elif not (w.permute(0, 2, 3, 1).is_contiguous()):
+            raise L.PylcError('conv weight must have KRSC (channels_last) memory')
+        b, _, h, wd = x.shape
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        yp = _r4(cout)
+        y = empty_nhwc(b, cout, oh, ow, x.device, yp)
+        d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
+        check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
+        ctx.save_for_backward(x, w_k)
+        ctx.geom = (stride, pad, dil, cin_w, bias is not None)
+        ctx.w_param, ctx.b_param = w, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_k = ctx.saved_tensors
+        stride, pad, dil, cin_w, has_bias = ctx.geom
+        w, bias = ctx.w_param, ctx.b_param
+        dy = as_nhwc(dy)
+        cout, _, r, s = w.shape
+        cin = x.shape[1]
+        yp = pitch_of(dy)
+        if yp < _r4(cout):      # a grad produced outside our kernels: re-pitch so vector loads stay in bounds
+            t = zeros_nhwc(dy.shape[0], cout, dy.shape[2], dy.shape[3], dy.device, _r4(cout))
+            t.copy_(dy)
+            dy, yp = t, _r4(cout)
+        d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, pitch_of(x), yp)
+        st = stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            kp = _r4(cout)
+            wt = torch.empty((cin, r * s, kp), device=x.device, dtype=torch.float32)
+            check(lib.pylc_weight_transpose(ptr(w_k), ptr(wt), cout, r * s, cin, st))
+            dx = empty_nhwc(*x.shape, device=x.device)
+            d.x_pitch = cin
+            check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, st))
+            d.x_pitch = pitch_of(x)
+        if ctx.needs_input_grad[1]:
+            nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
+            ws = _ws(nbytes, x.device)
+            tgt = _grad_target(w)
+            if cin_w % 4 == 0:
+                dw = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
+                check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, st))
+            else:
+                dw4 = torch.empty((cout, r, s, cin), device=x.device)
+                check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, st))
+                dw = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
+                dw.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
+            dw = _deliver_grad(w, dw)
+        if has_bias and ctx.needs_input_grad[2]:
+            m = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            cp = _r4(cout)
+            sums = torch.empty(2 * cp, device=x.device)
+            ws = torch.empty(lib.pylc_bn_workspace_floats(m, cp), device=x.device)
+            check(lib.pylc_bn_stats(ptr(dy), m, cp, yp, ptr(sums), ptr(ws), st))
+            tgt = _grad_target(bias)
+            if tgt is not None:
+                tgt.copy_(sums[:cout])
+                db = _deliver_grad(bias, tgt)
+            else:
+                db = sums[:cout].clone()
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil)
+
+
+# ----------------------------------------------------------------------------------------------
+# depthwise 3x3 (Xception separable convs)
+# ----------------------------------------------------------------------------------------------
+def _dw_desc(x, stride, dil, xp, yp):
+    b, c, h, w = x.shape
+    d = DwDesc()
+    d.B, d.H, d.W, d.C, d.stride, d.dil = b, h, w, c, stride, dil
+    d.OH, d.OW = (h - 1) // stride + 1, (w - 1) // stride + 1
+    d.x_pitch, d.y_pitch = xp, yp
+    return d
+
+
+class DwConv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, dil):
+        L.init()
+        x = as_nhwc(x)
+        b, c, h, wd = x.shape
+        if tuple(w.shape) != (c, 1, 3, 3) or not w.is_contiguous():
+            raise L.PylcError('depthwise weight must be contiguous [C,1,3,3]')
+        d = _dw_desc(x, stride, dil, pitch_of(x), c)
+        y = empty_nhwc(b, c, d.OH, d.OW, x.device)
+        check(lib.pylc_dwconv3x3_fwd(C.byref(d), ptr(x), ptr(w), ptr(y), stream()))
+        ctx.save_for_backward(x)
+        ctx.w_param, ctx.geom = w, (stride, dil)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w = ctx.w_param
+        stride, dil = ctx.geom
+        dy = as_nhwc(dy)
+        st = stream()
+        d = _dw_desc(x, stride, dil, pitch_of(x), pitch_of(dy))
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(*x.shape, device=x.device)
+            d.x_pitch = x.shape[1]
+            check(lib.pylc_dwconv3x3_dgrad(C.byref(d), ptr(dy), ptr(w), ptr(dx), st))
+            d.x_pitch = pitch_of(x)
+        if ctx.needs_input_grad[1]:
+            nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
+            ws = _ws(nbytes, x.device)
+            tgt = _grad_target(w)
+            dw = tgt if tgt is not None else torch.empty_like(w)
+            check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, st))
+            dw = _deliver_grad(w, dw)
+        return dx, dw, None, None
+
+
+def dwconv3x3(x, w, stride=1, dil=1):
+    return DwConv3x3Fn.apply(x, w, stride, dil)
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm (+ ReLU, + residual), optionally synchronised across a process group
+# ----------------------------------------------------------------------------------------------
+class BnActFn(torch.autograd.Function):
+    """out = act(BN(y) (+ residual)).  Training: batch statistics (all-reduced over `group` when given --
+    the SyncBN exchange of models/sync_batchnorm/batchnorm.py:48-125 as one RCCL all-reduce of
+    [sum, sumsq, count]); eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps):
+        L.init()
+        y = as_nhwc(y)
+        b, c, h, w = y.shape
+        m = b * h * w
+        dev = y.device
+        st = stream()
+        yp = pitch_of(y)
+        coef = torch.empty(4 * c, device=dev)            # mean | invstd | scale | shift
+        mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
+        n_global = float(m)
+        if training:
+            sums = torch.empty(2 * c + 1, device=dev)
+            ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
+            check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
+            if group is not None:
+                sums[2 * c] = float(m)
+                dist.all_reduce(sums, group=group)
+                n_global = float(m) * dist.get_world_size(group)      # equal shards (drop_last loader)
+            check(lib.pylc_bn_finalize(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
+                                       ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st))
+        else:
+            check(lib.pylc_bn_eval_coeffs(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
+                                          ptr(scale), ptr(shift), st))
+            mean.copy_(running_mean)
+            invstd.copy_(torch.rsqrt(running_var + eps))
+        res = None
+        if residual is not None:
+            res = as_nhwc(residual)
+        out = empty_nhwc(b, c, h, w, dev)
+        check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
+                                ptr(out), c, m, c, int(relu), st))
+        ctx.save_for_backward(y, out if relu else None, coef)
+        ctx.cfg = (relu, training, group, n_global, residual is not None)
+        ctx.g_param, ctx.b_param = gamma, beta
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, coef = ctx.saved_tensors
+        relu, training, group, n_global, has_res = ctx.cfg
+        gamma, beta = ctx.g_param, ctx.b_param
+        dout = as_nhwc(dout)
+        b, c, h, w = y.shape
+        m = b * h * w
+        dev = y.device
+        st = stream()
+        mean, invstd = coef[:c], coef[c:2 * c]
+        sums = torch.empty(2 * c, device=dev)
+        ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
+        op = pitch_of(out) if out is not None else 0
+        check(lib.pylc_bn_bwd_reduce(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                     m, c, int(relu), ptr(sums), ptr(ws), st))
+        local_sums = sums
+        if training and group is not None:
+            local_sums = sums.clone()          # parameter grads stay local; the grad all-reduce averages them later
+            dist.all_reduce(sums, group=group)
+        if not training:
+            sums_apply = torch.zeros_like(sums)   # running statistics are constants: dy = gamma*invstd*g
+        else:
+            sums_apply = sums
+        dy = empty_nhwc(b, c, h, w, dev)
+        g_out = empty_nhwc(b, c, h, w, dev) if (has_res and ctx.needs_input_grad[5]) else None
+        check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                    ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
+                                    ptr(g_out), c if g_out is not None else 0, st))
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1]:
+            tgt = _grad_target(gamma)
+            if tgt is not None:
+                tgt.copy_(local_sums[c:])
+                dgamma = _deliver_grad(gamma, tgt)
+            else:
+                dgamma = local_sums[c:].clone()
+        if ctx.needs_input_grad[2]:
+            tgt = _grad_target(beta)
+            if tgt is not None:
+                tgt.copy_(local_sums[:c])
+                dbeta = _deliver_grad(beta, tgt)
+            else:
+                dbeta = local_sums[:c].clone()
+        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None
+
+
+def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
+           group=None, clamp_eps=False):
+    return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps)
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.init()
+        x = as_nhwc(x)
+        b, c, h, w = x.shape
+        out = empty_nhwc(b, c, h, w, x.device)
+        check(lib.pylc_relu_fwd(ptr(x), pitch_of(x), ptr(out), c, b * h * w, c, stream()))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = as_nhwc(dout)
+        b, c, h, w = out.shape
+        dx = empty_nhwc(b, c, h, w, out.device)
+        check(lib.pylc_relu_bwd(ptr(dout), pitch_of(dout), ptr(out), c, ptr(dx), c, b * h * w, c, stream()))
+        return dx
+
+
+def relu(x):
+    return ReluFn.apply(x)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        L.init()
+        x = as_nhwc(x)
+        b, c, h, w = x.shape
+        out = empty_nhwc(b, c, h, w, x.device)
+        check(lib.pylc_dropout(ptr(x), pitch_of(x), ptr(out), c, b * h * w, c, p, seed, stream()))
+        ctx.cfg = (p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, seed = ctx.cfg
+        dout = as_nhwc(dout)
+        b, c, h, w = dout.shape
+        dx = empty_nhwc(b, c, h, w, dout.device)
+        check(lib.pylc_dropout(ptr(dout), pitch_of(dout), ptr(dx), c, b * h * w, c, p, seed, stream()))
+        return dx, None, None
+
+
+def dropout(x, p, seed):
+    return DropoutFn.apply(x, p, seed)
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling / resize
+# ----------------------------------------------------------------------------------------------
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        L.init()
+        x = as_nhwc(x)
+        if pitch_of(x) != x.shape[1]:
+            x = x.contiguous(memory_format=torch.channels_last)
+        b, c, h, w = x.shape
+        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        y = empty_nhwc(b, c, oh, ow, x.device)
+        need_idx = ctx.needs_input_grad[0]
+        idx = torch.empty((b, oh, ow, c), device=x.device, dtype=torch.uint8) if need_idx else None
+        check(lib.pylc_maxpool_fwd(ptr(x), ptr(y), ptr(idx), b, h, w, c, k, stride, pad, oh, ow, stream()))
+        ctx.save_for_backward(idx)
+        ctx.cfg = (b, c, h, w, k, stride, pad, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        b, c, h, w, k, stride, pad, oh, ow = ctx.cfg
+        dy = as_nhwc(dy)
+        if pitch_of(dy) != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = empty_nhwc(b, c, h, w, dy.device)
+        check(lib.pylc_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), b, h, w, c, k, stride, pad, oh, ow, stream()))
+        return dx, None, None, None
+
+
+def maxpool(x, k, stride, pad=0):
+    return MaxPoolFn.apply(x, k, stride, pad)
+
+
+class BilinearFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) to an explicit output size."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        L.init()
+        x = as_nhwc(x)
+        b, c, h, w = x.shape
+        cp = pitch_of(x)
+        cc = _r4(c)
+        if cc > cp:
+            raise L.PylcError('bilinear: channel count %d needs a pitch >= %d' % (c, cc))
+        y = empty_nhwc(b, c, oh, ow, x.device, cc)
+        check(lib.pylc_bilinear_fwd(ptr(x), cp, ptr(y), cc, b, h, w, cc, oh, ow, stream()))
+        ctx.cfg = (b, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, h, w, oh, ow = ctx.cfg
+        dy = as_nhwc(dy)
+        cc = _r4(c)
+        if pitch_of(dy) < cc:
+            t = zeros_nhwc(b, c, oh, ow, dy.device, cc)
+            t.copy_(dy)
+            dy = t
+        dx = empty_nhwc(b, c, h, w, dy.device, cc)
+        check(lib.pylc_bilinear_bwd(ptr(dy), pitch_of(dy), ptr(dx), cc, b, h, w, cc, oh, ow, stream()))
+        return dx, None, None
+
+
+def bilinear(x, oh, ow):
+    return BilinearFn.apply(x, oh, ow)
+
+
+class GapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.init()
+        x = as_nhwc(x)
+        if pitch_of(x) != x.shape[1]:
+            x = x.contiguous(memory_format=torch.channels_last)
+        b, c, h, w = x.shape
+        y = empty_nhwc(b, c, 1, 1, x.device)
+        check(lib.pylc_gap_fwd(ptr(x), ptr(y), b, h * w, c, stream()))
+        ctx.cfg = (b, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, h, w = ctx.cfg
+        dy = dy.reshape(b, c).contiguous()
+        dx = empty_nhwc(b, c, h, w, dy.device)
+        check(lib.pylc_gap_bwd(ptr(dy), ptr(dx), b, h * w, c, stream()))
+        return dx
+
+
+def global_avg_pool(x):
+    return GapFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# image ingest
+# ----------------------------------------------------------------------------------------------
+def image_pack(img, mean3, std3):
+    """Raw [B,1|3,H,W] 0..255 tiles -> normalised NHWC4 network input (Model.normalize_image + x3 stack)."""
+    L.init()
+    b, c, h, w = img.shape
+    img = img.contiguous()
+    out = empty_nhwc(b, 4, h, w, img.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    check(lib.pylc_image_pack(ptr(img), b, c, h, w, m, s, ptr(out), stream()))
+    return out
+
+
+def pack_nchw(x, pitch):
+    """Already-normalised NCHW fp32 -> NHWC with `pitch` channels (extra channels zero)."""
+    L.init()
+    b, c, h, w = x.shape
+    x = x.contiguous()
+    out = zeros_nhwc(b, pitch, h, w, x.device)
+    check(lib.pylc_nchw_to_nhwc(ptr(x), ptr(out), pitch, b, h, w, c, stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# MultiLoss
+# ----------------------------------------------------------------------------------------------
+class MultiLossFn(torch.autograd.Function):
+    """Returns a [4] tensor (total, ce, dice, focal); only total carries gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, w_ce, w_dice, w_focal, group):
+        L.init()
+        logits = as_nhwc(logits)
+        b, c, h, w = logits.shape
+        n = b * h * w
+        target = target.contiguous()
+        if target.dtype != torch.int64 or tuple(target.shape) != (b, h, w):
+            raise L.PylcError('target must be int64 [B,H,W] matching the logits')
+        dev = logits.device
+        st = stream()
+        k = 3 + 3 * c
+        stats = torch.empty(k, device=dev)
+        ws = torch.empty(lib.pylc_multiloss_workspace_floats(n, c), device=dev)
+        check(lib.pylc_multiloss_stats(ptr(logits), pitch_of(logits), ptr(target), n, c, ptr(class_weights), ptr(stats), ptr(ws), st))
+        n_global = float(n)
+        if group is not None:
+            dist.all_reduce(stats, group=group)      # Dice / weighted CE are not shard-decomposable
+            n_global = float(n) * dist.get_world_size(group)
+        losses = torch.empty(4, device=dev)
+        check(lib.pylc_multiloss_finalize(ptr(stats), n_global, c, w_ce, w_dice, w_focal, ptr(losses), st))
+        ctx.save_for_backward(logits, target, stats, class_weights)
+        ctx.cfg = (n_global, w_ce, w_dice, w_focal, group)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dlosses):
+        logits, target, stats, cw = ctx.saved_tensors
+        n_global, w_ce, w_dice, w_focal, group = ctx.cfg
+        b, c, h, w = logits.shape
+        n = b * h * w
+        # the loss is already the GLOBAL loss; each rank back-propagates its own pixels' share and the
+        # gradient all-reduce SUMS the shares (pylc_amd/parallel.py)
+        gs = dlosses[0:1].contiguous().float()
+        cp = _r4(c)
+        dl = empty_nhwc(b, c, h, w, logits.device, cp)
+        check(lib.pylc_multiloss_bwd(ptr(logits), pitch_of(logits), ptr(target), n, c, ptr(cw), ptr(stats), n_global,
+                                     w_ce, w_dice, w_focal, ptr(gs), ptr(dl), cp, stream()))
+        return dl, None, None, None, None, None, None
+
+
+def multiloss(logits, target, class_weights, w_ce, w_dice, w_focal, group=None):
+    return MultiLossFn.apply(logits, target, class_weights, w_ce, w_dice, w_focal, group)

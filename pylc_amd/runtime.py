@@ -1,0 +1,24 @@
+"""Process-wide runtime switches of the HIP path (no reference counterpart: the reference keeps the
+equivalent state in the `defaults` singleton, config.py:329, which SURVEY.md appendix D.12 says the
+build must replace with explicit arguments)."""
+import itertools
+
+
+class _Runtime:
+    def __init__(self):
+        self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
+        self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
+        self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
+        self.seed = 0x5EED
+        self._counter = itertools.count(1)
+
+    def next_seed(self):
+        """Distinct, reproducible seed per dropout call (rank-offset so data-parallel ranks draw different masks)."""
+        return (self.seed * 0x9E3779B97F4A7C15 + next(self._counter) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def manual_seed(self, seed, rank=0):
+        self.seed = (int(seed) * 1000003 + rank) & 0xFFFFFFFF
+        self._counter = itertools.count(1)
+
+
+runtime = _Runtime()

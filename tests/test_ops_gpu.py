@@ -1,0 +1,310 @@
+"""Parity of every HIP kernel family against the fp32/fp64 PyTorch CPU op it replaces (-m gpu).
+
+The conv kernels run on the exact-fp32 matrix pipe, so they are compared with an fp64 CPU convolution at a
+tolerance of a few fp32 ulps of the accumulated magnitude; integer-like outputs (pool indices) are exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def to_dev_nhwc(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dil, B, H, W, bias
+    (64, 64, 3, 1, 1, 1, 2, 20, 24, False),       # layer1 3x3
+    (64, 256, 1, 1, 0, 1, 2, 16, 16, False),      # 1x1 expand
+    (128, 128, 3, 2, 1, 1, 2, 18, 22, False),     # strided 3x3 (odd/even sizes)
+    (128, 128, 3, 2, 1, 1, 1, 17, 19, False),     # strided, odd input
+    (256, 512, 1, 2, 0, 1, 2, 16, 16, False),     # downsample 1x1 s2
+    (96, 64, 3, 1, 6, 6, 2, 16, 16, False),       # atrous, taps partly out of bounds (tap skipping)
+    (64, 64, 3, 1, 18, 18, 1, 16, 16, False),     # atrous d=18 on a 16^2 map: only the centre tap is ever valid
+    (304, 256, 3, 1, 1, 1, 1, 12, 12, False),     # Cin not a multiple of 32 (decoder concat)
+    (40, 48, 1, 1, 0, 1, 2, 9, 7, False),         # decoder.conv1-like, Cout=48
+    (256, 9, 1, 1, 0, 1, 2, 12, 12, True),        # 9-class head with bias (pitch 12)
+    (64, 11, 1, 1, 0, 1, 1, 10, 10, True),        # 11-class head
+    (64, 64, 3, 1, 0, 1, 2, 14, 14, True),        # U-Net valid conv with bias
+    (128, 64, 3, 1, 0, 1, 1, 20, 20, True),
+    (728, 728, 1, 1, 0, 1, 1, 8, 8, False),       # Xception pointwise (Cin % 32 != 0)
+    (32, 2048, 1, 1, 0, 1, 4, 1, 1, False),       # ASPP image-pool branch: 1x1 spatial
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(dev, case):
+    from pylc_amd import ops
+    cin, cout, k, stride, pad, dil, b, h, w, bias = case
+    x = rnd(1, b, cin, h, w)
+    wt = rnd(2, cout, cin, k, k, scale=(2.0 / (cin * k * k)) ** 0.5)
+    bs = rnd(3, cout, scale=0.1) if bias else None
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    br = bs.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride, pad, dil)
+    dy = rnd(4, *yr.shape)
+    yr.backward(dy.double())
+
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = to_dev_nhwc(wt, dev).requires_grad_(True)
+    bd = bs.to(dev).requires_grad_(True) if bias else None
+    y = ops.conv2d(xd, wd, bd, stride, pad, dil)
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(xd.grad, xr.grad) < 4e-6
+    assert rel_err(wd.grad, wr.grad) < 5e-6
+    if bias:
+        assert rel_err(bd.grad, br.grad) < 2e-6
+        # channels [cout, roundup4) of the padded logits buffer must be exact zeros
+        cp = (cout + 3) & ~3
+        if cp > cout:
+            full = torch.as_strided(y, (y.shape[0], cp, y.shape[2], y.shape[3]), y.stride(), y.storage_offset())
+            assert float(full[:, cout:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('k,stride,pad,hw', [(7, 2, 3, 40), (3, 1, 0, 30), (3, 2, 1, 33)])
+def test_conv_thin_input(dev, k, stride, pad, hw):
+    """3-channel image convs (ResNet stem 7x7/2, U-Net first 3x3, Xception stem 3x3/2) through the 4-channel pack."""
+    from pylc_amd import ops
+    b, cout = 2, 64
+    x = rnd(5, b, 3, hw, hw)
+    wt = rnd(6, cout, 3, k, k, scale=0.1)
+    wr = wt.double().requires_grad_(True)
+    yr = F.conv2d(x.double(), wr, None, stride, pad)
+    dy = rnd(7, *yr.shape)
+    yr.backward(dy.double())
+    x4 = ops.pack_nchw(x.to(dev), 4)
+    wd = to_dev_nhwc(wt, dev).requires_grad_(True)
+    y = ops.conv2d(x4, wd, None, stride, pad, 1)
+    y.backward(dy.to(dev))
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(wd.grad, wr.grad) < 5e-6
+
+
+@pytest.mark.parametrize('c,stride,dil,hw', [(64, 1, 1, 18), (128, 2, 1, 18), (728, 1, 1, 9), (1024, 1, 2, 10), (128, 2, 1, 17)])
+def test_dwconv(dev, c, stride, dil, hw):
+    from pylc_amd import ops
+    b = 2
+    x = rnd(8, b, c, hw, hw)
+    wt = rnd(9, c, 1, 3, 3, scale=0.3)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    total = 2 * dil
+    xp = F.pad(xr, (total // 2, total - total // 2, total // 2, total - total // 2))   # xception.py fixed_padding
+    yr = F.conv2d(xp, wr, None, stride, 0, dil, groups=c)
+    dy = rnd(10, *yr.shape)
+    yr.backward(dy.double())
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = wt.to(dev).requires_grad_(True)
+    y = ops.dwconv3x3(xd, wd, stride, dil)
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(dy.to(dev))
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(xd.grad, xr.grad) < 2e-6
+    assert rel_err(wd.grad, wr.grad) < 5e-6
+
+
+@pytest.mark.parametrize('c,b,hw,relu,res', [(64, 4, 16, True, False), (256, 2, 9, True, True), (48, 3, 11, True, False),
+                                             (728, 2, 6, False, False), (2048, 2, 4, True, True), (256, 5, 1, True, False)])
+def test_bn_train(dev, c, b, hw, relu, res):
+    from pylc_amd import ops
+    y = rnd(11, b, c, hw, hw, scale=2.0) + 0.5
+    g, be = 1 + 0.1 * rnd(12, c), 0.1 * rnd(13, c)
+    rm, rv = 0.1 * rnd(14, c), 1 + 0.1 * rnd(15, c).abs()
+    r = rnd(16, b, c, hw, hw) if res else None
+    yr, gr, ber = y.double().requires_grad_(True), g.double().requires_grad_(True), be.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    o = F.batch_norm(yr, rmr, rvr, gr, ber, True, 0.1, 1e-5)
+    if res:
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    do = rnd(17, *o.shape)
+    o.backward(do.double())
+    yd = to_dev_nhwc(y, dev).requires_grad_(True)
+    gd, bed = g.to(dev).requires_grad_(True), be.to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    rd = to_dev_nhwc(r, dev).requires_grad_(True) if res else None
+    od = ops.bn_act(yd, gd, bed, rmd, rvd, rd, relu, True)
+    od.backward(do.to(dev))
+    assert rel_err(od, o) < 5e-6
+    assert rel_err(rmd, rmr) < 1e-6 and rel_err(rvd, rvr) < 2e-6
+    assert rel_err(yd.grad, yr.grad) < 2e-5
+    assert rel_err(gd.grad, gr.grad) < 2e-5 and rel_err(bed.grad, ber.grad) < 2e-5
+    if res:
+        assert rel_err(rd.grad, rr.grad) < 1e-6
+
+
+def test_bn_eval(dev):
+    from pylc_amd import ops
+    c, b, hw = 128, 2, 7
+    y = rnd(18, b, c, hw, hw)
+    g, be, rm, rv = 1 + 0.1 * rnd(19, c), 0.1 * rnd(20, c), 0.1 * rnd(21, c), 1 + 0.1 * rnd(22, c).abs()
+    o = F.relu(F.batch_norm(y.double(), rm.double(), rv.double(), g.double(), be.double(), False, 0.1, 1e-5))
+    od = ops.bn_act(to_dev_nhwc(y, dev), g.to(dev), be.to(dev), rm.to(dev), rv.to(dev), None, True, False)
+    assert rel_err(od, o) < 2e-6
+
+
+@pytest.mark.parametrize('k,s,p,hw,c', [(3, 2, 1, 16, 64), (2, 2, 0, 21, 64), (2, 2, 0, 12, 128), (3, 2, 1, 15, 8)])
+def test_maxpool(dev, k, s, p, hw, c):
+    from pylc_amd import ops
+    x = F.relu(rnd(23, 2, c, hw, hw))          # post-ReLU: exact-zero ties exercise the first-max rule
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p)
+    dy = rnd(24, *yr.shape)
+    yr.backward(dy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y = ops.maxpool(xd, k, s, p)
+    y.backward(dy.to(dev))
+    assert torch.equal(y.cpu(), yr.detach())
+    assert rel_err(xd.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('c,h,w,oh,ow', [(256, 8, 8, 32, 32), (12, 16, 16, 64, 64), (256, 1, 1, 8, 8), (64, 12, 12, 24, 24),
+                                         (9, 10, 12, 40, 48), (128, 7, 5, 14, 10)])
+def test_bilinear(dev, c, h, w, oh, ow):
+    from pylc_amd import ops
+    x = rnd(25, 2, c, h, w)
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, size=(oh, ow), mode='bilinear', align_corners=True)
+    dy = rnd(26, *yr.shape)
+    yr.backward(dy.double())
+    cp = (c + 3) & ~3
+    xd = ops.zeros_nhwc(2, c, h, w, dev, cp)
+    xd.copy_(x.to(dev))
+    xd.requires_grad_(True)
+    y = ops.bilinear(xd, oh, ow)
+    y.backward(dy.to(dev))
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(xd.grad, xr.grad) < 5e-6
+
+
+def test_gap(dev):
+    from pylc_amd import ops
+    x = rnd(27, 3, 2048, 6, 5)
+    xr = x.double().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, 1)
+    dy = rnd(28, *yr.shape)
+    yr.backward(dy.double())
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y = ops.global_avg_pool(xd)
+    y.backward(dy.to(dev))
+    assert rel_err(y, yr) < 2e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+
+
+def test_relu_dropout(dev):
+    from pylc_amd import ops
+    x = rnd(29, 2, 64, 9, 9)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y = ops.relu(xd)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(y.cpu(), F.relu(x)) and torch.equal(xd.grad.cpu(), (x > 0).float())
+    big = torch.ones(4, 256, 32, 32, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    for p in (0.5, 0.1):
+        d = ops.dropout(big, p, 1234)
+        keep = (d != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 0.01
+        assert abs(d.max().item() - 1 / (1 - p)) < 1e-5
+        d2 = ops.dropout(big, p, 1234)
+        assert torch.equal(d, d2)                  # same seed -> same mask (backward regenerates it)
+        d.sum().backward()
+        assert torch.equal((big.grad != 0), (d != 0))
+        big.grad = None
+        assert not torch.equal(d, ops.dropout(big, p, 99))
+
+
+@pytest.mark.parametrize('n_cls,weighted', [(9, False), (9, True), (11, False), (11, True)])
+def test_multiloss_golden(dev, n_cls, weighted):
+    """Against the committed reference outputs (tests/golden/multiloss.*), and the oracle on the same inputs."""
+    import json, os
+    from pylc_amd import ops
+    import oracle
+    from tests import _data as D
+    here = os.path.join(os.path.dirname(__file__), 'golden')
+    gold = json.load(open(os.path.join(here, 'multiloss.json')))
+    arr = np.load(os.path.join(here, 'multiloss.npz'))
+    key = 'c%d_%s' % (n_cls, 'w' if weighted else 'u')
+    rs = np.random.RandomState(300 + n_cls)
+    z = torch.from_numpy((rs.standard_normal((2, n_cls, 40, 36)) * 3).astype(np.float32))
+    t = D.blob_masks(301 + n_cls, 2, 40, 36, n_cls, cell=4)
+    cw = torch.from_numpy(D.class_weights(n_cls))
+    zd = to_dev_nhwc(z, dev).requires_grad_(True)
+    losses = ops.multiloss(zd, t.to(dev), cw.to(dev) if weighted else None, 0.5, 0.5, 0.5)
+    losses[0].backward()
+    got = losses.detach().cpu().tolist()
+    for i, name in enumerate(('total', 'ce', 'dice', 'focal')):
+        assert abs(got[i] - gold[key][name]) < 2e-6 * max(1.0, abs(gold[key][name])), (name, got[i], gold[key][name])
+    g = torch.from_numpy(arr[key + '_grad'])
+    assert rel_err(zd.grad, g) < 1e-5
+    o = oracle.multiloss(z, t, (0.5, 0.5, 0.5), cw, weighted)
+    assert abs(got[0] - o[0].item()) < 2e-6 * max(1.0, abs(got[0]))
+
+
+def test_multiloss_saturated(dev):
+    """Huge logit gaps: -log p_t must come from log-sum-exp, not log(softmax) (no inf / nan)."""
+    from pylc_amd import ops
+    import oracle
+    z = torch.zeros(1, 9, 4, 4)
+    z[:, 0] = 200.0
+    t = torch.ones(1, 4, 4, dtype=torch.int64)
+    zd = to_dev_nhwc(z, dev).requires_grad_(True)
+    losses = ops.multiloss(zd, t.to(dev), None, 0.5, 0.5, 0.5)
+    losses[0].backward()
+    o = oracle.multiloss(z, t)
+    assert torch.isfinite(losses).all() and torch.isfinite(zd.grad).all()
+    assert abs(losses[1].item() - o[1].item()) < 1e-3      # ce = 200
+    assert abs(losses[2].item() - o[2].item()) < 1e-5
+
+
+def test_image_pack(dev):
+    from pylc_amd import ops
+    import oracle
+    from tests import _data as D
+    for ch in (3, 1):
+        img = D.tiles(31, 2, ch, 20, 24)
+        want = oracle.normalize_image(img, oracle.step.PX_RGB_MEAN, oracle.step.PX_RGB_STD)
+        if ch == 1:
+            want = torch.cat((want, want, want), 1)
+            m = float(np.mean(np.asarray(oracle.step.PX_RGB_MEAN, np.float32)))
+            s = float(np.mean(np.asarray(oracle.step.PX_RGB_STD, np.float32)))
+            got = ops.image_pack(img.to(dev), [m] * 3, [s] * 3)
+        else:
+            got = ops.image_pack(img.to(dev), oracle.step.PX_RGB_MEAN, oracle.step.PX_RGB_STD)
+        assert got.shape[1] == 4 and float(got[:, 3].abs().max()) == 0.0
+        assert (got[:, :3].cpu() - want).abs().max().item() < 1e-7
+
+
+def test_adamw_clip(dev):
+    import ctypes as C
+    from pylc_amd.lib import lib, check, ptr, stream
+    n = 100003
+    p0, g0 = rnd(32, n), rnd(33, n, scale=0.01)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-4, weight_decay=5e-5)
+    p, g = p0.to(dev), g0.to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    out2 = torch.empty(2, device=dev)
+    ws = torch.empty(lib.pylc_sqnorm_workspace_floats(n), device=dev)
+    for step in range(1, 4):
+        pr.grad = g0.clone() * step
+        norm_ref = torch.nn.utils.clip_grad_norm_([pr], 0.5)
+        opt.step()
+        gs = (g * step).contiguous()
+        check(lib.pylc_grad_norm_clip(ptr(gs), n, 0.5, ptr(out2), ptr(ws), stream()))
+        check(lib.pylc_adamw_step(ptr(p), ptr(gs), ptr(m), ptr(v), n, ptr(out2), 1e-4, 0.9, 0.999, 1e-8, 5e-5, step, stream()))
+        assert abs(out2[0].item() - norm_ref.item()) < 1e-5 * norm_ref.item()
+        assert (p.cpu() - pr.detach()).abs().max().item() < 2e-7
