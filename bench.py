@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 tiles/sec, fwd+bwd(+clip+AdamW), DeepLabV3+/ResNet101, 9 classes, bs 32 per GPU
+(BASELINE.json configs[2]; weak scaling over N GPUs), synthetic tiles resident in HBM.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline     : the dominant kernel = the 128x128-tile gather-GEMM (implicit-GEMM conv fwd + dgrad); achieved =
+                 algorithmic FLOPs (2*M*N*K with all taps counted) / its launch time measured live with HIP events
+                 on the launch stream over the timed region; peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (a restatement pinned bit-exactly to the reference) timed on the host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+# algorithmic fwd+bwd work per tile, DeepLabV3+/ResNet101 @512^2, 9 classes
+GFLOP_PER_TILE_ALL = 531.40
+GFLOP_PER_TILE_3X3 = 366.0
+
+
+def synth(rank, b, ch, hw, n_cls, dev):
+    x = torch.from_numpy(np.random.RandomState(1234 + rank).randint(0, 256, (b, ch, hw, hw)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(np.random.RandomState(4321 + rank).randint(0, n_cls, (b, hw, hw)).astype(np.int64)).to(dev)
+    return x, y
+
+
+def cpu_baseline(hw, n_cls, budget_s=25.0):
+    """Reference CPU path (oracle) on this box's host cores: bs=2 steps of the same train step, bounded in time."""
+    import oracle
+    from oracle import step as ostep
+    cores = torch.get_num_threads()
+    b = 2
+    cfg = ostep.StepConfig('deeplab', 'resnet', n_cls, 3)
+    sd = oracle.init_state(oracle.state_spec('deeplab', 'resnet', n_cls, 3), seed=0)
+    opt = ostep.make_optimizer(sd, cfg)
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (b, 3, hw, hw)).astype(np.float32))
+    y = torch.from_numpy(np.random.RandomState(2).randint(0, n_cls, (b, hw, hw)).astype(np.int64))
+    t0 = time.time()
+    ostep.train_step(sd, opt, cfg, x, y)          # warm-up (allocator, oneDNN primitive cache)
+    warm = time.time() - t0
+    times = []
+    while sum(times) + warm < budget_s and len(times) < 5:
+        t0 = time.time()
+        ostep.train_step(sd, opt, cfg, x, y)
+        times.append(time.time() - t0)
+    if not times:
+        times = [warm]
+    med = float(np.median(times))
+    return {'value': b / med, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
+            'sample': 'CPU oracle (restatement pinned bit-exactly to the reference), DeepLabV3+/R101 %dx%d bs=%d full '
+                      'train step, %d timed step(s) after 1 warm-up, median' % (hw, hw, b, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='tiles per GPU')
+    ap.add_argument('--tile', type=int, default=512)
+    ap.add_argument('--classes', type=int, default=9)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import pylc_amd
+    from pylc_amd import parallel, ops
+    from pylc_amd.model import Model, Meta
+    rank, world = parallel.init_from_env()
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(0)
+    meta = Meta(arch='deeplab', backbone='resnet', ch=3, n_classes=args.classes, report=10 ** 9)
+    model = Model(meta, dev).build()
+    if world > 1:
+        parallel.broadcast_parameters(model.arena)
+    x, y = synth(rank, args.batch, 3, args.tile, args.classes, dev)
+
+    for _ in range(args.warmup):
+        model.train(x, y)
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train(x, y)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.loss.flush()
+    if rank != 0:
+        return
+    tiles = args.batch * world * args.steps
+    value = tiles / dt
+    out = {
+        'metric': '512x512 tiles/sec fwd+bwd (DeepLabV3+/ResNet101, 9-class)',
+        'value': value, 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'DeepLabV3+ ResNet101 OS16, 3-ch %dx%d tiles, %d classes, CE+Dice+Focal, clip 0.5 + AdamW, '
+                               'bs=%d/GPU (BASELINE.json configs[2])' % (args.tile, args.tile, args.classes, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   'net_tflops_algorithmic': value * GFLOP_PER_TILE_ALL / 1e3 / world,
+                   'last_loss': [float(v) for v in losses[-1]] if losses else None},
+    }
+    if timer is not None:
+        out['roofline'] = timer.roofline(PEAK_F32_MFMA_TFLOPS)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args.tile, args.classes)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

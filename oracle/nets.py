@@ -371,6 +371,22 @@ def state_spec(arch='deeplab', backbone='resnet', n_classes=9, in_channels=3, ou
     return s
 
 
+def _residual_tail_bns(spec):
+    """Keys of the gamma of the last BatchNorm on each residual branch (ResNet bn3, Xception's last rep BN)."""
+    import re
+    out, last = set(), {}
+    for name, (_, kind) in spec.items():
+        if kind != 'bn_w':
+            continue
+        if re.search(r'layer\d+\.\d+\.bn3\.weight$', name):
+            out.add(name)
+        m = re.match(r'^(backbone\.block\d+)\.rep\.(\d+)\.weight$', name)
+        if m and int(m.group(2)) >= last.get(m.group(1), (-1, None))[0]:
+            last[m.group(1)] = (int(m.group(2)), name)
+    out.update(v[1] for v in last.values())
+    return out
+
+
 def _seed(name, salt):
     return (zlib.crc32(name.encode()) ^ (salt * 0x9E3779B1)) & 0xFFFFFFFF
 
@@ -383,11 +399,21 @@ def formula_state(spec, salt=0, dtype=torch.float32):
     so every term of the BN arithmetic is exercised.
     """
     sd = OrderedDict()
+    damped = _residual_tail_bns(spec)
     for name, (shape, kind) in spec.items():
         rs = np.random.RandomState(_seed(name, salt))
+        if name in damped:
+            # gamma ~ 0.25 on the last BN of every residual branch: with full-strength random residual branches a
+            # 33-block ResNet amplifies fp32 rounding noise ~1.2x per block (measured: two CPU runs with different
+            # thread counts disagree by 1e-1 in the logits), which would make any fixture meaningless.  Trained /
+            # zero-gamma-initialised networks are in this damped regime.
+            sd[name] = torch.from_numpy(0.25 * (1.0 + 0.1 * rs.standard_normal(shape))).to(dtype)
+            continue
         if kind.startswith('conv_w'):
             fan_in = shape[1] * shape[2] * shape[3]
             v = rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+            if name in ('decoder.last_conv.8.weight', 'last.weight'):
+                v *= 0.2          # classifier head: keeps the logits O(1) so the 1e-3 ABSOLUTE logit tolerance is meaningful
         elif kind.startswith('conv_b'):
             v = rs.standard_normal(shape) * 0.05
         elif kind == 'bn_w':

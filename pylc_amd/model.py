@@ -1,0 +1,206 @@
+"""Model wrapper of the HIP path: the counterpart of the reference's models/model.py:29-492 for the training /
+validation / inference step (`Model.train(x, y)`, `.eval(x, y)`, `.test(x)`), i.e. the three hot-path entry
+points called from train.py:118, train.py:149 and test.py:82.
+
+Differences that are deliberate and MI355X-driven (results are the same):
+  * input normalisation (model.py:416-445), the grayscale x3 stack (:310-311) and NCHW->NHWC packing are ONE
+    kernel on the device instead of CPU tensor ops before the H2D copy;
+  * the three per-step `.item()` host syncs (model.py:319) are replaced by a device-side loss log that is
+    only read at `report` intervals;
+  * clip_grad_norm_ + AdamW run over one flat parameter arena (pylc_amd/optim.py).
+The dead random flip (model.py:296-298: `random.randint(0, 1)` is always 0) is not reproduced.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .loss import MultiLoss
+from .nets import DeepLab, UNet
+from .optim import FlatArena, FlatAdamW, FlatSGD, StepLR
+from .runtime import runtime
+
+
+class Meta:
+    """The hot-path subset of config.py:85-248 `Parameters`, as explicit attributes (no global singleton)."""
+
+    def __init__(self, **kw):
+        self.arch = 'deeplab'              # config.py:215
+        self.backbone = 'resnet'           # config.py:217
+        self.ch = 3
+        self.n_classes = 9                 # schema_a
+        self.class_codes = None
+        self.class_labels = None
+        self.px_mean = [132.47, 144.47, 149.45]     # config.py:171 (px_rgb_mean) -- DB metadata overrides
+        self.px_std = [24.85, 22.04, 18.77]         # config.py:172
+        self.px_grayscale_mean = 142.01             # config.py:173
+        self.px_grayscale_std = 23.66               # config.py:174
+        self.normalize_default = False
+        self.weights = None                # class weights from the dataset profile (utils/profile.py:129-130)
+        self.weighted = False              # config.py:200
+        self.dice_weight = 0.5             # config.py:201-203
+        self.ce_weight = 0.5
+        self.focal_weight = 0.5
+        self.lr = 1e-4                     # config.py:193
+        self.weight_decay = 5e-5           # config.py:205
+        self.momentum = 0.9
+        self.gamma = 0.9                   # config.py:196
+        self.optim_type = 'adam'           # always 'adam' in the reference (flags ignored)
+        self.clip_norm = 0.5               # model.py:326
+        self.dropout = 0.5                 # config.py:191
+        self.up_mode = 'upsample'          # config.py:231
+        self.pad_size = 94                 # (512 - 324) // 2, config.py:230; the valid-conv shrink is 188 px at any size
+        self.report = 20                   # config.py:240
+        self.pretrained = False
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError('unknown Meta field %r' % k)
+            setattr(self, k, v)
+
+    def update(self, other):
+        """Copy only keys that already exist (config.py:259-269 semantics)."""
+        src = other if isinstance(other, dict) else vars(other)
+        for k, v in src.items():
+            if hasattr(self, k):
+                setattr(self, k, v)
+        return self
+
+
+class LossLog:
+    """Device-side replacement of RunningLoss.intv (models/modules/loss.py:218-305): per-step (ce, dice, focal)
+    triples stay on the GPU; `flush()` does the one D2H copy per report interval."""
+
+    def __init__(self):
+        self._pending = []
+        self.intv = []
+        self.train, self.valid, self.lr = [], [], []
+
+    def push(self, triple):
+        self._pending.append(triple)
+
+    def flush(self):
+        if self._pending:
+            vals = torch.stack(self._pending).cpu().tolist()
+            self.intv += [tuple(v) for v in vals]
+            self._pending = []
+        return self.intv
+
+    def log(self, it, training):
+        self.flush()
+        if self.intv:
+            avg = tuple(np.mean(np.asarray(self.intv), axis=0).tolist())
+            (self.train if training else self.valid).append((it,) + avg)
+        self.intv = []
+
+
+class Model:
+    def __init__(self, meta=None, device=None):
+        self.meta = meta if meta is not None else Meta()
+        self.device = torch.device(device if device is not None else 'cuda:0')
+        self.net = self.crit = self.optim = self.sched = self.arena = None
+        self.loss = LossLog()
+        self.iter = 0
+        self.epoch = 0
+
+    def update_meta(self, params):
+        self.meta.update(params)
+        return self
+
+    # ---- construction (model.py:123-220) -------------------------------------------------------------------
+    def build(self):
+        m = self.meta
+        if m.arch == 'unet':
+            self.net = UNet(in_channels=m.ch, n_classes=m.n_classes, up_mode=m.up_mode, dropout=m.dropout)
+        elif m.arch == 'deeplab':
+            self.net = DeepLab(backbone=m.backbone, n_classes=m.n_classes, in_channels=m.ch, pretrained=False)
+        else:
+            raise ValueError('Model {} not available.'.format(m.arch))
+        self.net = self.net.to(self.device)
+        self.crit = MultiLoss(
+            loss_weights={'weighted': m.weighted, 'weights': m.weights, 'ce': m.ce_weight, 'dice': m.dice_weight,
+                          'focal': m.focal_weight},
+            schema={'n_classes': m.n_classes, 'class_codes': m.class_codes, 'class_labels': m.class_labels}).to(self.device)
+        self.init_optim()
+        return self
+
+    def init_optim(self):
+        """model.py:238-280.  Call again after load_state_dict() into self.net is NOT needed: the arena aliases
+        the parameters, so loading a state dict writes straight into it."""
+        m = self.meta
+        self.arena = FlatArena(self.net)
+        if m.optim_type == 'adam':
+            self.optim = FlatAdamW(self.arena, lr=m.lr, weight_decay=m.weight_decay, clip=m.clip_norm)
+        elif m.optim_type == 'sgd':
+            self.optim = FlatSGD(self.arena, lr=m.lr, momentum=m.momentum, clip=m.clip_norm)
+        else:
+            raise ValueError('Optimizer is not defined.')
+        self.sched = StepLR(self.optim, m.gamma)
+
+    # ---- input handling (model.py:301-311, 416-445) ------------------------------------------------------------
+    def _stats(self, default=False):
+        m = self.meta
+        if m.ch == 1:
+            if default:
+                raise NotImplementedError('normalize_default for grayscale omits the /255 (model.py:431-432); not built')
+            mean = float(np.mean(np.asarray(m.px_mean, np.float32)))
+            std = float(np.mean(np.asarray(m.px_std, np.float32)))
+            return [mean] * 3, [std] * 3
+        if default:
+            return [132.47, 144.47, 149.45], [24.85, 22.04, 18.77]
+        return list(m.px_mean), list(m.px_std)
+
+    def pack_input(self, x, default=False):
+        """raw [B,ch,H,W] 0..255 (host or device) -> normalised NHWC4 device tensor."""
+        if x.dim() != 4 or x.shape[1] != self.meta.ch:
+            raise ValueError('expected [B,%d,H,W] tiles, got %s' % (self.meta.ch, tuple(x.shape)))
+        x = x.to(self.device, dtype=torch.float32, non_blocking=True)
+        mean, std = self._stats(default)
+        return ops.image_pack(x, mean, std)
+
+    def crop_target(self, y):
+        if self.meta.arch == 'unet':
+            p = self.meta.pad_size
+            y = y[:, p:y.shape[1] - p, p:y.shape[2] - p]          # model.py:306-307 at any tile size
+        return y.contiguous()
+
+    # ---- the three hot-path entry points ---------------------------------------------------------------------
+    def train(self, x, y):
+        """One optimisation step (model.py:282-336)."""
+        self.net.train()
+        x4 = self.pack_input(x)
+        y = self.crop_target(y.to(self.device, non_blocking=True))
+        y_hat = self.net(x4)
+        loss = self.crit(y_hat, y)
+        self.loss.push(torch.stack((self.crit.ce, self.crit.dsc, self.crit.fl)))
+        self.optim.zero_grad()
+        loss.backward()
+        if runtime.sync_group is not None:
+            from .parallel import allreduce_gradients
+            allreduce_gradients(self.arena, runtime.sync_group)
+        self.optim.step()
+        if self.iter % self.meta.report == 0:
+            self.log()
+        self.loss.lr += [(self.iter, self.optim.lr)]
+        self.iter += 1
+        return loss.detach()
+
+    def eval(self, x, y):
+        """Validation step (model.py:338-365): eval-mode forward, the three losses, returns [y_hat]."""
+        self.net.eval()
+        x4 = self.pack_input(x)
+        y = self.crop_target(y.to(self.device, non_blocking=True))
+        with torch.no_grad():
+            y_hat = self.net(x4)
+            self.loss.push(self.crit.all_losses(y_hat, y)[1:4])
+        return [y_hat]
+
+    def test(self, x):
+        """Inference forward (model.py:367-382)."""
+        x4 = self.pack_input(x, default=self.meta.normalize_default)
+        with torch.no_grad():
+            return [self.net(x4)]
+
+    def log(self):
+        self.loss.log(self.iter, self.net.training)
+
+    def get_lr(self):
+        return self.optim.lr

@@ -72,6 +72,52 @@ def _r4(c):
 
 
 # ----------------------------------------------------------------------------------------------
+# live kernel timing (bench.py's roofline leg)
+# ----------------------------------------------------------------------------------------------
+class KernelTimer:
+    """HIP-event timing of the dominant kernel's launches on the stream they are launched on.
+
+    Only launches that dispatch to gather_gemm_kernel<128,128,64,64,false> (pylc_amd/csrc/conv_igemm.hip: Cout_store > 64,
+    Cin % 4 == 0 and not the thin-input mode) are bracketed; FLOPs are algorithmic (2*M*N*K, every tap counted)."""
+
+    def __init__(self):
+        self.records = []          # (start_event, end_event, flops, launches, kind)
+
+    def bracket(self, flops, launches, kind):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((a, b, flops, launches, kind))
+        return a, b
+
+    def roofline(self, peak_tflops):
+        torch.cuda.synchronize()
+        tot_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in self.records)
+        flops = sum(r[2] for r in self.records)
+        launches = sum(r[3] for r in self.records)
+        by = {}
+        for a, b, f, n, kind in self.records:
+            e = by.setdefault(kind, [0.0, 0.0, 0])
+            e[0] += a.elapsed_time(b); e[1] += f; e[2] += n
+        ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        return {'bound': 'mfma', 'achieved': ach, 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': ach / peak_tflops,
+                'traffic': None, 'kernel': 'gather_gemm_kernel<128,128,64,64,false>', 'launches': launches,
+                'avg_launch_ms': tot_ms / max(launches, 1), 'kernel_time_ms_total': tot_ms,
+                'by_kind': {k: {'ms': v[0], 'tflops': v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0, 'launches': v[2]}
+                            for k, v in by.items()}}
+
+
+_timer = None
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
+def _is_big_tile(n_store, cin, taps):
+    return n_store > 64 and not (cin == 4 and taps > 1)
+
+
+# ----------------------------------------------------------------------------------------------
 # dense convolution
 # ----------------------------------------------------------------------------------------------
 def _conv_desc(x, cin, cout, r, s, stride, pad, dil, x_pitch, y_pitch):
@@ -125,7 +171,13 @@ class Conv2dFn(torch.autograd.Function):
         yp = _r4(cout)
         y = empty_nhwc(b, cout, oh, ow, x.device, yp)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
+        ev = None
+        if _timer is not None and _is_big_tile(yp, cin, r * s):
+            ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s))
+            ev[0].record()
         check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
+        if ev is not None:
+            ev[1].record()
         ctx.save_for_backward(x, w_k)
         ctx.geom = (stride, pad, dil, cin_w, bias is not None)
         ctx.w_param, ctx.b_param = w, bias
@@ -153,7 +205,14 @@ class Conv2dFn(torch.autograd.Function):
             check(lib.pylc_weight_transpose(ptr(w_k), ptr(wt), cout, r * s, cin, st))
             dx = empty_nhwc(*x.shape, device=x.device)
             d.x_pitch = cin
+            ev = None
+            if _timer is not None and _is_big_tile(cin, kp, 2):
+                n_launch = 1 if stride == 1 else min(r, 2) * min(s, 2)     # one launch per non-empty output parity class
+                ev = _timer.bracket(2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * r * s * cin, n_launch, 'dgrad%dx%d' % (r, s))
+                ev[0].record()
             check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, st))
+            if ev is not None:
+                ev[1].record()
             d.x_pitch = pitch_of(x)
         if ctx.needs_input_grad[1]:
             nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))

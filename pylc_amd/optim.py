@@ -1,0 +1,132 @@
+"""Flat-arena optimiser: every parameter (and its gradient, and both Adam moments) lives in ONE contiguous
+fp32 buffer, so global-norm clipping + AdamW is three kernel launches and the data-parallel gradient
+exchange is a handful of large RCCL all-reduces instead of 341 small ones.
+
+Replaces torch.optim.AdamW / SGD + clip_grad_norm_ as used at models/model.py:238-254,322-328 and
+StepLR at models/model.py:256-263 / train.py:91."""
+import torch
+
+from . import lib as L
+from .lib import lib, check, ptr, stream
+
+
+def _dense_numel(p):
+    return p.numel()
+
+
+class FlatArena:
+    """Re-homes the parameters of `module` into one buffer (keeping every tensor's shape and strides, e.g. the
+    KRSC memory of conv weights) and gives each a same-layout gradient view registered as `p._pylc_grad`,
+    which the backward kernels write directly (pylc_amd/ops.py:_deliver_grad)."""
+
+    ALIGN = 4       # floats (16 B): every tensor starts on a vector boundary
+
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('module has no trainable parameters')
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = total
+        self.params = params
+        self.offsets = offs
+        self.p = torch.zeros(total, device=dev)
+        self.g = torch.zeros(total, device=dev)
+        for p, o in zip(params, offs):
+            dst = torch.as_strided(self.p, p.shape, p.stride(), o)
+            dst.copy_(p.data)
+            p.data = dst
+            p._pylc_grad = torch.as_strided(self.g, p.shape, p.stride(), o)
+            p.grad = p._pylc_grad
+
+    def zero_grad(self):
+        self.g.zero_()
+
+
+class _FlatOptimizer:
+    def __init__(self, arena, lr, clip):
+        self.arena = arena
+        self.lr = float(lr)
+        self.clip = clip
+        self.steps = 0
+        dev = arena.p.device
+        self.norm = torch.zeros(2, device=dev)           # [grad L2 norm, clip coefficient] of the last step
+        self._ws = torch.empty(lib.pylc_sqnorm_workspace_floats(arena.numel), device=dev)
+        self.param_groups = [{'lr': self.lr}]             # models/model.py:394-397 get_lr() reads this
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients are overwritten by the backward kernels every step; nothing to clear."""
+
+    def _clip(self):
+        a = self.arena
+        if self.clip is None:
+            return None
+        check(lib.pylc_grad_norm_clip(ptr(a.g), a.numel, float(self.clip), ptr(self.norm), ptr(self._ws), stream()))
+        return self.norm
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.param_groups[0]['lr'] = self.lr
+
+
+class FlatAdamW(_FlatOptimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt) preceded by
+    torch.nn.utils.clip_grad_norm_(params, clip)."""
+
+    def __init__(self, arena, lr=1e-4, weight_decay=5e-5, betas=(0.9, 0.999), eps=1e-8, clip=0.5):
+        super().__init__(arena, lr, clip)
+        self.wd, self.betas, self.eps = float(weight_decay), betas, float(eps)
+        self.m = torch.zeros_like(arena.p)
+        self.v = torch.zeros_like(arena.p)
+
+    def step(self):
+        L.init()
+        a = self.arena
+        coef = self._clip()
+        self.steps += 1
+        check(lib.pylc_adamw_step(ptr(a.p), ptr(a.g), ptr(self.m), ptr(self.v), a.numel, ptr(coef), self.lr,
+                                  self.betas[0], self.betas[1], self.eps, self.wd, self.steps, stream()))
+
+    def state_dict(self):
+        return {'kind': 'flat_adamw', 'steps': self.steps, 'lr': self.lr, 'm': self.m, 'v': self.v}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd['steps'])
+        self.set_lr(sd['lr'])
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+
+
+class FlatSGD(_FlatOptimizer):
+    def __init__(self, arena, lr=1e-4, momentum=0.9, clip=0.5):
+        super().__init__(arena, lr, clip)
+        self.momentum = float(momentum)
+        self.buf = torch.zeros_like(arena.p)
+
+    def step(self):
+        L.init()
+        a = self.arena
+        coef = self._clip()
+        self.steps += 1
+        check(lib.pylc_sgd_step(ptr(a.p), ptr(a.g), ptr(self.buf), a.numel, ptr(coef), self.lr, self.momentum, self.steps, stream()))
+
+    def state_dict(self):
+        return {'kind': 'flat_sgd', 'steps': self.steps, 'lr': self.lr, 'buf': self.buf}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd['steps'])
+        self.set_lr(sd['lr'])
+        self.buf.copy_(sd['buf'])
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size=1, gamma): lr <- lr * gamma once per epoch (train.py:91)."""
+
+    def __init__(self, optim, gamma=0.9):
+        self.optim, self.gamma = optim, gamma
+
+    def step(self):
+        self.optim.set_lr(self.optim.lr * self.gamma)

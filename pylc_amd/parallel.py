@@ -1,0 +1,68 @@
+"""Tile-batch data parallelism: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+
+The reference has no working multi-GPU path (nn.DataParallel is commented out at models/model.py:186-188 and
+the vendored models/sync_batchnorm is never constructed), so the contract here is "N ranks == one process at the
+global batch" (SURVEY.md section 8e):
+  * BatchNorm statistics and their backward sums are all-reduced per layer (pylc_amd/ops.py BnActFn) -- the
+    RCCL form of batchnorm.py:48-125's master/slave reduce+broadcast;
+  * the loss head all-reduces its 3+3C partial sums before the non-linear Dice / weighted-CE finalisation;
+  * gradients are SUMMED over ranks (the loss is already the global mean) in a few large buckets of the flat
+    gradient arena.  xGMI is point-to-point (7 links/GPU): large buckets keep every link busy and amortise the
+    per-collective latency; 59.3 M fp32 gradients = 237 MB = 4 buckets of 64 MB.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .runtime import runtime
+
+BUCKET_FLOATS = 16 * 1024 * 1024        # 64 MB
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world == 1:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(0)
+        return 0, 1
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend)
+    runtime.sync_group = dist.group.WORLD
+    runtime.manual_seed(runtime.seed, rank)
+    return rank, world
+
+
+def bucket_ranges(numel, bucket=BUCKET_FLOATS):
+    return [(o, min(numel, o + bucket)) for o in range(0, numel, bucket)]
+
+
+def allreduce_gradients(arena, group=None):
+    """SUM-all-reduce the flat gradient arena in large buckets; returns when the reduced values are visible to the
+    current stream (torch's NCCL work objects order the collective against it)."""
+    works = []
+    for lo, hi in bucket_ranges(arena.numel):
+        works.append(dist.all_reduce(arena.g[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
+def broadcast_parameters(arena, group=None, src=0):
+    """Make every rank start from rank `src`'s parameters (replicas must be identical)."""
+    for lo, hi in bucket_ranges(arena.numel):
+        dist.broadcast(arena.p[lo:hi], src, group=group)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,141 @@
+"""Whole-network parity on the MI355X (-m gpu): HIP path vs the committed reference outputs
+(tests/golden/*.npz|json, generated from the real reference by tests/golden/make_golden.py) and vs the
+CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): logits / loss within 1e-3 in fp32; argmax masks bit-exact wherever the
+reference's own top-1/top-2 margin exceeds the logit tolerance (ties / near-ties are identified by the margin
+fixture instead of failing spuriously, SURVEY.md section 7 'Hard parts').
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.join(os.path.dirname(__file__), 'golden')
+LOGIT_TOL = 1e-3
+LOSS_TOL = 1e-3
+
+
+def load_golden(tag):
+    meta = json.load(open(os.path.join(HERE, tag + '.json')))
+    arr = np.load(os.path.join(HERE, tag + '.npz'))
+    return meta, arr
+
+
+def make_model(meta_g, dev):
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import runtime
+    from tests import _data as D
+    c = meta_g['config']
+    runtime.dropout_enabled = False
+    cfg = ostep.StepConfig(c['arch'], c['backbone'], c['n_classes'], c['ch'], dropout=False)
+    spec = oracle.state_spec(c['arch'], c['backbone'], c['n_classes'], 3 if c['arch'] == 'deeplab' else c['ch'])
+    x = D.tiles(c['tile_seed'], c['b'], c['ch'], c['hw'], c['hw'])
+    y = D.blob_masks(c['mask_seed'], c['b'], c['hw'], c['hw'], c['n_classes'], cell=c['mask_cell'])
+    w = ostep.calibrate_bn(oracle.formula_state(spec, salt=c['weight_salt']), cfg, x.clone())
+    meta = Meta(arch=c['arch'], backbone=c['backbone'], ch=c['ch'], n_classes=c['n_classes'],
+                weights=[float(v) for v in D.class_weights(c['n_classes'])])
+    model = Model(meta, dev).build()
+    assert [(k, list(v.shape)) for k, v in model.net.state_dict().items()] == [(k, list(s)) for k, s in meta_g['keys']]
+    model.net.load_state_dict(w)
+    return model, cfg, w, x, y
+
+
+@pytest.mark.parametrize('tag', ['deeplab_resnet', 'deeplab_xception', 'unet'])
+def test_eval_forward_matches_reference(dev, tag):
+    meta_g, arr = load_golden(tag)
+    model, cfg, w, x, y = make_model(meta_g, dev)
+    model.net.eval()
+    logits = model.test(x)[0]
+    ref = torch.from_numpy(arr['eval_logits'])
+    assert tuple(logits.shape) == tuple(ref.shape)
+    got = logits.float().cpu()
+    err = (got - ref).abs().max().item()
+    print('%s eval logits max|diff| = %.3g (|ref| max %.3g)' % (tag, err, ref.abs().max().item()))
+    assert err < LOGIT_TOL
+    # argmax: bit-exact wherever the reference margin is above the logit tolerance
+    margin = torch.from_numpy(arr['eval_margin'])
+    am = got.argmax(1).to(torch.uint8)
+    ref_am = torch.from_numpy(arr['eval_argmax'])
+    decided = margin > 2 * LOGIT_TOL
+    assert decided.float().mean().item() > 0.95
+    assert torch.equal(am[decided], ref_am[decided])
+    # validation losses (Model.eval semantics)
+    model.eval(x, y)
+    ce, dice, fl = model.loss.flush()[-1]
+    for a, b in zip((ce, dice, fl), meta_g['eval_losses']):
+        assert abs(a - b) < LOSS_TOL, (a, b)
+
+
+@pytest.mark.parametrize('tag', ['deeplab_resnet', 'deeplab_xception', 'unet'])
+def test_train_steps_match_reference(dev, tag):
+    """Two Model.train steps (dropout off): losses, clipped gradients and post-AdamW state vs the reference."""
+    meta_g, arr = load_golden(tag)
+    model, cfg, w, x, y = make_model(meta_g, dev)
+    steps = meta_g['train_steps']
+    zero_keys = set(meta_g.get('zero_grad_keys', []))
+    for it in range(2):
+        model.train(x, y)
+        ce, dice, fl = [float(v) for v in (model.crit.ce, model.crit.dsc, model.crit.fl)]
+        print('%s step %d: (%.6f %.6f %.6f) ref (%.6f %.6f %.6f)' % (tag, it, ce, dice, fl, steps[it]['ce'], steps[it]['dice'], steps[it]['focal']))
+        assert abs(ce - steps[it]['ce']) < LOSS_TOL and abs(dice - steps[it]['dice']) < LOSS_TOL and abs(fl - steps[it]['focal']) < LOSS_TOL
+        gnorm, coef = model.optim.norm.cpu().tolist()
+        cond = meta_g['conditioning_train'][it]          # reference-vs-reference noise of this fixture (1 vs 8 CPU threads)
+        if it == 0:
+            gd = meta_g['grad_digest_step0']
+            gcond = meta_g['grad_conditioning_step0']
+            gmax = max(v[2] for v in gd.values())
+            worst = 0.0
+            for k, p in model.net.named_parameters():
+                if k in zero_keys:
+                    continue
+                l2 = float((p.grad.double() * coef).pow(2).sum().sqrt())
+                ref_s, _, ref_l2 = gd[k]
+                tol = max(5e-3, 4 * gcond[k])
+                worst = max(worst, abs(l2 - ref_l2) / (ref_l2 + 1e-3 * gmax))
+                assert abs(l2 - ref_l2) <= tol * ref_l2 + 1e-4 * gmax, (k, l2, ref_l2, gcond[k])
+            assert abs(gnorm - steps[it]['grad_norm_preclip']) < max(2e-3, 4 * cond['gnorm_rel']) * steps[it]['grad_norm_preclip']
+            print('%s worst grad-l2 rel diff %.3g' % (tag, worst))
+            sdg = meta_g['state_digest_step0']
+            for k, v in model.net.state_dict().items():
+                if not v.is_floating_point():
+                    continue
+                l2 = float(v.double().pow(2).sum().sqrt())
+                assert abs(l2 - sdg[k][2]) <= 1e-4 * sdg[k][2] + 3e-4 * (v.numel() ** 0.5), (k, l2, sdg[k][2])
+    nbt = [v for k, v in model.net.state_dict().items() if k.endswith('num_batches_tracked')]
+    assert all(int(t) == 2 for t in nbt)
+
+
+def test_oracle_parity_deeplab_train_mode_logits(dev):
+    """Training-mode forward (batch statistics) against the CPU oracle at a second, non-fixture size."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import runtime
+    from tests import _data as D
+    runtime.dropout_enabled = False
+    cfg = ostep.StepConfig('deeplab', 'resnet', 9, 3, dropout=False)
+    spec = oracle.state_spec('deeplab', 'resnet', 9, 3)
+    x = D.tiles(555, 3, 3, 80, 112)
+    w = oracle.formula_state(spec, salt=3)
+    sd = {k: v.clone() for k, v in w.items()}
+    xin, _ = ostep._prep(cfg, x.clone())
+    with torch.no_grad():
+        want = ostep.forward(sd, cfg, xin, True)
+    model = Model(Meta(), dev).build()
+    model.net.load_state_dict(w)
+    model.net.train()
+    with torch.no_grad():
+        got = model.net(model.pack_input(x)).float().cpu()
+    assert (got - want).abs().max().item() < LOGIT_TOL
+    # running statistics after one training forward
+    new = model.net.state_dict()
+    for k in ('backbone.bn1.running_var', 'backbone.layer3.22.bn3.running_mean', 'aspp.global_avg_pool.2.running_var',
+              'decoder.last_conv.5.running_var'):
+        assert (new[k].cpu() - sd[k]).abs().max().item() < 1e-4 * max(1.0, sd[k].abs().max().item()), k
