@@ -66,14 +66,6 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void bn_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ sums) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 2C
-    if (i >= 2 * C) return;
-    double acc = 0.0;
-    for (int s = 0; s < nslab; ++s) acc += (double)partial[(size_t)s * 2 * C + i];
-    sums[i] = (float)acc;
-}
-
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
                                    float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
@@ -222,7 +214,7 @@ extern "C" int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, fl
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nslab), dim3(256), 0, st, y, y_pitch, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, g, C,
                        workspace);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, g.nslab, C, sums);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -271,7 +263,7 @@ extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
                        relu, g, C, workspace);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, workspace, g.nslab, C, sums);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

@@ -68,14 +68,6 @@ __global__ __launch_bounds__(256) void multiloss_stats_kernel(const float* __res
     }
 }
 
-__global__ void multiloss_combine_kernel(const float* __restrict__ partial, int nblocks, int K, float* __restrict__ stats) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += (double)partial[(size_t)b * K + k];
-    stats[k] = (float)acc;
-}
-
 __global__ void multiloss_finalize_kernel(const float* __restrict__ stats, double n, int C, float w_ce, float w_d, float w_f,
                                           float* __restrict__ losses) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -170,7 +162,7 @@ extern "C" int pylc_multiloss_stats(const float* logits, int pitch, const int64_
 #undef LAUNCH_STATS
     PYLC_LAUNCH_CHECK();
     const int K = 3 + 3 * C;
-    hipLaunchKernelGGL(multiloss_combine_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, K, stats);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(K, 16)), dim3(256), 0, st, workspace, blocks, K, stats);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
