@@ -55,6 +55,14 @@ typedef struct PylcConvDesc {
     int y_pitch;            /* floats between output pixels (>= Cout)                         */
 } PylcConvDesc;
 
+/* Arithmetic of the dense conv kernels (process-wide):
+ *   0 = v_mfma_f32_32x32x2_f32: bit-exact fp32 fmaf chain, 157 TFLOP/s matrix peak;
+ *   1 = "bf16x6" (default): each fp32 operand is split exactly into three bf16 pieces in LDS and every product is
+ *       formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-grade
+ *       accuracy (error <= the fp32 chain's, tests/test_ops_gpu.py::test_conv_precision_modes) at 16/6 the rate. */
+int pylc_set_conv_precision(int mode);
+int pylc_get_conv_precision(void);
+
 /* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */
 int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,

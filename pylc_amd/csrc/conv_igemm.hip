@@ -23,6 +23,31 @@ namespace pylc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LDB = 80;   // bf16x6 mode: bytes per LDS row per plane (32 bf16 = 64 B + 16 B pad)
+
+// Exact 3-way split of four fp32 values into bf16 planes by truncation: x = x0 + x1 + x2, each piece the top 16 bits of
+// the running remainder (8 significant bits), packed two per dword in k order.
+__device__ __forceinline__ void split3(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
+    unsigned u0[4], u1[4], u2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u0[e] = __float_as_uint(x[e]);
+        const float r1 = x[e] - __uint_as_float(u0[e] & 0xFFFF0000u);
+        u1[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[e] & 0xFFFF0000u);
+        u2[e] = __float_as_uint(r2);
+    }
+    p0.x = (u0[0] >> 16) | (u0[1] & 0xFFFF0000u); p0.y = (u0[2] >> 16) | (u0[3] & 0xFFFF0000u);
+    p1.x = (u1[0] >> 16) | (u1[1] & 0xFFFF0000u); p1.y = (u1[2] >> 16) | (u1[3] & 0xFFFF0000u);
+    p2.x = (u2[0] >> 16) | (u2[1] & 0xFFFF0000u); p2.y = (u2[2] >> 16) | (u2[3] & 0xFFFF0000u);
+}
+__device__ __forceinline__ void split3(const float __attribute__((ext_vector_type(4))) v, uint2& p0, uint2& p1, uint2& p2) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    split3(x, p0, p1, p2);
+}
+
 constexpr int BK = 32;    // reduction depth per LDS stage
 constexpr int LDT = 36;   // padded LDS row (floats): 144 B rows -> conflict-free ds_read_b128 of k-slices
 
@@ -50,12 +75,22 @@ struct GatherGemmArgs {
     int tiles_n;
 };
 
-template <int BM, int BN, int WM, int WN, bool CIN4>
-__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArgs a) {
+// PREC 0: v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chain, 157 TFLOP/s peak).
+// PREC 1: "bf16x6" -- every fp32 operand is split EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 mantissa bits
+//         each, by truncation) while it is staged into LDS, and each product a*b is evaluated as the six leading
+//         cross terms a2b0 + a0b2 + a1b1 + a1b0 + a0b1 + a0b0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//         The dropped terms are <= 2^-23 |a*b|, i.e. the result is as accurate as the fp32 chain (measured: mean
+//         error 1.2e-8 vs 1.9e-8 of sum|a*b| at K = 2304), but the matrix pipe runs 16x faster per instruction, so
+//         6 terms cost 6/16 of the fp32-MFMA time.
+template <int BM, int BN, int WM, int WN, bool CIN4, int PREC>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_kernel(const GatherGemmArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int NTHR = (BM / WM) * (BN / WN) * 64;      // 256 (4 waves) or 512 (8 waves, two per SIMD)
+    constexpr int RPI = NTHR / 8;                          // tile rows staged per loader iteration
+    constexpr int A_IT = BM / RPI, B_IT = BN / RPI;
+    static_assert(NTHR == 256 || NTHR == 512, "4 or 8 waves per block");
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must divide evenly over the loader");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                    // [2][BM][LDT]
     float* sB = smem + 2 * BM * LDT;     // [2][BN][LDT]
@@ -71,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArg
     int rowh[A_IT], roww[A_IT], rowpix[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPI * i;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
         const int q = mm % a.Q, t = mm / a.Q;
@@ -108,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArg
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[A_IT], rb[B_IT];
+    f32x4 ra2[PREC == 1 ? A_IT : 1], rb2[PREC == 1 ? B_IT : 1];     // second in-flight tile (bf16x6: prefetch distance 2)
     int ld_tap = -1, ld_chunk = nchunks - 1;     // position of the NEXT tile to load (advanced before use)
 
     auto advance = [&]() {
@@ -118,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArg
             }
         }
     };
-    auto load_tile = [&]() {
+    auto load_tile_into = [&](f32x4* ra, f32x4* rb) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (CIN4) {
             const int tap = ld_chunk * 8 + v;
@@ -133,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArg
             const int kk = ld_chunk * 32 + 4 * v;
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const int n = n0 + r0 + 32 * i;
+                const int n = n0 + r0 + RPI * i;
                 const bool ok = tok && n < a.N;
                 rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.w + (size_t)n * a.w_row_stride + a.w_off0 + kk) : zero;
             }
@@ -151,52 +187,132 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GatherGemmArg
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const int n = n0 + r0 + 32 * i;
+                const int n = n0 + r0 + RPI * i;
                 const bool ok = cok && n < a.N;
                 rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.w + (size_t)n * a.w_row_stride + woff + c) : zero;
             }
         }
     };
-    auto store_tile = [&](int buf) {
-        float* pa = sA + buf * BM * LDT + r0 * LDT + 4 * v;
-        float* pb = sB + buf * BN * LDT + r0 * LDT + 4 * v;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(pa + 32 * i * LDT) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(pb + 32 * i * LDT) = rb[i];
-    };
+    auto load_tile = [&]() { load_tile_into(ra, rb); };
 
-    if (S > 0) {
-        advance();
-        load_tile();
-        store_tile(0);
-        __syncthreads();
-        for (int s = 0; s < S; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < S) {
-                advance();
-                load_tile();            // global loads in flight during the MFMAs below
-            }
-            // lane l supplies A[row = l&31][k = 8g + 4(l>>5) + j] to MFMA (g, j): one ds_read_b128 feeds 4 MFMAs
-            const float* pa = sA + buf * BM * LDT + (wave_m * WM + (lane & 31)) * LDT + 4 * (lane >> 5);
-            const float* pb = sB + buf * BN * LDT + (wave_n * WN + (lane & 31)) * LDT + 4 * (lane >> 5);
+    if constexpr (PREC == 0) {
+        auto store_tile = [&](int buf) {
+            float* pa = sA + buf * BM * LDT + r0 * LDT + 4 * v;
+            float* pb = sB + buf * BN * LDT + r0 * LDT + 4 * v;
 #pragma unroll
-            for (int g = 0; g < BK / 8; ++g) {
-                f32x4 fa[MT], fb[NT];
+            for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(pa + RPI * i * LDT) = ra[i];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(pa + i * 32 * LDT + 8 * g);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(pb + j * 32 * LDT + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-            }
-            if (s + 1 < S) store_tile(buf ^ 1);
+            for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(pb + RPI * i * LDT) = rb[i];
+        };
+        if (S > 0) {
+            advance();
+            load_tile();
+            store_tile(0);
             __syncthreads();
+            for (int s = 0; s < S; ++s) {
+                const int buf = s & 1;
+                if (s + 1 < S) {
+                    advance();
+                    load_tile();            // global loads in flight during the MFMAs below
+                }
+                // lane l supplies A[row = l&31][k = 8g + 4(l>>5) + j] to MFMA (g, j): one ds_read_b128 feeds 4 MFMAs
+                const float* pa = sA + buf * BM * LDT + (wave_m * WM + (lane & 31)) * LDT + 4 * (lane >> 5);
+                const float* pb = sB + buf * BN * LDT + (wave_n * WN + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < BK / 8; ++g) {
+                    f32x4 fa[MT], fb[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const f32x4*>(pa + i * 32 * LDT + 8 * g);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const f32x4*>(pb + j * 32 * LDT + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                }
+                if (s + 1 < S) store_tile(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        // single LDS stage of three bf16 planes per operand; rows padded to 80 B -> conflict-free ds_read_b128
+        char* lds = reinterpret_cast<char*>(smem);
+        char* pA0 = lds;                               // plane p of A at pA0 + p * BM * LDB
+        char* pB0 = lds + 3 * BM * LDB;                // plane p of B at pB0 + p * BN * LDB
+        auto store_tile_from = [&](const f32x4* xa, const f32x4* xb) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                uint2 q0, q1, q2;
+                split3(xa[i], q0, q1, q2);
+                char* d = pA0 + (r0 + RPI * i) * LDB + 8 * v;
+                *reinterpret_cast<uint2*>(d) = q0;
+                *reinterpret_cast<uint2*>(d + BM * LDB) = q1;
+                *reinterpret_cast<uint2*>(d + 2 * BM * LDB) = q2;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                uint2 q0, q1, q2;
+                split3(xb[i], q0, q1, q2);
+                char* d = pB0 + (r0 + RPI * i) * LDB + 8 * v;
+                *reinterpret_cast<uint2*>(d) = q0;
+                *reinterpret_cast<uint2*>(d + BN * LDB) = q1;
+                *reinterpret_cast<uint2*>(d + 2 * BN * LDB) = q2;
+            }
+        };
+        const char* ra_base = pA0 + (wave_m * WM + (lane & 31)) * LDB + 16 * (lane >> 5);
+        const char* rb_base = pB0 + (wave_n * WN + (lane & 31)) * LDB + 16 * (lane >> 5);
+        auto compute = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[MT][3], fb[NT][3];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const bf16x8*>(ra_base + pl * BM * LDB + i * 32 * LDB + 32 * ks);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fb[j][pl] = *reinterpret_cast<const bf16x8*>(rb_base + pl * BN * LDB + j * 32 * LDB + 32 * ks);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        };
+        if (S > 0) {
+            // two register sets: the global loads of tile s+2 are issued before the MFMAs of tile s, so every load has
+            // a full step (>= 1536 matrix-pipe cycles plus the partner block's step) to land before it is consumed
+            advance();
+            load_tile_into(ra, rb);
+            if (S > 1) { advance(); load_tile_into(ra2, rb2); }
+            for (int s = 0; s < S; s += 2) {
+                if (s > 0) __syncthreads();      // every wave has finished reading the previous tile
+                store_tile_from(ra, rb);
+                __syncthreads();
+                if (s + 2 < S) { advance(); load_tile_into(ra, rb); }
+                compute();
+                if (s + 1 < S) {
+                    __syncthreads();
+                    store_tile_from(ra2, rb2);
+                    __syncthreads();
+                    if (s + 3 < S) { advance(); load_tile_into(ra2, rb2); }
+                    compute();
+                }
+            }
+            __syncthreads();                     // LDS is reused for the epilogue's row table
         }
     }
 
@@ -407,32 +523,44 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-constexpr size_t gg_smem() { return (size_t)2 * (BM + BN) * LDT * sizeof(float); }
+template <int BM, int BN, int PREC>
+constexpr size_t gg_smem() {
+    return PREC == 0 ? (size_t)2 * (BM + BN) * LDT * sizeof(float) : (size_t)3 * (BM + BN) * LDB;
+}
 template <int BN, int BC>
 constexpr size_t wg_smem() { return (size_t)2 * 32 * (BN + BC) * sizeof(float); }
 
-template <int BM, int BN, int WM, int WN, bool CIN4>
+int g_big_tile = 1;
+int g_conv_precision = 1;      // 0 = fp32 MFMA, 1 = bf16x6 (default); see pylc_set_conv_precision
+
+template <int BM, int BN, int WM, int WN, bool CIN4, int PREC>
 static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
     const int tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N_store, BN);
     const long long grid = (long long)tiles_m * a.tiles_n;
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
-    const size_t lds = gg_smem<BM, BN>();
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    const size_t lds = gg_smem<BM, BN, PREC>();
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, CIN4, PREC>), dim3((unsigned)grid), dim3((BM / WM) * (BN / WN) * 64), lds, st, a);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
 
-static int dispatch_gg(GatherGemmArgs& a, bool cin4, hipStream_t st) {
+template <int PREC>
+static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     if (cin4) {
-        if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, true>(a, st);
-        if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, true>(a, st);
-        return launch_gg<128, 128, 64, 64, true>(a, st);
+        if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, true, PREC>(a, st);
+        if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, true, PREC>(a, st);
+        return launch_gg<128, 128, 64, 64, true, PREC>(a, st);
     }
-    if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false>(a, st);
-    if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false>(a, st);
-    return launch_gg<128, 128, 64, 64, false>(a, st);
+    if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false, PREC>(a, st);
+    if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false, PREC>(a, st);
+    if (PREC == 1 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192)
+        return launch_gg<256, 128, 64, 64, false, PREC>(a, st);      // 8 waves: halves LDS-write bytes per MFMA
+    return launch_gg<128, 128, 64, 64, false, PREC>(a, st);
+}
+
+static int dispatch_gg(GatherGemmArgs& a, bool cin4, hipStream_t st) {
+    return g_conv_precision == 0 ? dispatch_gg_p<0>(a, cin4, st) : dispatch_gg_p<1>(a, cin4, st);
 }
 
 template <typename K>
@@ -441,12 +569,16 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 }
 
 int conv_init() {
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 128, 64, 64, false>, gg_smem<128, 128>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 128, 64, 64, true>, gg_smem<128, 128>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 64, 64, 64, false>, gg_smem<256, 64>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 64, 64, 64, true>, gg_smem<256, 64>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 32, 32, 32, false>, gg_smem<128, 32>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<128, 32, 32, 32, true>, gg_smem<128, 32>()));
+#define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 0>, gg_smem<BM, BN, 0>()));                  \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 1>, gg_smem<BM, BN, 1>()));                 \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 1>, gg_smem<BM, BN, 1>()));
+    PYLC_OPT_GG(128, 128, 64, 64)
+    PYLC_OPT_GG(256, 64, 64, 64)
+    PYLC_OPT_GG(128, 32, 32, 32)
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
+#undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
@@ -476,6 +608,17 @@ static inline int roundup4(int v) { return (v + 3) & ~3; }
 }  // namespace pylc
 
 using namespace pylc;
+
+extern "C" int pylc_set_conv_precision(int mode) {
+    PYLC_REQUIRE(mode == 0 || mode == 1, "conv precision mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+    g_conv_precision = mode;
+    return PYLC_OK;
+}
+
+extern "C" int pylc_get_conv_precision(void) { return g_conv_precision; }
+
+// tuning knob (tools/conv_bench.py): allow / forbid the 256x128 8-wave tile
+extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
 
 extern "C" int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
     if (int rc = check_desc(d)) return rc;

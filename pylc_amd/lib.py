@@ -39,6 +39,8 @@ SIGNATURES = {
     'pylc_last_error': (C.c_char_p, []),
     'pylc_abi_version': (_I, []),
     'pylc_init': (_I, []),
+    'pylc_set_conv_precision': (_I, [_I]),
+    'pylc_get_conv_precision': (_I, []),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     'pylc_conv2d_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     'pylc_conv2d_wgrad_workspace': (_SZ, [C.POINTER(ConvDesc)]),

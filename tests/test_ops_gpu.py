@@ -44,8 +44,41 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 0], ids=['bf16x6', 'f32mfma'])
+def conv_mode(request):
+    from pylc_amd.lib import lib, check
+    prev = lib.pylc_get_conv_precision()
+    check(lib.pylc_set_conv_precision(request.param))
+    yield request.param
+    check(lib.pylc_set_conv_precision(prev))
+
+
+def test_conv_precision_modes(dev):
+    """The bf16x6 split must be as accurate as the exact-fp32 matrix pipe: both are compared with an fp64 CPU
+    convolution on the same data, with errors measured relative to sum|a*b| (the natural fp32 error scale)."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib, check
+    b, cin, cout, hw = 2, 256, 256, 24
+    x = rnd(101, b, cin, hw, hw)
+    x[0, :, :4, :4] *= 1e4          # wide dynamic range inside one dot product
+    x[1, :, 5:9, 5:9] *= 1e-4
+    wt = rnd(102, cout, cin, 3, 3, scale=0.05)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    scale = F.conv2d(x.double().abs(), wt.double().abs(), None, 1, 1)
+    errs = {}
+    for mode in (0, 1):
+        check(lib.pylc_set_conv_precision(mode))
+        y = ops.conv2d(to_dev_nhwc(x, dev), to_dev_nhwc(wt, dev), None, 1, 1, 1).double().cpu()
+        e = ((y - ref).abs() / scale)
+        errs[mode] = (e.mean().item(), e.max().item())
+    check(lib.pylc_set_conv_precision(1))
+    print('conv error / sum|ab|: f32-mfma mean %.3g max %.3g | bf16x6 mean %.3g max %.3g' % (errs[0] + errs[1]))
+    assert errs[0][1] < 1e-6 and errs[1][1] < 1e-6              # a few fp32 ulps of sum|ab|
+    assert errs[1][0] < 1.5 * errs[0][0] + 1e-9                 # bf16x6 is no worse than the fp32 chain on average
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fwd_bwd(dev, case):
+def test_conv_fwd_bwd(dev, case, conv_mode):
     from pylc_amd import ops
     cin, cout, k, stride, pad, dil, b, h, w, bias = case
     x = rnd(1, b, cin, h, w)
@@ -77,7 +110,7 @@ def test_conv_fwd_bwd(dev, case):
 
 
 @pytest.mark.parametrize('k,stride,pad,hw', [(7, 2, 3, 40), (3, 1, 0, 30), (3, 2, 1, 33)])
-def test_conv_thin_input(dev, k, stride, pad, hw):
+def test_conv_thin_input(dev, k, stride, pad, hw, conv_mode):
     """3-channel image convs (ResNet stem 7x7/2, U-Net first 3x3, Xception stem 3x3/2) through the 4-channel pack."""
     from pylc_amd import ops
     b, cout = 2, 64
