@@ -492,6 +492,173 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// wgrad on the bf16x6 arithmetic (see gather_gemm_kernel PREC 1).  Both operands are pixel-major in memory while the
+// MFMA wants 8 consecutive reduction indices (pixels) per lane, so the bf16 planes are stored pixel-major in LDS
+// exactly as they are loaded ([32 pixels][channels], rows padded so that 4 consecutive rows fall in different
+// bank quarters) and the fragments are fetched with the hardware transpose read ds_read_b64_tr_b16: per 16-lane
+// group, lane 4q+p addresses row q / columns 4p..4p+3 and lane i receives column i of the 4 rows.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__host__ __device__ constexpr int wg_rowb(int w) { return w * 2 + (w == 32 ? 0 : 64); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * rowb));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BN, int BC, int WN, int WC, bool CIN4>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a) {
+    constexpr int WAVES_C = BC / WC;
+    constexpr int NT = WN / 32, CT = WC / 32;
+    constexpr int VA = BN / 4, RA = 256 / VA, IA = 32 / RA;
+    constexpr int VB = BC / 4, RB = 256 / VB, IB = 32 / RB;
+    constexpr int ROWA = wg_rowb(BN), ROWB = wg_rowb(BC);
+    constexpr int PLA = 32 * ROWA, PLB = 32 * ROWB;          // bytes per plane
+    static_assert((BN / WN) * (BC / WC) == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sA = reinterpret_cast<char*>(smem);               // 3 planes of dy
+    char* sB = sA + 3 * PLA;                                 // 3 planes of gathered x
+
+    const int T = a.TR * a.TS;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = id % a.tiles_c; id /= a.tiles_c;
+    const int tn = id % a.tiles_n; id /= a.tiles_n;
+    int tap = 0;
+    if (!CIN4) { tap = id % T; id /= T; }
+    const int split = id;
+    const int n0 = tn * BN, c0 = tc * BC;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const int S = (m_end - m_begin + 31) / 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int va = tid % VA, pra = tid / VA;
+    const int vb = tid % VB, prb = tid / VB;
+
+    int dh = 0, dw = 0;
+    if (!CIN4) {
+        dh = a.dh0 + (tap / a.TS) * a.dh_step;
+        dw = a.dw0 + (tap % a.TS) * a.dw_step;
+    } else {
+        const int t = c0 / 4 + vb;
+        dh = a.dh0 + (t / a.TS) * a.dh_step;
+        dw = a.dw0 + (t % a.TS) * a.dw_step;
+    }
+    const bool b_col_ok = CIN4 ? (c0 / 4 + vb < T) : (c0 + 4 * vb < a.Cin);
+    const bool a_col_ok = n0 + 4 * va < a.N_ld;
+
+    f32x16 acc[NT][CT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[IA], rb[IB];
+    auto load_tile = [&](int s) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const int mb = m_begin + s * 32;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int m = mb + pra + RA * i;
+            const bool ok = a_col_ok && m < m_end;
+            ra[i] = ok ? *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.dy_pitch + n0 + 4 * va) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int m = mb + prb + RB * i;
+            bool ok = b_col_ok && m < m_end;
+            const int mm = ok ? m : 0;
+            const int q = mm % a.Q, t = mm / a.Q;
+            const int p = t % a.P, b = t / a.P;
+            const int hi = p * a.in_sh + dh, wi = q * a.in_sw + dw;
+            ok = ok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+            const size_t off = (size_t)((b * a.IH + hi) * a.IW + wi) * a.x_pitch + (CIN4 ? 0 : c0 + 4 * vb);
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + off) : zero;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            uint2 q0, q1, q2;
+            split3(ra[i], q0, q1, q2);
+            char* d = sA + (pra + RA * i) * ROWA + 8 * va;
+            *reinterpret_cast<uint2*>(d) = q0;
+            *reinterpret_cast<uint2*>(d + PLA) = q1;
+            *reinterpret_cast<uint2*>(d + 2 * PLA) = q2;
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            uint2 q0, q1, q2;
+            split3(rb[i], q0, q1, q2);
+            char* d = sB + (prb + RB * i) * ROWB + 8 * vb;
+            *reinterpret_cast<uint2*>(d) = q0;
+            *reinterpret_cast<uint2*>(d + PLB) = q1;
+            *reinterpret_cast<uint2*>(d + 2 * PLB) = q2;
+        }
+    };
+    // transpose-read addressing: group g = lane>>4 covers channels 16*(g&1).., reduction half h = g>>1
+    const int g = lane >> 4, h = g >> 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const char* fa_base = sA + (8 * h + q4) * ROWA + 2 * (wave_n * WN + 16 * (g & 1) + 4 * p4);
+    const char* fb_base = sB + (8 * h + q4) * ROWB + 2 * (wave_c * WC + 16 * (g & 1) + 4 * p4);
+
+    if (S > 0) {
+        load_tile(0);
+        for (int s = 0; s < S; ++s) {
+            if (s > 0) __syncthreads();
+            store_tile();
+            __syncthreads();
+            if (s + 1 < S) load_tile(s + 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[NT][3], fb[CT][3];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    float* out = a.out + (size_t)split * a.slab_stride;
+    const int col_limit = CIN4 ? T * 4 : a.Cin;
+    const int col_base = CIN4 ? 0 : tap * a.Cin;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int c = c0 + wave_c * WC + j * 32 + (lane & 31);
+        if (c >= col_limit) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wave_n * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // dw[i] = sum_s slab[s][i] in a fixed order (deterministic).
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n4,
                                      int splits, long long slab_stride) {
@@ -529,6 +696,8 @@ constexpr size_t gg_smem() {
 }
 template <int BN, int BC>
 constexpr size_t wg_smem() { return (size_t)2 * 32 * (BN + BC) * sizeof(float); }
+template <int BN, int BC>
+constexpr size_t wg16_smem() { return (size_t)3 * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
 
 int g_big_tile = 1;
 int g_conv_precision = 1;      // 0 = fp32 MFMA, 1 = bf16x6 (default); see pylc_set_conv_precision
@@ -583,6 +752,10 @@ int conv_init() {
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, true>, wg_smem<64, 64>()));
+    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<128, 128, 64, 64, false>, wg16_smem<128, 128>()));
+    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<64, 64, 32, 32, false>, wg16_smem<64, 64>()));
+    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<32, 128, 32, 32, false>, wg16_smem<32, 128>()));
+    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<64, 64, 32, 32, true>, wg16_smem<64, 64>()));
     return PYLC_OK;
 }
 
@@ -737,6 +910,12 @@ extern "C" size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d) {
 template <int BN, int BC, int WN, int WC, bool CIN4>
 static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
+    if (g_conv_precision == 1) {
+        const size_t lds16 = wg16_smem<BN, BC>();
+        hipLaunchKernelGGL((wgrad_bf16x6_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     const size_t lds = wg_smem<BN, BC>();
     hipLaunchKernelGGL((wgrad_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
     PYLC_LAUNCH_CHECK();
