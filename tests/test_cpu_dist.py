@@ -1,0 +1,97 @@
+"""CPU suite (-m "not gpu"): the N>1 path on 2 gloo processes -- bucketed gradient SUM all-reduce over the flat
+arena, parameter broadcast, and the "N ranks == one process at the global batch" algebra of the SyncBN / loss-head
+exchanges (the wire formats all-reduced by pylc_amd/ops.py), checked against the CPU oracle on the global batch."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import torch.nn.functional as F
+from pylc_amd import parallel, UNet
+from pylc_amd.optim import FlatArena
+from pylc_amd.runtime import runtime
+import oracle
+
+rank, world = parallel.init_from_env('gloo')
+assert world == 2 and runtime.sync_group is not None
+
+# --- 1. gradient all-reduce (SUM) over the flat arena in buckets, parameter broadcast -------------------------------
+torch.manual_seed(rank)                      # deliberately different replicas
+net = UNet(in_channels=3, n_classes=9, dropout=0.5)
+arena = FlatArena(net)
+parallel.broadcast_parameters(arena)
+chk = arena.p.double().sum().reshape(1).clone()
+both = [torch.zeros_like(chk) for _ in range(2)]
+dist.all_gather(both, chk)
+assert both[0].item() == both[1].item(), 'replicas differ after broadcast'
+arena.g.copy_(torch.arange(arena.numel, dtype=torch.float32) %% 1000 * (rank + 1))
+old = parallel.BUCKET_FLOATS
+parallel.BUCKET_FLOATS = 1 << 20             # force several buckets
+try:
+    works = parallel.bucket_ranges(arena.numel, parallel.BUCKET_FLOATS)
+    assert len(works) > 5
+    import pylc_amd.parallel as P
+    orig = P.bucket_ranges
+    P.bucket_ranges = lambda n, bucket=parallel.BUCKET_FLOATS: orig(n, bucket)
+    parallel.allreduce_gradients(arena, runtime.sync_group)
+finally:
+    parallel.BUCKET_FLOATS = old
+want = torch.arange(arena.numel, dtype=torch.float32) %% 1000 * 3
+assert torch.equal(arena.g, want)
+for p in net.parameters():                   # the per-parameter .grad views see the reduced values
+    assert p.grad.data_ptr() == p._pylc_grad.data_ptr()
+
+# --- 2. SyncBN algebra: all-reduced [sum, sumsq, n] -> global-batch statistics ----------------------------------------
+rs = np.random.RandomState(5)
+xg = torch.from_numpy(rs.standard_normal((8, 16, 6, 6)).astype(np.float32) * 2 + 0.3)     # global batch
+xl = xg[rank * 4:(rank + 1) * 4]
+c = 16
+sums = torch.cat([xl.sum((0, 2, 3)), (xl * xl).sum((0, 2, 3)), torch.tensor([float(xl.numel() // c)])])
+dist.all_reduce(sums)
+n = sums[2 * c].item()
+mean = sums[:c] / n
+var = sums[c:2 * c] / n - mean * mean
+rm, rv = torch.zeros(c), torch.ones(c)
+ref = F.batch_norm(xg, rm, rv, None, None, True, 0.1, 1e-5)
+mine = (xl - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5)
+assert (mine - ref[rank * 4:(rank + 1) * 4]).abs().max().item() < 1e-5
+assert (rv - (0.9 + 0.1 * var * n / (n - 1))).abs().max().item() < 1e-5
+
+# --- 3. loss-head algebra: all-reduced 3+3C partials -> the global-batch MultiLoss of the oracle ---------------------
+C = 9
+z = torch.from_numpy(rs.standard_normal((4, C, 10, 10)).astype(np.float32) * 2)
+t = torch.from_numpy(rs.randint(0, C, (4, 10, 10)).astype(np.int64))
+zl, tl = z[rank * 2:(rank + 1) * 2], t[rank * 2:(rank + 1) * 2]
+p = F.softmax(zl, 1)
+oh = F.one_hot(tl, C).permute(0, 3, 1, 2).float()
+pt = (p * oh).sum(1)
+stats = torch.cat([(-torch.log_softmax(zl, 1) * oh).sum().reshape(1), torch.tensor([float(tl.numel())]),
+                   (-0.25 * (1 - (pt + 1e-8)) ** 2 * torch.log(pt + 1e-8)).sum().reshape(1),
+                   (p * oh).sum((0, 2, 3)), p.sum((0, 2, 3)), oh.sum((0, 2, 3))])
+dist.all_reduce(stats)
+ng = float(t.numel())
+ce = stats[0] / stats[1]
+fl = stats[2] / ng
+dice = (1 - (2 * stats[3:3 + C] + 1) / (stats[3 + C:3 + 2 * C] + stats[3 + 2 * C:] + 1)).mean()
+tot, oce, odice, ofl = oracle.multiloss(z, t)
+assert abs(ce - oce) < 1e-5 and abs(dice - odice) < 1e-5 and abs(fl - ofl) < 1e-5
+parallel.barrier()
+if rank == 0:
+    print('DIST_OK')
+'''
+
+
+def test_two_rank_gloo():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    script = WORKER % {'root': ROOT}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29531', '--no-python', sys.executable, '-c', script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'DIST_OK' in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

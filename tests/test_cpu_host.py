@@ -1,0 +1,138 @@
+"""CPU suite (-m "not gpu"): the C-ABI library loads and exports every declared symbol; host-side logic of the
+package (module trees / state_dict names, flat parameter arena, layout helpers, argument validation); and the
+"fail loudly" rule -- no op silently falls back to a CPU path."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_library_exports_every_header_symbol():
+    import ctypes
+    from pylc_amd import lib as L
+    hdr = open(os.path.join(ROOT, 'include', 'pylc_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(pylc_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 40
+    dll = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), 'libpylc_hip.so does not export %s' % name
+        assert name in L.SIGNATURES, 'pylc_amd/lib.py has no binding for %s' % name
+    assert set(L.SIGNATURES) <= set(declared)
+    assert dll.pylc_abi_version() == L.ABI_VERSION
+
+
+def test_error_reporting_without_gpu():
+    """Argument validation happens on the host before any launch: callable (and failing cleanly) without a GPU."""
+    import ctypes as C
+    from pylc_amd.lib import lib, ConvDesc
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S, d.stride, d.pad, d.dil = 1, 8, 8, 3, 8, 3, 3, 1, 1, 1
+    d.OH, d.OW, d.x_pitch, d.y_pitch = 8, 8, 3, 8
+    rc = lib.pylc_conv2d_fwd(C.byref(d), 16, 16, None, 16, None)
+    assert rc != 0 and b'multiple of 4' in lib.pylc_last_error()
+    d.Cin, d.x_pitch, d.OH = 4, 4, 7
+    rc = lib.pylc_conv2d_fwd(C.byref(d), 16, 16, None, 16, None)
+    assert rc != 0 and b'inconsistent' in lib.pylc_last_error()
+    assert lib.pylc_set_conv_precision(7) != 0
+    assert lib.pylc_conv2d_wgrad_workspace(C.byref(d)) == 0          # invalid descriptor -> 0, never a crash
+
+
+def test_ops_refuse_cpu_tensors():
+    from pylc_amd import ops
+    from pylc_amd.lib import PylcError
+    x = torch.zeros(1, 4, 8, 8).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(8, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    with pytest.raises((PylcError, RuntimeError)):
+        ops.conv2d(x, w, None, 1, 1, 1)
+
+
+@pytest.mark.parametrize('tag,kw', [('deeplab_resnet', dict(backbone='resnet', n_classes=9)),
+                                    ('deeplab_xception', dict(backbone='xception', n_classes=11)),
+                                    ('unet', dict(in_channels=3, n_classes=9, dropout=0.5))])
+def test_module_state_dict_names_match_reference(tag, kw):
+    import pylc_amd
+    keys = json.load(open(os.path.join(HERE, tag + '.json')))['keys']
+    net = pylc_amd.UNet(**kw) if tag == 'unet' else pylc_amd.DeepLab(**kw)
+    assert [(k, list(v.shape)) for k, v in net.state_dict().items()] == [(k, list(s)) for k, s in keys]
+    for name, p in net.named_parameters():
+        if p.dim() == 4 and p.shape[1] > 1:
+            assert p.permute(0, 2, 3, 1).is_contiguous(), '%s is not KRSC in memory' % name
+
+
+def test_reference_constructor_signatures():
+    """models/model.py:140-147 and :166-173 call the nets with these keywords."""
+    import pylc_amd
+    pylc_amd.UNet(in_channels=3, n_classes=9, up_mode='upsample', activ_func=torch.nn.ReLU(), normalizer=torch.nn.BatchNorm2d,
+                  dropout=0.5)
+    pylc_amd.DeepLab(activ_func=torch.nn.ReLU(), normalizer=torch.nn.BatchNorm2d, backbone='resnet', n_classes=9, in_channels=3,
+                     pretrained=False)
+    with pytest.raises(ValueError):
+        pylc_amd.DeepLab(backbone='drn')
+
+
+def test_flat_arena_rehomes_parameters():
+    import pylc_amd
+    from pylc_amd.optim import FlatArena
+    net = pylc_amd.UNet(in_channels=3, n_classes=9, dropout=0.5)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    strides = {k: p.stride() for k, p in net.named_parameters()}
+    arena = FlatArena(net)
+    assert arena.numel % 4 == 0 and arena.numel >= sum(p.numel() for p in net.parameters())
+    for k, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[k]) and p.stride() == strides[k]
+        assert p.data_ptr() >= arena.p.data_ptr() and p.data_ptr() < arena.p.data_ptr() + 4 * arena.numel
+        assert p.grad is p._pylc_grad and p.grad.shape == p.shape and p.grad.stride() == p.stride()
+        assert (p.data_ptr() - arena.p.data_ptr()) % 16 == 0
+    # loading a state dict writes straight into the arena
+    net.load_state_dict({k: torch.full_like(v, 3) if v.is_floating_point() else v for k, v in before.items()})
+    n_param = sum(p.numel() for p in net.parameters())
+    assert float(arena.p.double().sum()) == 3.0 * n_param
+
+
+def test_layout_helpers():
+    from pylc_amd import ops
+    from pylc_amd.lib import PylcError
+    t = ops.empty_nhwc(2, 9, 5, 7, 'cpu', pitch=12)
+    assert tuple(t.shape) == (2, 9, 5, 7) and ops.pitch_of(t) == 12
+    assert ops.pitch_of(ops.empty_nhwc(3, 16, 1, 1, 'cpu')) == 16
+    with pytest.raises(PylcError):
+        ops.pitch_of(torch.zeros(2, 8, 4, 4))              # NCHW memory
+    assert ops.pitch_of(ops.as_nhwc(torch.zeros(2, 8, 4, 4))) == 8
+    assert ops.conv_out_size(512, 7, 2, 3, 1) == 256 and ops.conv_out_size(32, 3, 1, 18, 18) == 32
+
+
+def test_meta_update_only_existing_keys():
+    from pylc_amd.model import Meta
+    m = Meta(arch='unet')
+    m.update({'lr': 0.5, 'optim': 'sgd', 'not_a_field': 1})      # config.py:259-269: unknown keys are dropped
+    assert m.lr == 0.5 and m.optim_type == 'adam' and not hasattr(m, 'not_a_field')
+    with pytest.raises(AttributeError):
+        Meta(bogus=1)
+
+
+def test_multiloss_validation_matches_reference_contract():
+    from pylc_amd.loss import MultiLoss
+    crit = MultiLoss({'weighted': False, 'weights': None, 'ce': 0.5, 'dice': 0.5, 'focal': 0.5},
+                     {'n_classes': 9, 'class_codes': None, 'class_labels': None})
+    with pytest.raises(TypeError):
+        crit(np.zeros((1, 9, 4, 4)), torch.zeros(1, 4, 4, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        crit(torch.zeros(1, 9, 4, 4), torch.zeros(2, 4, 4, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        crit(torch.zeros(1, 5, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        MultiLoss({'weighted': True, 'weights': [1, 2], 'ce': 1, 'dice': 0, 'focal': 0}, {'n_classes': 9})
+
+
+def test_bucket_ranges_cover_arena():
+    from pylc_amd.parallel import bucket_ranges
+    r = bucket_ranges(100, 32)
+    assert r == [(0, 32), (32, 64), (64, 96), (96, 100)]
+    assert bucket_ranges(59341228)[-1][1] == 59341228
