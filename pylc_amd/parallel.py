@@ -25,10 +25,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world == 1:
+    if world == 1 and not os.environ.get('PYLC_FORCE_PG'):
         if torch.cuda.is_available():
             torch.cuda.set_device(0)
         return 0, 1
+    # PYLC_FORCE_PG=1: create the process group even for one rank so that the SyncBN / loss / gradient all-reduce code
+    # paths run (and can be tested) on a single-GPU box
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:

@@ -139,3 +139,40 @@ def test_oracle_parity_deeplab_train_mode_logits(dev):
     for k in ('backbone.bn1.running_var', 'backbone.layer3.22.bn3.running_mean', 'aspp.global_avg_pool.2.running_var',
               'decoder.last_conv.5.running_var'):
         assert (new[k].cpu() - sd[k]).abs().max().item() < 1e-4 * max(1.0, sd[k].abs().max().item()), k
+
+
+def test_distributed_code_path_single_rank(dev):
+    """The data-parallel code path (RCCL process group, SyncBN / loss-statistics all-reduce, bucketed gradient
+    all-reduce) with world_size 1 must reproduce the plain single-GPU step exactly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import torch, pylc_amd
+from pylc_amd import parallel, runtime
+from pylc_amd.model import Model, Meta
+from tests import _data as D
+import oracle
+rank, world = parallel.init_from_env()
+runtime.dropout_enabled = False
+x = D.tiles(1, 2, 3, 64, 64); y = D.blob_masks(2, 2, 64, 64, 9, cell=8)
+w = oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=5)
+m = Model(Meta(), torch.device('cuda:0')).build()
+m.net.load_state_dict(w)
+if runtime.sync_group is not None:
+    parallel.broadcast_parameters(m.arena)
+for _ in range(2):
+    m.train(x, y)
+print('RESULT', runtime.sync_group is not None, float(m.crit.ce), float(m.crit.dsc), float(m.crit.fl), float(m.optim.norm[0]))
+''' % root
+    res = {}
+    for force in ('', '1'):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYLC_FORCE_PG=force)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
+        assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-2000:]
+        f = line[0].split()
+        res[force] = (f[1], [float(v) for v in f[2:]])
+    assert res[''][0] == 'False' and res['1'][0] == 'True'
+    assert res[''][1] == res['1'][1], res
