@@ -1,0 +1,32 @@
+"""Run ONE conv shape a few times (for rocprofv3 --pmc passes on the GPU box).
+usage: conv_one.py <fwd|dgrad|wgrad> cin cout k stride pad dil B H [reps]"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pylc_amd import ops, lib as L
+from pylc_amd.lib import lib, check, ptr, stream
+kind = sys.argv[1]
+cin, cout, k, stride, pad, dil, b, h = [int(v) for v in sys.argv[2:10]]
+reps = int(sys.argv[10]) if len(sys.argv) > 10 else 3
+L.init()
+check(lib.pylc_set_conv_precision(int(os.environ.get('PYLC_MODE', '1'))))
+dev = torch.device('cuda:0')
+x = torch.randn(b, h, h, cin, device=dev).permute(0, 3, 1, 2)
+w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).permute(0, 3, 1, 2)
+d = ops._conv_desc(x, cin, cout, k, k, stride, pad, dil, cin, (cout + 3) & ~3)
+y = ops.empty_nhwc(b, cout, d.OH, d.OW, dev)
+dy = torch.randn(b, d.OH, d.OW, cout, device=dev).permute(0, 3, 1, 2)
+wt = torch.empty((cin, k * k, (cout + 3) & ~3), device=dev)
+check(lib.pylc_weight_transpose(ptr(w), ptr(wt), cout, k * k, cin, stream()))
+dx = ops.empty_nhwc(b, cin, h, h, dev)
+dw = torch.empty((cout, k, k, cin), device=dev)
+nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
+ws = torch.empty(max(nbytes, 4) // 4 + 1, device=dev)
+for _ in range(reps):
+    if kind == 'fwd':
+        check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
+    elif kind == 'dgrad':
+        check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, stream()))
+    else:
+        check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, stream()))
+torch.cuda.synchronize()
