@@ -38,6 +38,21 @@ def synth(rank, b, ch, hw, n_cls, dev):
     return x, y
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact).
+    PMC collection needs the profiler, so it cannot be measured live here; None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    want = ''.join(kernel.split())
+    for name, v in json.load(open(files[-1])).items():
+        if want in ''.join(name.split()):
+            return v['hbm_bytes_per_launch']
+    return None
+
+
 def cpu_baseline(hw, n_cls, budget_s=25.0):
     """Reference CPU path (oracle) on this box's host cores: bs=2 steps of the same train step, bounded in time."""
     import oracle
@@ -127,6 +142,7 @@ def main():
     }
     if timer is not None:
         out['roofline'] = timer.roofline(PEAK_BF16_MFMA_TFLOPS)
+        out['roofline']['traffic'] = pmc_traffic(out['roofline']['kernel'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.tile, args.classes)
     print(json.dumps(out))

@@ -86,10 +86,12 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []          # (start_event, end_event, flops, launches, kind)
+        self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
 
-    def bracket(self, flops, launches, kind):
+    def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.append((a, b, flops, launches, kind))
+        self.alg_bytes += nbytes
         return a, b
 
     def roofline(self, peak_bf16_tflops=2500.0):
@@ -105,7 +107,7 @@ class KernelTimer:
         peak = peak_bf16_tflops / 6.0
         return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                 'kernel': self.KERNEL, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1),
-                'kernel_time_ms_total': tot_ms,
+                'kernel_time_ms_total': tot_ms, 'algorithmic_bytes_per_launch': self.alg_bytes / max(launches, 1),
                 'note': 'achieved = algorithmic fp32 FLOP/s; arithmetic = 6-term bf16 split (fp32-grade accuracy) on '
                         'v_mfma_f32_32x32x16_bf16, so peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6; executed MFMA '
                         'rate = 6 x achieved; the exact-fp32 matrix pipe peaks at 157.3 TFLOP/s',
@@ -185,7 +187,8 @@ class Conv2dFn(torch.autograd.Function):
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
         ev = None
         if _timer is not None and _is_dominant_tile(b * oh * ow, yp, cin, r * s):
-            ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s))
+            ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
+                                4.0 * (b * h * wd * cin + cout * r * s * cin + b * oh * ow * cout))
             ev[0].record()
         check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
         if ev is not None:
@@ -220,7 +223,8 @@ class Conv2dFn(torch.autograd.Function):
             ev = None
             n_launch = 1 if stride == 1 else min(r, 2) * min(s, 2)     # one launch per non-empty output parity class
             if _timer is not None and _is_dominant_tile(x.shape[0] * x.shape[2] * x.shape[3] // n_launch, cin, kp, 2):
-                ev = _timer.bracket(2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * r * s * cin, n_launch, 'dgrad%dx%d' % (r, s))
+                ev = _timer.bracket(2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * r * s * cin, n_launch, 'dgrad%dx%d' % (r, s),
+                                    4.0 * (dy.numel() + cout * r * s * cin + x.numel()))
                 ev[0].record()
             check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, st))
             if ev is not None:

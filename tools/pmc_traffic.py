@@ -1,0 +1,23 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+gfx950 corrections (MI355X_MICROARCH.md section HBM): FETCH_SIZE (KB) under-reports wide coalesced streaming reads by
+exactly 2x -> doubled; WRITE_SIZE (KB) is exact for 16-B-per-lane stores."""
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: {'fetch_kb': 0.0, 'write_kb': 0.0, 'n_fetch': 0, 'n_write': 0})
+for kind, key in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+    for f in glob.glob('%s/%s/*/*counter_collection.csv' % (out, kind)):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != key:
+                continue
+            k = r['Kernel_Name']
+            acc[k][kind + '_kb'] += float(r['Counter_Value'])
+            acc[k]['n_' + kind] += 1
+res = {}
+for k, v in acc.items():
+    n = max(v['n_fetch'], v['n_write'], 1)
+    res[k[:120]] = {'launches': n,
+                    'fetch_bytes_per_launch': 2.0 * 1024 * v['fetch_kb'] / max(v['n_fetch'], 1),
+                    'write_bytes_per_launch': 1024 * v['write_kb'] / max(v['n_write'], 1)}
+    res[k[:120]]['hbm_bytes_per_launch'] = res[k[:120]]['fetch_bytes_per_launch'] + res[k[:120]]['write_bytes_per_launch']
+top = dict(sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12])
+print(json.dumps(top, indent=1))
