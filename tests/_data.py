@@ -37,3 +37,16 @@ def digest(t):
     """(sum, abs-sum, l2) of a tensor in float64 -- the per-tensor checksum stored in fixtures."""
     d = t.detach().double()
     return [float(d.sum()), float(d.abs().sum()), float(d.pow(2).sum().sqrt())]
+
+
+def learnable_tiles(seed, b, hw, n_classes, cell=8, noise=12.0):
+    """Synthetic tiles whose masks are LEARNABLE from the pixels: every cell x cell blob has a
+    class, and the blob's colour is that class's palette colour plus Gaussian noise (uint8-valued float32)."""
+    rs = np.random.RandomState(seed)
+    palette = np.random.RandomState(99).randint(30, 226, (n_classes, 3)).astype(np.float32)
+    g = (hw + cell - 1) // cell
+    cls = rs.randint(0, n_classes, (b, g, g))
+    mask = np.repeat(np.repeat(cls, cell, 1), cell, 2)[:, :hw, :hw]
+    img = palette[mask].transpose(0, 3, 1, 2) + noise * rs.standard_normal((b, 3, hw, hw)).astype(np.float32)
+    img = np.clip(np.rint(img), 0, 255).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(img)), torch.from_numpy(np.ascontiguousarray(mask).astype(np.int64))
