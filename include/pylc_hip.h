@@ -121,8 +121,9 @@ int pylc_bn_eval_coeffs(const float* running_mean, const float* running_var, con
 int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift,
                   const float* residual, int res_pitch, float* out, int out_pitch,
                   long long M, int C, int relu, void* stream);
-/* Backward, training mode.  g = dout * (out > 0 if relu).  sums[0:C] = sum g (= dbeta),
- * sums[C:2C] = sum g * xhat (= dgamma), xhat = (y - mean) * invstd. */
+/* Backward, training mode.  g = dout * (out > 0 if relu).  sums[0:C] = sum g * xhat (= dgamma),
+ * sums[C:2C] = sum g (= dbeta), xhat = (y - mean) * invstd  -- parameter order, so `sums` may point straight at the
+ * adjacent (gamma, beta) gradient slots of a flat arena. */
 int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch,
                        const float* y, int y_pitch, const float* mean, const float* invstd,
                        long long M, int C, int relu, float* sums /*[2C]*/, float* workspace, void* stream);

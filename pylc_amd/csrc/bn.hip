@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         if (ty == 0 && cv < g.CV) {
             for (int k = 1; k < g.RL; ++k) { s0 += red[0][k * g.cols + tx]; s1 += red[1][k * g.cols + tx]; }
             float* p = partial + (size_t)blockIdx.x * 2 * C;
-            st4(p + 4 * cv, s0);
-            st4(p + C + 4 * cv, s1);
+            // MODE 0: [sum | sumsq].  MODE 1: [sum g*xhat (dgamma) | sum g (dbeta)] -- the parameter order, so the
+            // result can land directly in the adjacent (gamma, beta) slots of the flat gradient arena
+            st4(p + 4 * cv, MODE == 0 ? s0 : s1);
+            st4(p + C + 4 * cv, MODE == 0 ? s1 : s0);
         }
         __syncthreads();
     }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int cv = tx; cv < g.CV; cv += g.cols) {
         const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
         const f32x4 k = ld4(gamma + 4 * cv) * is;
-        const f32x4 sg = ld4(sums + 4 * cv) * inv_n, sgx = ld4(sums + C + 4 * cv) * inv_n;
+        const f32x4 sgx = ld4(sums + 4 * cv) * inv_n, sg = ld4(sums + C + 4 * cv) * inv_n;
         for (long long r = r_begin + ty; r < r_end; r += g.RL) {
             f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
             if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
@@ -214,7 +216,7 @@ extern "C" int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, fl
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nslab), dim3(256), 0, st, y, y_pitch, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, g, C,
                        workspace);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -263,7 +265,7 @@ extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
                        relu, g, C, workspace);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

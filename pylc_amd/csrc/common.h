@@ -52,21 +52,21 @@ __device__ inline float block_sum_256(float v, float* red) {
 }
 
 // out[c] = sum_r partial[r][c] for r < nrows, accumulated in fp64 in a fixed order (deterministic).
-// Launch with 256 threads and grid = cdiv(ncols, 16): 16 columns x 16 row lanes per block.
+// Launch with 256 threads and grid = cdiv(ncols, 8): 8 columns x 32 row lanes per block.
 __global__ __launch_bounds__(256) static void column_sum_kernel(const float* __restrict__ partial, int nrows, int ncols,
                                                                  float* __restrict__ out) {
-    __shared__ double red[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + tx;
+    __shared__ double red[32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx;
     double acc = 0.0;
     if (c < ncols)
-        for (int r = ty; r < nrows; r += 16) acc += (double)partial[(size_t)r * ncols + c];
+        for (int r = ty; r < nrows; r += 32) acc += (double)partial[(size_t)r * ncols + c];
     red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && c < ncols) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[k][tx];
+        for (int k = 0; k < 32; ++k) s += red[k][tx];
         out[c] = (float)s;
     }
 }

@@ -162,7 +162,7 @@ extern "C" int pylc_multiloss_stats(const float* logits, int pitch, const int64_
 #undef LAUNCH_STATS
     PYLC_LAUNCH_CHECK();
     const int K = 3 + 3 * C;
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(K, 16)), dim3(256), 0, st, workspace, blocks, K, stats);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(K, 8)), dim3(256), 0, st, workspace, blocks, K, stats);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

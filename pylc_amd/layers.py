@@ -63,6 +63,7 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(c))
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.zeros((), dtype=torch.long))
+        self._nbt_pending = 0       # training forwards not yet added to the buffer (flushed when the state is read)
 
     @classmethod
     def evaluate(cls, c):          # the reference's U-Net calls normalizer.evaluate(out_size) (unet.py:113,117)
@@ -70,10 +71,23 @@ class BatchNorm2d(nn.Module):
 
     def forward(self, y, residual=None, relu=False):
         if self.training:
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1          # no per-layer device add: 113 tiny launches per step otherwise
         return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, residual, relu,
                           self.training, self.eps, self.momentum, runtime.sync_group if self.training else None,
                           runtime.bn_clamp_eps)
+
+    def flush_counter(self):
+        if self._nbt_pending:
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def extra_repr(self):
         return '%d' % self.num_features

@@ -374,17 +374,21 @@ class BnActFn(torch.autograd.Function):
         dev = y.device
         st = stream()
         mean, invstd = coef[:c], coef[c:2 * c]
-        sums = torch.empty(2 * c, device=dev)
+        # [dgamma | dbeta] go straight into the flat gradient arena when gamma/beta own adjacent slots there
+        tg, tb = _grad_target(gamma), _grad_target(beta)
+        direct = (tg is not None and tb is not None and tb.data_ptr() == tg.data_ptr() + 4 * c
+                  and ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
+        sums = torch.as_strided(tg, (2 * c,), (1,)) if direct else torch.empty(2 * c, device=dev)
         ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
         op = pitch_of(out) if out is not None else 0
         check(lib.pylc_bn_bwd_reduce(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
                                      m, c, int(relu), ptr(sums), ptr(ws), st))
         local_sums = sums
         if training and group is not None:
-            local_sums = sums.clone()          # parameter grads stay local; the grad all-reduce averages them later
+            sums = local_sums.clone()          # parameter grads stay local (the gradient all-reduce sums them later)
             dist.all_reduce(sums, group=group)
         if not training:
-            sums_apply = torch.zeros_like(sums)   # running statistics are constants: dy = gamma*invstd*g
+            sums_apply = torch.zeros(2 * c, device=dev)   # running statistics are constants: dy = gamma*invstd*g
         else:
             sums_apply = sums
         dy = empty_nhwc(b, c, h, w, dev)
@@ -393,20 +397,22 @@ class BnActFn(torch.autograd.Function):
                                     ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
                                     ptr(g_out), c if g_out is not None else 0, st))
         dgamma = dbeta = None
-        if ctx.needs_input_grad[1]:
-            tgt = _grad_target(gamma)
-            if tgt is not None:
-                tgt.copy_(local_sums[c:])
-                dgamma = _deliver_grad(gamma, tgt)
-            else:
-                dgamma = local_sums[c:].clone()
-        if ctx.needs_input_grad[2]:
-            tgt = _grad_target(beta)
-            if tgt is not None:
-                tgt.copy_(local_sums[:c])
-                dbeta = _deliver_grad(beta, tgt)
-            else:
-                dbeta = local_sums[:c].clone()
+        if direct:
+            _deliver_grad(gamma, tg)
+            _deliver_grad(beta, tb)
+        else:
+            if ctx.needs_input_grad[1]:
+                if tg is not None:
+                    tg.copy_(local_sums[:c])
+                    dgamma = _deliver_grad(gamma, tg)
+                else:
+                    dgamma = local_sums[:c].clone()
+            if ctx.needs_input_grad[2]:
+                if tb is not None:
+                    tb.copy_(local_sums[c:])
+                    dbeta = _deliver_grad(beta, tb)
+                else:
+                    dbeta = local_sums[c:].clone()
         return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None
 
 
