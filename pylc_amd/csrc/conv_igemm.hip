@@ -886,13 +886,20 @@ WgradPlan plan_wgrad(const PylcConvDesc* d) {
     p.tiles_n = cdiv(d->Cout, bn);
     p.tiles_c = p.cin4 ? cdiv(T * 4, bc) : cdiv(d->Cin, bc);
     const long long tiles = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T);
-    // enough blocks for ~3 per CU, at least 16 K-steps (512 pixels) per block
-    long long want = cdiv<long long>(3 * kNumCU, tiles);
+    // A fixed number of blocks is resident at once (LDS-limited) and all blocks of a launch do equal work: size the split
+    // so that tiles * splits fills whole rounds of resident blocks (792 blocks on 512 slots run as 512 + 280 = 2 rounds
+    // at 77 %), with at least 16 K-steps (512 pixels) per block.
+    const long long slots = (p.cfg == 0 ? 2 : 4) * kNumCU;      // resident blocks: 61 KB LDS (128x128 tile) vs 37 KB
     long long max_splits = cdiv<long long>(M, 512);
-    long long s = want < 1 ? 1 : want;
-    if (s > max_splits) s = max_splits;
-    if (s > 256) s = 256;
-    if (s < 1) s = 1;
+    if (max_splits > 256) max_splits = 256;
+    if (max_splits < 1) max_splits = 1;
+    long long s = 1;
+    double best = -1.0;
+    for (long long c = 1; c <= max_splits; ++c) {
+        const long long blocks = tiles * c;
+        const double eff = (double)blocks / (double)(cdiv<long long>(blocks, slots) * slots);
+        if (eff > best + 0.04) { best = eff; s = c; }      // prefer the smallest split within 4 % of the best fill
+    }
     long long mps = cdiv<long long>(cdiv<long long>(M, s), 32) * 32;
     s = cdiv<long long>(M, mps);
     p.splits = (int)s; p.m_per_split = (int)mps;
