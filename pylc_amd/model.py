@@ -100,6 +100,7 @@ class Model:
         self.loss = LossLog()
         self.iter = 0
         self.epoch = 0
+        self._bucketer = None
 
     def update_meta(self, params):
         self.meta.update(params)
@@ -172,10 +173,16 @@ class Model:
         loss = self.crit(y_hat, y)
         self.loss.push(torch.stack((self.crit.ce, self.crit.dsc, self.crit.fl)))
         self.optim.zero_grad()
+        if runtime.sync_group is not None:
+            if self._bucketer is None:
+                from .parallel import GradBucketer
+                self._bucketer = GradBucketer(self.arena, runtime.grad_group)
+            self._bucketer.reset()
+            runtime.grad_ready = self._bucketer.ready
         loss.backward()
         if runtime.sync_group is not None:
-            from .parallel import allreduce_gradients
-            allreduce_gradients(self.arena, runtime.sync_group)
+            runtime.grad_ready = None
+            self._bucketer.finish()               # gradient SUM all-reduce, overlapped with the backward above
         self.optim.step()
         if self.iter % self.meta.report == 0:
             self.log()

@@ -12,6 +12,7 @@ import torch.distributed as dist
 
 from . import lib as L
 from .lib import lib, check, ptr, stream, ConvDesc, DwDesc
+from .runtime import runtime as _runtime
 
 
 # ----------------------------------------------------------------------------------------------
@@ -155,6 +156,8 @@ def _deliver_grad(param, g):
     if _grad_target(param) is not None:
         if param.grad is None or param.grad.data_ptr() != g.data_ptr():
             param.grad = g
+        if _runtime.grad_ready is not None:
+            _runtime.grad_ready(param)        # data-parallel: may trigger this bucket's asynchronous all-reduce
         return None
     return g
 

@@ -44,8 +44,62 @@ def init_from_env(backend=None):
     else:
         dist.init_process_group(backend)
     runtime.sync_group = dist.group.WORLD
+    runtime.grad_group = dist.new_group(backend=backend) if backend == 'nccl' else dist.group.WORLD
     runtime.manual_seed(runtime.seed, rank)
     return rank, world
+
+
+class GradBucketer:
+    """Overlaps the gradient exchange with the backward pass.
+
+    The flat gradient arena is cut into buckets of whole parameters (>= BUCKET_FLOATS each, in arena = module order).
+    Backward produces gradients in reverse module order (decoder -> ASPP -> layer4 -> ... -> stem), so buckets complete
+    from the END of the arena; the moment the last gradient of a bucket has been written (pylc_amd/ops.py calls
+    `ready(param)` right after launching the kernel that writes it) its SUM all-reduce is enqueued asynchronously on a
+    dedicated RCCL communicator -- a second process group, so the 64 MB transfers never queue in front of the
+    latency-critical SyncBN collectives.  torch's NCCL work objects order each collective after the kernels already
+    enqueued on the compute stream."""
+
+    def __init__(self, arena, group=None, bucket_floats=BUCKET_FLOATS):
+        self.arena = arena
+        self.group = group
+        self.buckets = []            # [lo, hi, n_params]
+        lo, n = 0, 0
+        for p, off in zip(arena.params, arena.offsets):
+            if n and off - lo >= bucket_floats:
+                self.buckets.append([lo, off, n])
+                lo, n = off, 0
+            p._pylc_bucket = len(self.buckets)
+            n += 1
+        self.buckets.append([lo, arena.numel, n])
+        self.pending = [b[2] for b in self.buckets]
+        self.works = []
+
+    def reset(self):
+        self.pending = [b[2] for b in self.buckets]
+        self.works = []
+
+    def ready(self, param):
+        b = getattr(param, '_pylc_bucket', None)
+        if b is None:
+            return
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        self.pending[b] = -1
+        self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch whatever did not complete on its own (parameters without a gradient this step) and wait for all."""
+        for b, n in enumerate(self.pending):
+            if n >= 0:
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 def bucket_ranges(numel, bucket=BUCKET_FLOATS):

@@ -7,6 +7,8 @@ import itertools
 class _Runtime:
     def __init__(self):
         self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
+        self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
+        self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         self.seed = 0x5EED

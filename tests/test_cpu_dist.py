@@ -48,6 +48,22 @@ assert torch.equal(arena.g, want)
 for p in net.parameters():                   # the per-parameter .grad views see the reduced values
     assert p.grad.data_ptr() == p._pylc_grad.data_ptr()
 
+# --- 1b. overlapped path: buckets fire as their last gradient becomes ready (reverse module order) -------------------
+arena.g.copy_(torch.arange(arena.numel, dtype=torch.float32) %% 777 * (rank + 2))
+gb = parallel.GradBucketer(arena, runtime.grad_group, bucket_floats=1 << 20)
+assert len(gb.buckets) > 5 and gb.buckets[0][0] == 0 and gb.buckets[-1][1] == arena.numel
+gb.reset()
+params = list(net.parameters())
+fired = []
+for p in reversed(params[3:]):               # the first three parameters never report: finish() must still reduce them
+    before = len(gb.works)
+    gb.ready(p)
+    if len(gb.works) > before:
+        fired.append(p._pylc_bucket)
+assert fired == sorted(fired, reverse=True) and len(fired) == len(gb.buckets) - 1
+gb.finish()
+assert torch.equal(arena.g, torch.arange(arena.numel, dtype=torch.float32) %% 777 * 5)
+
 # --- 2. SyncBN algebra: all-reduced [sum, sumsq, n] -> global-batch statistics ----------------------------------------
 rs = np.random.RandomState(5)
 xg = torch.from_numpy(rs.standard_normal((8, 16, 6, 6)).astype(np.float32) * 2 + 0.3)     # global batch
