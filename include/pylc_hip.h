@@ -164,6 +164,24 @@ int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream)
  * mean3 / std3 are HOST arrays of 3 floats. */
 int pylc_image_pack(const float* img_nchw, int B, int Cimg, int H, int W, const float* mean3,
                     const float* std3, float* out_nhwc4, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-window inference (test.py:50-110): tile extraction fused with normalisation, replacing
+ * Extractor.__split utils/extract.py:279-310; tile stitching + argmax replacing utils/tools.py:209-319
+ * reconstruct() (overlap quirks reproduced, see csrc/stitch.hip); palette + INTER_NEAREST resize replacing
+ * colourize utils/tools.py:322-358 and the cv2.resize at :315-317.
+ * ------------------------------------------------------------------------------------------- */
+/* img: [Cimg][H][W] raw 0..255 (fitted: H, W multiples of stride); writes tiles first_tile .. first_tile+n_tiles-1
+ * (row-major tile order) as normalised [n][tile][tile][4]. mean3/std3 are HOST arrays. */
+int pylc_image_pack_tiles(const float* img, int Cimg, int H, int W, int tile, int stride, int first_tile, int n_tiles,
+                          const float* mean3, const float* std3, float* out, void* stream);
+/* logits: [rows*cols][tile][tile][pitch] (NHWC tiles in row-major order), stride = tile or tile/2.
+ * mask: uint8 [rows*stride + (tile-stride)][cols*stride + (tile-stride)]. */
+int pylc_stitch_argmax(const float* logits, int pitch, int rows, int cols, int tile, int stride, int C,
+                       unsigned char* mask, void* stream);
+/* out_rgb[oy][ox][3] = palette[mask[floor(oy*h/oh)][floor(ox*w/ow)]]; palette_rgb: device uint8 [n_classes][3]. */
+int pylc_colourize_resize(const unsigned char* mask, int h, int w, const unsigned char* palette_rgb,
+                          unsigned char* out_rgb, int oh, int ow, void* stream);
+
 /* Layout converters for module-boundary tensors (logits): [B][H][W][pitch] <-> [B][C][H][W]. */
 int pylc_nhwc_to_nchw(const float* x, int x_pitch, float* y, int B, int H, int W, int C, void* stream);
 int pylc_nchw_to_nhwc(const float* x, float* y, int y_pitch, int B, int H, int W, int C, void* stream);

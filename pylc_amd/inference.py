@@ -1,0 +1,80 @@
+"""Sliding-window inference over a full-resolution (already fitted) image, entirely on the GPU.
+
+Counterpart of the reference's test path, test.py:50-110: Extractor(...).extract(fit=True, stride=tile//2)
+(utils/extract.py:106-231, :279-310) -> Model.test per batch of 8 tiles (test.py:69,81-84) -> utils.reconstruct
+(utils/tools.py:209-319) -> colourize + resize.  The reference moves every logit tile to the host and stitches in numpy;
+here tiles are cut (and normalised) straight from the device image, logits stay in HBM, and one kernel blends the
+overlaps and takes the argmax, so only the uint8 class mask (1 byte per pixel) ever needs to leave the GPU.
+
+Out of scope here (host I/O in the reference): reading the image file and cv2-resizing it to a multiple of the tile
+size (utils/tools.py:77-206); callers pass the fitted image."""
+import ctypes as C
+
+import torch
+
+from . import ops, lib as L
+from .lib import lib, check, ptr, stream
+
+
+def tile_grid(h, w, tile, stride):
+    if h < tile or w < tile or (h - tile) % stride or (w - tile) % stride:
+        raise ValueError('image %dx%d is not fitted to tile %d / stride %d (utils/tools.py:151-206 adjust_to_tile)' % (h, w, tile, stride))
+    return (h - tile) // stride + 1, (w - tile) // stride + 1
+
+
+def predict_image(model, image, tile=512, stride=None, batch=8):
+    """image: [C,H,W] raw 0..255 float tensor (host or device), fitted.  Returns the uint8 class mask [H,W] (device)."""
+    L.init()
+    stride = tile // 2 if stride is None else stride          # test.py:63
+    dev = model.device
+    img = image.to(dev, dtype=torch.float32).contiguous()
+    cimg, h, w = img.shape
+    if cimg != model.meta.ch:
+        raise ValueError('model expects %d-channel images' % model.meta.ch)
+    rows, cols = tile_grid(h, w, tile, stride)
+    n = rows * cols
+    mean, std = model._stats(model.meta.normalize_default)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    ncls = model.meta.n_classes
+    cp = (ncls + 3) & ~3
+    logits = torch.empty((n, tile, tile, cp), device=dev)
+    was_training = model.net.training
+    model.net.eval()
+    with torch.no_grad():
+        for k in range(0, n, batch):
+            b = min(batch, n - k)
+            x4 = ops.empty_nhwc(b, 4, tile, tile, dev)
+            check(lib.pylc_image_pack_tiles(ptr(img), cimg, h, w, tile, stride, k, b, m, s, ptr(x4), stream()))
+            y = model.net(x4)                                  # [b, ncls, tile', tile'] NHWC memory, pitch cp
+            if y.shape[2] != tile or y.shape[3] != tile:
+                raise ValueError('sliding-window stitching needs a same-size network (DeepLab); got %s' % (tuple(y.shape),))
+            logits[k:k + b].copy_(torch.as_strided(y, (b, tile, tile, cp), (tile * tile * ops.pitch_of(y), tile * ops.pitch_of(y), ops.pitch_of(y), 1),
+                                                   y.storage_offset()))
+    model.net.train(was_training)
+    mask = torch.empty((rows * stride + tile - stride, cols * stride + tile - stride), device=dev, dtype=torch.uint8)
+    check(lib.pylc_stitch_argmax(ptr(logits), cp, rows, cols, tile, stride, ncls, ptr(mask), stream()))
+    return mask
+
+
+def stitch_logits(logits_tiles, rows, cols, tile, stride):
+    """[n, C, tile, tile] logits (any layout, device) -> uint8 class mask, reconstruct() semantics."""
+    L.init()
+    n, c = logits_tiles.shape[:2]
+    cp = (c + 3) & ~3
+    buf = torch.zeros((n, tile, tile, cp), device=logits_tiles.device)
+    buf[..., :c] = logits_tiles.permute(0, 2, 3, 1)
+    mask = torch.empty((rows * stride + tile - stride, cols * stride + tile - stride), device=buf.device, dtype=torch.uint8)
+    check(lib.pylc_stitch_argmax(ptr(buf), cp, rows, cols, tile, stride, c, ptr(mask), stream()))
+    return mask
+
+
+def colourize(mask, palette_rgb, out_h=None, out_w=None):
+    """uint8 class mask [h,w] -> RGB uint8 [out_h,out_w,3] via the schema palette, nearest-neighbour resized."""
+    L.init()
+    h, w = mask.shape
+    oh, ow = out_h or h, out_w or w
+    pal = torch.as_tensor(palette_rgb, dtype=torch.uint8, device=mask.device).contiguous()
+    out = torch.empty((oh, ow, 3), device=mask.device, dtype=torch.uint8)
+    check(lib.pylc_colourize_resize(ptr(mask.contiguous()), h, w, ptr(pal), ptr(out), oh, ow, stream()))
+    return out

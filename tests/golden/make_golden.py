@@ -254,10 +254,39 @@ def golden_multiloss(out_dir):
         json.dump(out, f)
 
 
+def golden_stitch(out_dir):
+    """tools.reconstruct on synthetic logits (cv2.resize stubbed to identity) vs oracle.stitch_classes."""
+    import oracle
+    from utils.tools import reconstruct
+    print('== stitch')
+    palette = np.random.RandomState(77).randint(0, 256, (9, 3)).astype(np.uint8)
+    out, arrays = {}, {}
+    for tag, rows, cols, tile, stride in (('half', 3, 4, 16, 8), ('full', 2, 3, 16, 16)):
+        rs = np.random.RandomState(500 + rows)
+        tiles = (rs.standard_normal((rows * cols, 9, tile, tile)) * 2).astype(np.float32)
+        olap = tile - stride
+        w, h = cols * stride + olap, rows * stride + olap
+        meta = types.SimpleNamespace(extract={'w_fitted': w, 'h_fitted': h, 'w_scaled': w, 'h_scaled': h, 'offset': 0},
+                                     tile_size=tile, stride=stride, palette_rgb=[list(map(int, p)) for p in palette], n_classes=9)
+        batches = [torch.from_numpy(tiles[k:k + 5].copy()) for k in range(0, len(tiles), 5)]     # reconstruct mutates its input
+        ref_rgb = reconstruct(batches, meta)
+        mine = oracle.stitch_classes(tiles, rows, cols, tile, stride)
+        assert ref_rgb.shape == (h, w, 3)
+        assert np.array_equal(ref_rgb.astype(np.uint8), palette[mine]), 'oracle stitch != reference reconstruct'
+        arrays[tag + '_mask'] = mine
+        out[tag] = {'rows': rows, 'cols': cols, 'tile': tile, 'stride': stride, 'logit_seed': 500 + rows, 'logit_scale': 2}
+        print('  %s: %dx%d tiles -> mask %s identical to the reference' % (tag, rows, cols, mine.shape))
+    np.savez_compressed(os.path.join(out_dir, 'stitch.npz'), palette=palette, **arrays)
+    with open(os.path.join(out_dir, 'stitch.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def main():
     torch.set_num_threads(8)
     enter_reference()
-    which = sys.argv[1:] or ['multiloss', 'deeplab_resnet', 'deeplab_xception', 'unet']
+    which = sys.argv[1:] or ['multiloss', 'stitch', 'deeplab_resnet', 'deeplab_xception', 'unet']
+    if 'stitch' in which:
+        golden_stitch(HERE)
     if 'multiloss' in which:
         golden_multiloss(HERE)
     if 'deeplab_resnet' in which:
