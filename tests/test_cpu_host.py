@@ -136,3 +136,34 @@ def test_bucket_ranges_cover_arena():
     r = bucket_ranges(100, 32)
     assert r == [(0, 32), (32, 64), (64, 96), (96, 100)]
     assert bucket_ranges(59341228)[-1][1] == 59341228
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """checkpoint.py:51-67 layout; `meta` pickled as config.Parameters without the reference installed; optimizer state in
+    torch.optim.AdamW's layout.  (Cross-loading with the real reference: tests/golden/check_checkpoint_compat.py.)"""
+    import sys
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import checkpoint as ck
+    m = Model(Meta(arch='unet', n_classes=9, lr=3e-4), 'cpu').build()
+    m.optim.steps = 3
+    m.optim.m.normal_()
+    m.optim.v.uniform_()
+    m.epoch, m.iter = 2, 57
+    path = str(tmp_path / 'checkpoint.pth')
+    ck.save(m, path)
+    assert 'config' not in sys.modules
+    raw = ck.load_reference_file(path)
+    assert sorted(raw) == ['epoch', 'iter', 'meta', 'model', 'optim']
+    assert (type(raw['meta']).__module__, type(raw['meta']).__name__) == ('config', 'Parameters') and raw['meta'].lr == 3e-4
+    assert list(raw['model']) == list(m.net.state_dict())
+    m2 = Model(ck.meta_from_reference(raw['meta']), 'cpu').build()
+    ck.load_into(m2, path, resume=True)
+    assert (m2.iter, m2.epoch, m2.optim.steps) == (57, 2, 3) and abs(m2.optim.lr - 3e-4) < 1e-12
+    for (p, off), (p2, off2) in zip(zip(m.arena.params, m.arena.offsets), zip(m2.arena.params, m2.arena.offsets)):
+        assert torch.equal(p, p2)
+        assert torch.equal(torch.as_strided(m.optim.v, p.shape, p.stride(), off), torch.as_strided(m2.optim.v, p2.shape, p2.stride(), off2))
+    opt = torch.optim.AdamW(list(m2.net.parameters()), lr=1e-4)
+    opt.load_state_dict(raw['optim'])                              # a stock AdamW accepts the exported state
+    best = str(tmp_path / 'best.pth')
+    ck.save(m, best, best=True)
+    assert sorted(ck.load_reference_file(best)) == ['meta', 'model', 'optim']
