@@ -1,0 +1,67 @@
+"""BASELINE.json configurations at FULL size on the MI355X (-m gpu), checked through size-independent properties
+(the CPU oracle cannot run these sizes in seconds): shapes, finiteness, loss decomposition, BN-induced invariants,
+and a descent check over a few steps."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _finite(model):
+    g = model.arena.g
+    return bool(torch.isfinite(g).all()) and bool(torch.isfinite(model.arena.p).all())
+
+
+def test_config2_unet_512_bs16_ce_only(dev):
+    """configs[1]: U-Net, 3-ch 512x512, 9 classes, bs=16, CE loss only."""
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import runtime
+    from tests import _data as D
+    runtime.dropout_enabled = True
+    x, y = D.learnable_tiles(31, 16, 512, 9, cell=32)
+    model = Model(Meta(arch='unet', ce_weight=1.0, dice_weight=0.0, focal_weight=0.0, lr=1e-3), dev).build()
+    logits = model.test(x[:2])[0]
+    assert tuple(logits.shape) == (2, 9, 324, 324)                      # 512 - 188 (valid convs), unet.py:91-104
+    losses = []
+    for _ in range(4):
+        model.train(x, y)
+        losses.append(float(model.crit.ce))
+        assert _finite(model)
+    assert abs(losses[0] - math.log(9)) < 1.0 and losses[-1] < losses[0]   # starts near ln(9), descends
+    # a conv bias that feeds a training-mode BatchNorm has an identically zero gradient
+    gb = model.net.encoder[0].block.child(0).bias.grad
+    gw = model.net.encoder[0].block.child(0).weight.grad
+    assert float(gb.abs().max()) < 1e-4 * max(float(gw.abs().max()), 1e-12) + 1e-6
+    # total == ce when dice/focal weights are zero
+    yv = model.crit_target = model.crop_target(y.to(dev))
+    with torch.no_grad():
+        out = model.net(model.pack_input(x))
+        all4 = model.crit.all_losses(out, yv)
+    assert abs(float(all4[0]) - float(all4[1])) < 1e-6
+
+
+def test_config5_xception_1024_gray_bs8(dev):
+    """configs[4] (single-GPU part): DeepLabV3+/Xception, 1-channel 1024x1024 tiles, bs=8, full multi-loss."""
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import runtime
+    from tests import _data as D
+    runtime.dropout_enabled = True
+    x3, y = D.learnable_tiles(32, 8, 1024, 11, cell=64)
+    x = x3[:, :1].contiguous()
+    model = Model(Meta(backbone='xception', ch=1, n_classes=11, lr=1e-3), dev).build()
+    first = None
+    for it in range(3):
+        model.train(x, y)
+        tot = 0.5 * (float(model.crit.ce) + float(model.crit.dsc) + float(model.crit.fl))
+        first = tot if first is None else first
+        assert _finite(model)
+    assert tot < first
+    logits = model.test(x[:1])[0]
+    assert tuple(logits.shape) == (1, 11, 1024, 1024)
+    # Dice is bounded in [0, 1]; the three reported terms recombine to the optimised total (loss.py:112)
+    with torch.no_grad():
+        l4 = model.crit.all_losses(model.net(model.pack_input(x[:2])), y[:2].to(dev))
+    assert 0.0 <= float(l4[2]) <= 1.0
+    assert abs(float(l4[0]) - 0.5 * float(l4[1] + l4[2] + l4[3])) < 1e-5
