@@ -182,6 +182,18 @@ int pylc_stitch_argmax(const float* logits, int pitch, int rows, int cols, int t
 int pylc_colourize_resize(const unsigned char* mask, int h, int w, const unsigned char* palette_rgb,
                           unsigned char* out_rgb, int oh, int ow, void* stream);
 
+/* Confusion matrix cm[t*C + p] += 1 over n pixels of class-index masks (uint8 or int64; *_bytes = 1 or 8); the scores of
+ * utils/metrics.py:64-88 (weighted F1, weighted IoU = the "mIoU", MCC, normalised matrix) are functions of it.
+ * force_coverage applies Evaluator.validate()'s overwrite of the first C pixels (utils/evaluate.py:171-174). cm must be
+ * zeroed by the caller; integer atomics make the result exact and order-independent. */
+int pylc_confusion_matrix(const void* y_true, int true_bytes, const void* y_pred, int pred_bytes, long long n, int C,
+                          int force_coverage, unsigned long long* cm, void* stream);
+
+/* pylc_image_pack for uint8 tiles (the dtype the HDF5 database stores, db/database.py:218-233; db/buffer.py:62 converts to
+ * float32 on the host): the H2D copy carries 1 byte per sample instead of 4. */
+int pylc_image_pack_u8(const unsigned char* img_nchw, int B, int Cimg, int H, int W, const float* mean3,
+                       const float* std3, float* out_nhwc4, void* stream);
+
 /* Layout converters for module-boundary tensors (logits): [B][H][W][pitch] <-> [B][C][H][W]. */
 int pylc_nhwc_to_nchw(const float* x, int x_pitch, float* y, int B, int H, int W, int C, void* stream);
 int pylc_nchw_to_nhwc(const float* x, float* y, int y_pitch, int B, int H, int W, int C, void* stream);

@@ -214,6 +214,25 @@ __global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg
     }
 }
 
+// same as image_pack_kernel for uint8 tiles as stored in the HDF5 database (db/database.py:218-233): 4x fewer PCIe bytes
+__global__ void image_pack_u8_kernel(const unsigned char* __restrict__ img, int B, int Cimg, int HW, f32x4 mean, f32x4 sd,
+                                     float* __restrict__ out) {
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, p = i % HW;
+        const unsigned char* src = img + b * Cimg * HW + p;
+        const float x = (float)src[0];
+        const float y = Cimg == 3 ? (float)src[HW] : x;
+        const float z = Cimg == 3 ? (float)src[2 * (long long)HW] : x;
+        f32x4 r;
+        r.x = ((x - mean.x) / sd.x) / 255.f;
+        r.y = ((y - mean.y) / sd.y) / 255.f;
+        r.z = ((z - mean.z) / sd.z) / 255.f;
+        r.w = 0.f;
+        st4(out + 4 * i, r);
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ y, int B, int HW, int C) {
     const long long total = (long long)B * C * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -298,6 +317,15 @@ extern "C" int pylc_image_pack(const float* img, int B, int Cimg, int H, int W, 
     PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3), "image_pack: bad arguments");
     f32x4 mean = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
     hipLaunchKernelGGL(image_pack_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream), img, B, Cimg, H * W, mean, sd, out);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_image_pack_u8(const unsigned char* img, int B, int Cimg, int H, int W, const float* mean3, const float* std3, float* out,
+                                  void* stream) {
+    PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3), "image_pack_u8: bad arguments");
+    f32x4 mean = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+    hipLaunchKernelGGL(image_pack_u8_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream), img, B, Cimg, H * W, mean, sd, out);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

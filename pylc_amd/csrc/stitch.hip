@@ -174,3 +174,50 @@ extern "C" int pylc_image_pack_tiles(const float* img, int Cimg, int H, int W, i
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Evaluation: confusion matrix of class-index masks (replaces the sklearn passes over ~1e7-pixel flattened arrays in
+// utils/metrics.py:64-88; the scores are simple functions of the n_cls x n_cls count matrix).  Integer counts in LDS,
+// merged with 64-bit integer atomics: exact and order-independent.  Evaluator.validate()'s coverage quirk
+// (utils/evaluate.py:171-174: the first n_classes pixels of both arrays are overwritten with 0..n_classes-1) is applied
+// on the fly when force_coverage != 0.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace pylc {
+template <typename TT, typename TP>
+__global__ __launch_bounds__(256) void confusion_kernel(const TT* __restrict__ yt, const TP* __restrict__ yp, long long n, int C,
+                                                         int force_coverage, unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int hist[SMAXC * SMAXC];
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int t = (int)yt[i], p = (int)yp[i];
+        if (force_coverage && i < C) { t = (int)i; p = (int)i; }
+        if ((unsigned)t < (unsigned)C && (unsigned)p < (unsigned)C) atomicAdd(&hist[t * C + p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+}  // namespace pylc
+
+extern "C" int pylc_confusion_matrix(const void* y_true, int true_bytes, const void* y_pred, int pred_bytes, long long n, int C,
+                                     int force_coverage, unsigned long long* cm /* [C*C], zeroed by the caller */, void* stream) {
+    PYLC_REQUIRE(y_true && y_pred && cm && n > 0 && C >= 2 && C <= SMAXC, "confusion_matrix: bad arguments");
+    PYLC_REQUIRE((true_bytes == 1 || true_bytes == 8) && (pred_bytes == 1 || pred_bytes == 8), "confusion_matrix: masks must be uint8 or int64");
+    const int blocks = grid_for(n) < 1024 ? grid_for(n) : 1024;
+    hipStream_t st = as_stream(stream);
+    if (true_bytes == 1 && pred_bytes == 1)
+        hipLaunchKernelGGL((confusion_kernel<unsigned char, unsigned char>), dim3(blocks), dim3(256), 0, st, (const unsigned char*)y_true,
+                           (const unsigned char*)y_pred, n, C, force_coverage, cm);
+    else if (true_bytes == 8 && pred_bytes == 1)
+        hipLaunchKernelGGL((confusion_kernel<long long, unsigned char>), dim3(blocks), dim3(256), 0, st, (const long long*)y_true,
+                           (const unsigned char*)y_pred, n, C, force_coverage, cm);
+    else if (true_bytes == 1 && pred_bytes == 8)
+        hipLaunchKernelGGL((confusion_kernel<unsigned char, long long>), dim3(blocks), dim3(256), 0, st, (const unsigned char*)y_true,
+                           (const long long*)y_pred, n, C, force_coverage, cm);
+    else
+        hipLaunchKernelGGL((confusion_kernel<long long, long long>), dim3(blocks), dim3(256), 0, st, (const long long*)y_true,
+                           (const long long*)y_pred, n, C, force_coverage, cm);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

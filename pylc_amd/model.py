@@ -153,7 +153,9 @@ class Model:
         """raw [B,ch,H,W] 0..255 (host or device) -> normalised NHWC4 device tensor."""
         if x.dim() != 4 or x.shape[1] != self.meta.ch:
             raise ValueError('expected [B,%d,H,W] tiles, got %s' % (self.meta.ch, tuple(x.shape)))
-        x = x.to(self.device, dtype=torch.float32, non_blocking=True)
+        if x.dtype != torch.uint8:
+            x = x.to(dtype=torch.float32)
+        x = x.to(self.device, non_blocking=True)
         mean, std = self._stats(default)
         return ops.image_pack(x, mean, std)
 
@@ -168,7 +170,7 @@ class Model:
         """One optimisation step (model.py:282-336)."""
         self.net.train()
         x4 = self.pack_input(x)
-        y = self.crop_target(y.to(self.device, non_blocking=True))
+        y = self.crop_target(y.to(self.device, non_blocking=True).long())
         y_hat = self.net(x4)
         loss = self.crit(y_hat, y)
         self.loss.push(torch.stack((self.crit.ce, self.crit.dsc, self.crit.fl)))
@@ -194,7 +196,7 @@ class Model:
         """Validation step (model.py:338-365): eval-mode forward, the three losses, returns [y_hat]."""
         self.net.eval()
         x4 = self.pack_input(x)
-        y = self.crop_target(y.to(self.device, non_blocking=True))
+        y = self.crop_target(y.to(self.device, non_blocking=True).long())
         with torch.no_grad():
             y_hat = self.net(x4)
             self.loss.push(self.crit.all_losses(y_hat, y)[1:4])

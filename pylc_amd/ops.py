@@ -582,7 +582,10 @@ def image_pack(img, mean3, std3):
     out = empty_nhwc(b, 4, h, w, img.device)
     m = (C.c_float * 3)(*[float(v) for v in mean3])
     s = (C.c_float * 3)(*[float(v) for v in std3])
-    check(lib.pylc_image_pack(ptr(img), b, c, h, w, m, s, ptr(out), stream()))
+    if img.dtype == torch.uint8:          # tiles as stored in the database: normalise straight from bytes
+        check(lib.pylc_image_pack_u8(ptr(img), b, c, h, w, m, s, ptr(out), stream()))
+    else:
+        check(lib.pylc_image_pack(ptr(img.float()), b, c, h, w, m, s, ptr(out), stream()))
     return out
 
 

@@ -85,3 +85,51 @@ def test_predict_image_matches_oracle(dev):
     print('predict_image: %.2f%% pixels agree, %.1f%% decided' % (100 * agree, 100 * decided.mean()))
     assert decided.mean() > 0.4 and agree > 0.97
     assert np.array_equal(got[decided], want[decided])
+
+
+def test_gpu_metrics_match_oracle(dev):
+    """Confusion-matrix kernel + closed-form scores vs the oracle (itself equal to sklearn, tests/test_cpu_oracle.py)."""
+    import oracle
+    from oracle import metrics as om
+    from pylc_amd import metrics
+    rs = np.random.RandomState(3)
+    for n_cls, n in ((9, 1 << 20), (11, 777777)):
+        yt = rs.randint(0, n_cls, n)
+        yp = np.where(rs.rand(n) < 0.6, yt, rs.randint(0, n_cls - 2, n))
+        for tdt, pdt in ((torch.int64, torch.uint8), (torch.uint8, torch.uint8), (torch.int64, torch.int64)):
+            cm = metrics.confusion_matrix(torch.from_numpy(yt).to(dev, tdt), torch.from_numpy(yp).to(dev, pdt), n_cls)
+            want = om.confusion_matrix(yt, yp, n_cls)
+            assert np.array_equal(cm.cpu().numpy(), want)
+        got = metrics.scores(cm)
+        ref = om.scores_from_confusion(want)
+        assert abs(got['iou'] - oracle.weighted_jaccard(yt, yp, n_cls)) < 1e-12
+        for k in ('f1', 'iou', 'mcc'):
+            assert abs(got[k] - ref[k]) < 1e-12
+        assert np.abs(got['cmatrix'] - ref['cmatrix']).max() < 1e-12
+
+
+def test_uint8_feed_equals_float_path(dev):
+    """uint8 tiles through the pinned, double-buffered feeder give bit-identical network inputs and training losses."""
+    from pylc_amd import runtime
+    from pylc_amd.data import TileFeeder
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    import oracle
+    runtime.dropout_enabled = False
+    batches = [D.learnable_tiles(40 + i, 2, 64, 9) for i in range(4)]
+    u8 = [(x.to(torch.uint8).numpy(), y.to(torch.uint8).numpy()) for x, y in batches]
+    w = oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=4)
+    res = []
+    for feed in (batches, TileFeeder(u8, dev)):
+        model = Model(Meta(), dev).build()
+        model.net.load_state_dict(w)
+        out = []
+        for x, y in feed:
+            model.train(x, y)
+            out.append((float(model.crit.ce), float(model.crit.dsc), float(model.crit.fl)))
+        res.append(out)
+    assert len(res[1]) == 4 and res[0] == res[1]
+    x = batches[0][0]
+    a = Model(Meta(), dev).pack_input(x)
+    b = Model(Meta(), dev).pack_input(x.to(torch.uint8))
+    assert torch.equal(a, b)
