@@ -22,3 +22,4 @@ from .loss import multiloss, ce_loss, dice_loss, focal_loss  # noqa: F401
 from .step import normalize_image, train_step, eval_step, test_step, make_optimizer, calibrate_bn, StepConfig  # noqa: F401
 from .metrics import weighted_jaccard  # noqa: F401
 from .stitch import split_tiles, stitch_scores, stitch_classes, colourize_resize  # noqa: F401
+from .driver import run_training  # noqa: F401

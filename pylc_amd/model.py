@@ -73,6 +73,7 @@ class LossLog:
         self._pending = []
         self.intv = []
         self.train, self.valid, self.lr = [], [], []
+        self.avg_dice, self.best_dice, self.is_best = 1.0, 1.0, False
 
     def push(self, triple):
         self._pending.append(triple)
@@ -85,10 +86,18 @@ class LossLog:
         return self.intv
 
     def log(self, it, training):
+        """RunningLoss.log (loss.py:270-293): interval average; a validation entry also updates best-Dice tracking."""
         self.flush()
         if self.intv:
-            avg = tuple(np.mean(np.asarray(self.intv), axis=0).tolist())
-            (self.train if training else self.valid).append((it,) + avg)
+            avg = tuple(np.mean(np.asarray(self.intv, np.float64), axis=0).tolist())
+            if training:
+                self.train.append((it,) + avg)
+            else:
+                self.valid.append((it,) + avg)
+                self.avg_dice = avg[1]
+                self.is_best = self.avg_dice < self.best_dice
+                if self.is_best:
+                    self.best_dice = self.avg_dice
         self.intv = []
 
 
@@ -213,3 +222,17 @@ class Model:
 
     def get_lr(self):
         return self.optim.lr
+
+    def model_id(self):
+        """gen_id (model.py:482-492): pylc_<arch>_ch<channels>_<schema>."""
+        return 'pylc_%s_ch%d_schema_%s' % (self.meta.arch, self.meta.ch, 'a' if self.meta.n_classes == 9 else 'b')
+
+    def save(self, save_dir):
+        """Model.save (model.py:389-392 -> checkpoint.py:51-67): checkpoint.pth always, <id>.pth on a new best validation Dice."""
+        import os
+        from . import checkpoint
+        d = os.path.join(save_dir, self.model_id())
+        os.makedirs(d, exist_ok=True)
+        checkpoint.save(self, os.path.join(d, 'checkpoint.pth'))
+        if self.loss.is_best:
+            checkpoint.save(self, os.path.join(d, self.model_id() + '.pth'), best=True)

@@ -281,12 +281,62 @@ def golden_stitch(out_dir):
         json.dump(out, f)
 
 
+def golden_driver(out_dir):
+    """train.py's train_epoch / validate cadence + RunningLoss bookkeeping on a 3-batch synthetic dataset."""
+    import oracle
+    from oracle import step as ostep
+    from tests import _data as D
+    import train as ref_train
+    print('== driver')
+    n_cls, b, hw, n_epochs, report = 9, 3, 96, 2, 2
+    cw = D.class_weights(n_cls)
+    ref = build_reference_model('deeplab', 'resnet', n_cls, 3, ostep.PX_RGB_MEAN, ostep.PX_RGB_STD, cw, False)
+    ref.meta.report = report
+    spec = oracle.state_spec('deeplab', 'resnet', n_cls, 3)
+    tr = [D.learnable_tiles(700 + i, b, hw, n_cls) for i in range(3)]
+    va = [D.learnable_tiles(800 + i, b, hw, n_cls) for i in range(2)]
+    cfg = ostep.StepConfig('deeplab', 'resnet', n_cls, 3, dropout=False)
+    w = ostep.calibrate_bn(oracle.formula_state(spec, salt=6), cfg, tr[0][0].clone())
+    ref.net.load_state_dict(w)
+    ref.net.train()
+    best = []
+    orig_save = ref.save
+    def save_spy():
+        best.append(bool(ref.loss.is_best))
+        orig_save()
+    ref.save = save_spy
+    for epoch in range(n_epochs):                      # train.py:72-92 (the loop body; the CLI/DB setup above it is out of scope)
+        ref.loss.lr += [(ref.iter, ref.get_lr())]
+        if epoch == 0:
+            ref = ref_train.validate(ref, [(x.clone(), y.clone()) for x, y in va], len(va))
+        ref = ref_train.train_epoch(ref, [(x.clone(), y.clone()) for x, y in tr], len(tr))
+        ref = ref_train.validate(ref, [(x.clone(), y.clone()) for x, y in va], len(va))
+        ref.sched.step()
+        ref.epoch += 1
+    sd = {k: v.clone() for k, v in w.items()}
+    log = oracle.run_training(sd, cfg, tr, va, n_epochs, report=report)
+    f = lambda rows: [[float(v) for v in r] for r in rows]
+    rt, rv = f(ref.loss.train), f(ref.loss.valid)
+    assert [r[0] for r in rt] == [r[0] for r in log.train] and [r[0] for r in rv] == [r[0] for r in log.valid]
+    err = max(abs(a - b) for A, B in ((rt, log.train), (rv, log.valid)) for ra, rb in zip(A, B) for a, b in zip(ra, rb))
+    print('  train entries %s, valid entries %s, max|diff| vs oracle driver %.3g, best events %s' % ([r[0] for r in rt], [r[0] for r in rv], err, best))
+    assert err < 1e-3 and best == log.best_events
+    assert abs(ref.get_lr() - 1e-4 * 0.9 ** n_epochs) < 1e-12
+    with open(os.path.join(out_dir, 'driver.json'), 'w') as fh:
+        json.dump({'train': rt, 'valid': rv, 'best_events': best, 'best_dice': float(ref.loss.best_dice),
+                   'lr': f(ref.loss.lr), 'final_lr': ref.get_lr(),
+                   'config': {'n_classes': n_cls, 'b': b, 'hw': hw, 'n_epochs': n_epochs, 'report': report, 'weight_salt': 6,
+                              'train_seeds': [700, 701, 702], 'valid_seeds': [800, 801]}}, fh)
+
+
 def main():
     torch.set_num_threads(8)
     enter_reference()
-    which = sys.argv[1:] or ['multiloss', 'stitch', 'deeplab_resnet', 'deeplab_xception', 'unet']
+    which = sys.argv[1:] or ['multiloss', 'stitch', 'driver', 'deeplab_resnet', 'deeplab_xception', 'unet']
     if 'stitch' in which:
         golden_stitch(HERE)
+    if 'driver' in which:
+        golden_driver(HERE)
     if 'multiloss' in which:
         golden_multiloss(HERE)
     if 'deeplab_resnet' in which:

@@ -176,3 +176,35 @@ print('RESULT', runtime.sync_group is not None, float(m.crit.ce), float(m.crit.d
         res[force] = (f[1], [float(v) for v in f[2:]])
     assert res[''][0] == 'False' and res['1'][0] == 'True'
     assert res[''][1] == res['1'][1], res
+
+
+def test_epoch_driver_matches_reference(dev, tmp_path):
+    """pylc_amd.train.trainer vs the reference's train.py loop (fixture tests/golden/driver.json): same logging cadence,
+    interval averages, best-Dice events, learning-rate schedule, checkpoint files."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import runtime, train
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    g = json.load(open(os.path.join(HERE, 'driver.json')))
+    c = g['config']
+    runtime.dropout_enabled = False
+    tr = [D.learnable_tiles(s, c['b'], c['hw'], c['n_classes']) for s in c['train_seeds']]
+    va = [D.learnable_tiles(s, c['b'], c['hw'], c['n_classes']) for s in c['valid_seeds']]
+    cfg = ostep.StepConfig('deeplab', 'resnet', c['n_classes'], 3, dropout=False)
+    w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec('deeplab', 'resnet', c['n_classes'], 3), salt=c['weight_salt']), cfg, tr[0][0].clone())
+    model = Model(Meta(report=c['report']), dev).build()
+    model.net.load_state_dict(w)
+    best_seen = []
+    orig = model.save
+    model.save = lambda d: (best_seen.append(bool(model.loss.is_best)), orig(d))
+    train.trainer(model, tr, va, c['n_epochs'], save_dir=str(tmp_path))
+    for mine, ref in ((model.loss.train, g['train']), (model.loss.valid, g['valid'])):
+        assert [r[0] for r in mine] == [r[0] for r in ref]
+        for a, b in zip(mine, ref):
+            assert max(abs(x - y) for x, y in zip(a[1:], b[1:])) < 2e-3, (a, b)
+    assert best_seen == g['best_events'] and abs(model.loss.best_dice - g['best_dice']) < 2e-3
+    assert abs(model.get_lr() - g['final_lr']) < 1e-12 and model.epoch == c['n_epochs']
+    assert [round(v[1], 12) for v in model.loss.lr] == [round(v[1], 12) for v in g['lr']]
+    d = os.path.join(str(tmp_path), model.model_id())
+    assert sorted(os.listdir(d)) == ['checkpoint.pth', model.model_id() + '.pth']
