@@ -1,0 +1,32 @@
+"""Throughput of the other BASELINE configurations on one MI355X (informational; bench.py is the contract)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pylc_amd.model import Model, Meta
+dev = torch.device('cuda:0')
+CFG = {
+    'c2_unet_512_bs16_ce': (Meta(arch='unet', ce_weight=1.0, dice_weight=0.0, focal_weight=0.0, report=10**9), 16, 3, 512, 9),
+    'c3_r101_512_bs32': (Meta(report=10**9), 32, 3, 512, 9),
+    'c4_r101_512_bs32_11cls': (Meta(n_classes=11, report=10**9), 32, 3, 512, 11),
+    'c5_xception_1024_gray_bs8': (Meta(backbone='xception', ch=1, n_classes=11, report=10**9), 8, 1, 1024, 11),
+}
+for name in (sys.argv[1:] or list(CFG)):
+    meta, b, ch, hw, ncls = CFG[name]
+    model = Model(meta, dev).build()
+    x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (b, ch, hw, hw)).astype(np.float32)).to(dev)
+    y = torch.from_numpy(np.random.RandomState(2).randint(0, ncls, (b, hw, hw)).astype(np.int64)).to(dev)
+    for _ in range(2): model.train(x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 5
+    for _ in range(n): model.train(x, y)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    model.net.eval()
+    with torch.no_grad():
+        for _ in range(2): model.test(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): model.test(x)
+        torch.cuda.synchronize(); di = (time.perf_counter() - t0) / n
+    print('%-28s train %7.1f ms/step %7.1f tiles/s | inference %7.1f ms/batch %7.1f tiles/s | peak mem %.1f GB' % (
+        name, dt * 1e3, b / dt, di * 1e3, b / di, torch.cuda.max_memory_allocated() / 2**30), flush=True)
+    del model, x, y
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
