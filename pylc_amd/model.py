@@ -191,6 +191,7 @@ class Model:
             self._bucketer.reset()
             runtime.grad_ready = self._bucketer.ready
         loss.backward()
+        ops.sync_side_streams()                   # wgrad kernels run on a side stream
         if runtime.sync_group is not None:
             runtime.grad_ready = None
             self._bucketer.finish()               # gradient SUM all-reduce, overlapped with the backward above

@@ -145,6 +145,31 @@ def _conv_desc(x, cin, cout, r, s, stride, pad, dil, x_pitch, y_pitch):
     return d
 
 
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def sync_side_streams():
+    """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
+    all-reduce reads the arena)."""
+    for st in _side_streams.values():
+        torch.cuda.current_stream().wait_stream(st)
+
+
 def _grad_target(param):
     """Arena-backed gradient view for `param` if the optimiser registered one, else None."""
     return getattr(param, '_pylc_grad', None)
@@ -234,17 +259,31 @@ class Conv2dFn(torch.autograd.Function):
                 ev[1].record()
             d.x_pitch = pitch_of(x)
         if ctx.needs_input_grad[1]:
-            nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
-            ws = _ws(nbytes, x.device)
-            tgt = _grad_target(w)
-            if cin_w % 4 == 0:
-                dw = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
-                check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, st))
-            else:
-                dw4 = torch.empty((cout, r, s, cin), device=x.device)
-                check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, st))
-                dw = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
-                dw.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
+            # wgrad is off the critical chain (only the optimiser needs it), so it runs on a side stream: the matrix-bound
+            # wgrad kernels then overlap the HBM-bound BatchNorm-backward kernels of the layers that follow on the main stream
+            side = _side_stream(x.device) if _runtime.wgrad_side_stream else None
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                x.record_stream(side)
+                dy.record_stream(side)
+                w_k.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else _nullcontext():
+                sst = stream()
+                nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
+                ws = _ws(nbytes, x.device)
+                tgt = _grad_target(w)
+                if cin_w % 4 == 0:
+                    dw = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
+                    check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, sst))
+                else:
+                    dw4 = torch.empty((cout, r, s, cin), device=x.device)
+                    check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, sst))
+                    dw = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
+                    dw.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
+            if side is not None and tgt is None:
+                torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
             dw = _deliver_grad(w, dw)
         if has_bias and ctx.needs_input_grad[2]:
             m = dy.shape[0] * dy.shape[2] * dy.shape[3]

@@ -90,6 +90,8 @@ class GradBucketer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.pending[b] = -1
+        from .ops import sync_side_streams
+        sync_side_streams()          # this bucket's conv gradients were produced on the wgrad side stream
         self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):

@@ -9,6 +9,7 @@ class _Runtime:
         self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
+        self.wgrad_side_stream = True  # run conv wgrad kernels on a second HIP stream (overlaps BN backward)
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         self.seed = 0x5EED
