@@ -67,6 +67,12 @@ int pylc_get_conv_precision(void);
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */
 int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
                     float* y, void* stream);
+/* Same, and additionally emits per-M-tile partial column sums of y for the BatchNorm that follows (saves a full read
+ * of y): stats_partial has pylc_conv2d_fwd_stats_floats(d) floats, laid out [rows][2][roundup4(Cout)] = (sum | sum of
+ * squares); *stats_rows receives the number of rows written.  Combine with pylc_bn_stats_from_partial. */
+size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d);
+int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
+                          float* y, float* stats_partial, int* stats_rows, void* stream);
 /* dx = conv_transpose(dy, w).  w_crsk = weights re-laid-out as [Cin][R][S][Cout] by
  * pylc_weight_transpose.  accumulate != 0 adds into dx instead of overwriting it. */
 int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx,
@@ -107,6 +113,8 @@ size_t pylc_bn_workspace_floats(long long M, int C);
  * models/sync_batchnorm/batchnorm.py:66-68 (sum, ssum, size). */
 int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, float* sums /*[2C]*/,
                   float* workspace, void* stream);
+/* sums[0:2C] from the per-tile partials written by pylc_conv2d_fwd_stats (fp64 combine, fixed order). */
+int pylc_bn_stats_from_partial(const float* partial, int n_rows, int C, float* sums /*[2C]*/, void* stream);
 /* From (possibly all-reduced) sums and the GLOBAL row count n: mean, invstd = 1/sqrt(var_biased + eps)
  * (clamp_eps != 0 selects batchnorm.py:125's clamp(var, eps)^-1/2 instead), running stats update with
  * the unbiased variance (momentum), and the fused affine scale = gamma*invstd, shift = beta - mean*scale. */

@@ -221,6 +221,13 @@ extern "C" int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, fl
     return PYLC_OK;
 }
 
+extern "C" int pylc_bn_stats_from_partial(const float* partial, int n_rows, int C, float* sums, void* stream) {
+    PYLC_REQUIRE(partial && sums && n_rows > 0 && C > 0, "bn_stats_from_partial: bad arguments");
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, 2 * C, sums);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
 extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                 float* shift, void* stream) {

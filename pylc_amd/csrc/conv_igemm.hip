@@ -73,6 +73,7 @@ struct GatherGemmArgs {
     int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
     int accumulate;
     int tiles_n;
+    float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)
 };
 
 // PREC 0: v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chain, 157 TFLOP/s peak).
@@ -329,23 +330,53 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         rowoff[tid] = off;
     }
     __syncthreads();
+    // BatchNorm statistics ride along: each lane owns one output column of the wave tile, so the column sums of the
+    // values just computed cost 2 FMAs per element here instead of a separate full read of y
+    float* sred = reinterpret_cast<float*>(smem) + 1024;          // [BM/WM][BN][2], past the row table
+    const bool do_stats = a.stats != nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
-        if (n >= a.N_store) continue;
+        const bool nok = n < a.N_store;
         const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+        float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const long long off = rowoff[row];
-                if (off >= 0) {
+                if (nok && off >= 0) {
                     float val = acc[i][j][r] + bv;
                     float* dst = a.y + off + n;
                     if (a.accumulate) val += *dst;
                     *dst = val;
+                    cs += val;
+                    css += val * val;
                 }
+            }
+        }
+        if (do_stats) {
+            cs += __shfl_xor(cs, 32, 64);                           // lanes l and l+32 hold the same column
+            css += __shfl_xor(css, 32, 64);
+            if (lane < 32) {
+                float* d = sred + ((wave_m * BN) + wave_n * WN + j * 32 + lane) * 2;
+                d[0] = cs;
+                d[1] = css;
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int n = n0 + tid;
+            if (n < a.N_store) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
+                float* dst = a.stats + (size_t)(tile / a.tiles_n) * 2 * a.N_store;
+                dst[n] = sm;
+                dst[a.N_store + n] = sq;
             }
         }
     }
@@ -702,8 +733,11 @@ constexpr size_t wg16_smem() { return (size_t)3 * 32 * (wg_rowb(BN) + wg_rowb(BC
 int g_big_tile = 1;
 int g_conv_precision = 1;      // 0 = fp32 MFMA, 1 = bf16x6 (default); see pylc_set_conv_precision
 
+static thread_local int g_last_bm = 128;      // M-tile height of the most recent gather-GEMM launch on this thread
+
 template <int BM, int BN, int WM, int WN, bool CIN4, int PREC>
 static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
+    g_last_bm = BM;
     const int tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N_store, BN);
     const long long grid = (long long)tiles_m * a.tiles_n;
@@ -793,10 +827,31 @@ extern "C" int pylc_get_conv_precision(void) { return g_conv_precision; }
 // tuning knob (tools/conv_bench.py): allow / forbid the 256x128 8-wave tile
 extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
 
+static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
+                           void* stream);
+
 extern "C" int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, stream);
+}
+
+extern "C" size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d) {
+    if (check_desc(d)) return 0;
+    const long long M = (long long)d->B * d->OH * d->OW;
+    return (size_t)cdiv<long long>(M, 128) * 2 * (size_t)roundup4(d->Cout);      // smallest M tile is 128 rows
+}
+
+extern "C" int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats_partial,
+                                     int* stats_rows, void* stream) {
+    PYLC_REQUIRE(stats_partial && stats_rows, "conv2d_fwd_stats: null statistics buffer");
+    return conv2d_fwd_impl(d, x, w, bias, y, stats_partial, stats_rows, stream);
+}
+
+static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
+                           void* stream) {
     if (int rc = check_desc(d)) return rc;
     PYLC_REQUIRE(x && w && y, "null pointer");
     GatherGemmArgs a{};
+    a.stats = stats;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
     a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
@@ -808,7 +863,9 @@ extern "C" int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const floa
     a.OH = d->OH; a.OW = d->OW; a.out_sh = a.out_sw = 1; a.oh0 = a.ow0 = 0; a.y_pitch = d->y_pitch;
     a.accumulate = 0;
     const bool cin4 = d->Cin == 4 && d->R * d->S > 1;
-    return dispatch_gg(a, cin4, as_stream(stream));
+    if (int rc = dispatch_gg(a, cin4, as_stream(stream))) return rc;
+    if (stats_rows) *stats_rows = cdiv(a.M, a.tiles_n > 0 ? g_last_bm : 128);
+    return PYLC_OK;
 }
 
 extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate, void* stream) {

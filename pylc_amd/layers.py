@@ -13,9 +13,10 @@ from .runtime import runtime
 class Conv2d(nn.Module):
     """Dense conv; weight is logical [Cout, Cin, k, k] with KRSC memory (what the MFMA kernel streams)."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False, init='resnet'):
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False, init='resnet', bn=False):
         super().__init__()
         self.cin, self.cout, self.k = cin, cout, k
+        self.feeds_bn = bn and cout % 4 == 0      # a BatchNorm consumes the output: emit its statistics from the conv epilogue
         self.stride, self.padding, self.dilation = stride, padding, dilation
         w = torch.empty(cout, k, k, cin)
         fan_in = cin * k * k
@@ -32,7 +33,7 @@ class Conv2d(nn.Module):
             self.register_parameter('bias', None)
 
     def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training)
 
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,

@@ -42,6 +42,8 @@ SIGNATURES = {
     'pylc_set_conv_precision': (_I, [_I]),
     'pylc_get_conv_precision': (_I, []),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    'pylc_conv2d_fwd_stats_floats': (_SZ, [C.POINTER(ConvDesc)]),
+    'pylc_conv2d_fwd_stats': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(_I), _P]),
     'pylc_conv2d_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
     'pylc_conv2d_wgrad_workspace': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _SZ, _P]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     'pylc_dwconv3x3_wgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _SZ, _P]),
     'pylc_bn_workspace_floats': (_SZ, [_LL, _I]),
     'pylc_bn_stats': (_I, [_P, _LL, _I, _I, _P, _P, _P]),
+    'pylc_bn_stats_from_partial': (_I, [_P, _I, _I, _P, _P]),
     'pylc_bn_finalize': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'pylc_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P]),

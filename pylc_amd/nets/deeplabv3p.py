@@ -15,7 +15,7 @@ from .encoder_xception import AlignedXception
 class _ASPPBranch(nn.Module):
     def __init__(self, cin, cout, k, dilation):
         super().__init__()
-        self.atrous_conv = Conv2d(cin, cout, k, 1, 0 if k == 1 else dilation, dilation, init='kaiming')
+        self.atrous_conv = Conv2d(cin, cout, k, 1, 0 if k == 1 else dilation, dilation, init='kaiming', bn=True)
         self.bn = BatchNorm2d(cout)
 
     def forward(self, x):
@@ -30,8 +30,8 @@ class ASPP(nn.Module):
         self.aspp2 = _ASPPBranch(inplanes, 256, 3, dil[1])
         self.aspp3 = _ASPPBranch(inplanes, 256, 3, dil[2])
         self.aspp4 = _ASPPBranch(inplanes, 256, 3, dil[3])
-        self.global_avg_pool = Named(_1=Conv2d(inplanes, 256, 1, init='kaiming'), _2=BatchNorm2d(256))
-        self.conv1 = Conv2d(1280, 256, 1, init='kaiming')
+        self.global_avg_pool = Named(_1=Conv2d(inplanes, 256, 1, init='kaiming', bn=True), _2=BatchNorm2d(256))
+        self.conv1 = Conv2d(1280, 256, 1, init='kaiming', bn=True)
         self.bn1 = BatchNorm2d(256)
         self.dropout = Dropout(0.5)
 
@@ -47,10 +47,10 @@ class ASPP(nn.Module):
 class Decoder(nn.Module):
     def __init__(self, n_classes, low_level_inplanes):
         super().__init__()
-        self.conv1 = Conv2d(low_level_inplanes, 48, 1, init='kaiming')
+        self.conv1 = Conv2d(low_level_inplanes, 48, 1, init='kaiming', bn=True)
         self.bn1 = BatchNorm2d(48)
-        self.last_conv = Named(_0=Conv2d(304, 256, 3, 1, 1, init='kaiming'), _1=BatchNorm2d(256),
-                               _4=Conv2d(256, 256, 3, 1, 1, init='kaiming'), _5=BatchNorm2d(256),
+        self.last_conv = Named(_0=Conv2d(304, 256, 3, 1, 1, init='kaiming', bn=True), _1=BatchNorm2d(256),
+                               _4=Conv2d(256, 256, 3, 1, 1, init='kaiming', bn=True), _5=BatchNorm2d(256),
                                _8=Conv2d(256, n_classes, 1, bias=True, init='kaiming'))
         self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
 

@@ -13,14 +13,14 @@ from ..layers import Conv2d, BatchNorm2d, Named
 class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride, dilation, project):
         super().__init__()
-        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.conv1 = Conv2d(inplanes, planes, 1, bn=True)
         self.bn1 = BatchNorm2d(planes)
-        self.conv2 = Conv2d(planes, planes, 3, stride, dilation, dilation)
+        self.conv2 = Conv2d(planes, planes, 3, stride, dilation, dilation, bn=True)
         self.bn2 = BatchNorm2d(planes)
-        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.conv3 = Conv2d(planes, planes * 4, 1, bn=True)
         self.bn3 = BatchNorm2d(planes * 4)
         if project:
-            self.downsample = Named(_0=Conv2d(inplanes, planes * 4, 1, stride), _1=BatchNorm2d(planes * 4))
+            self.downsample = Named(_0=Conv2d(inplanes, planes * 4, 1, stride, bn=True), _1=BatchNorm2d(planes * 4))
         else:
             self.downsample = None
 
@@ -46,7 +46,7 @@ class ResNet101(nn.Module):
             strides, dils = (1, 2, 1, 1), (1, 1, 2, 4)
         else:
             raise NotImplementedError(output_stride)
-        self.conv1 = Conv2d(3, 64, 7, 2, 3)
+        self.conv1 = Conv2d(3, 64, 7, 2, 3, bn=True)
         self.bn1 = BatchNorm2d(64)
         inpl = 64
         for li, (planes, n) in enumerate(self.LAYERS):

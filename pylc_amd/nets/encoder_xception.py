@@ -17,7 +17,7 @@ class SeparableConv2d(nn.Module):
         super().__init__()
         self.conv1 = DepthwiseConv3x3(cin, stride, dilation)
         self.bn = BatchNorm2d(cin)
-        self.pointwise = Conv2d(cin, cout, 1)
+        self.pointwise = Conv2d(cin, cout, 1, bn=True)         # every SeparableConv2d is followed by a BatchNorm (Block / bn3-5)
 
     def forward(self, x):
         return self.pointwise(self.bn(self.conv1(x)))
@@ -27,7 +27,7 @@ class Block(nn.Module):
     def __init__(self, inpl, planes, reps, stride=1, dilation=1, start_with_relu=True, grow_first=True, is_last=False):
         super().__init__()
         if planes != inpl or stride != 1:
-            self.skip = Conv2d(inpl, planes, 1, stride)
+            self.skip = Conv2d(inpl, planes, 1, stride, bn=True)
             self.skipbn = BatchNorm2d(planes)
         else:
             self.skip = None
@@ -89,9 +89,9 @@ class AlignedXception(nn.Module):
             b3s, mid_d, exit_d = 1, 2, (2, 4)
         else:
             raise NotImplementedError(output_stride)
-        self.conv1 = Conv2d(3, 32, 3, 2, 1)
+        self.conv1 = Conv2d(3, 32, 3, 2, 1, bn=True)
         self.bn1 = BatchNorm2d(32)
-        self.conv2 = Conv2d(32, 64, 3, 1, 1)
+        self.conv2 = Conv2d(32, 64, 3, 1, 1, bn=True)
         self.bn2 = BatchNorm2d(64)
         self.block1 = Block(64, 128, 2, 2, 1, start_with_relu=False)
         self.block2 = Block(128, 256, 2, 2, 1, start_with_relu=False)

@@ -13,8 +13,8 @@ class UNetConvBlock(nn.Module):
     def __init__(self, cin, cout, padding, dropout):
         super().__init__()
         p = int(padding)
-        self.block = Named(_0=Conv2d(cin, cout, 3, 1, p, bias=True, init='torch'), _1=BatchNorm2d(cout),
-                           _3=Conv2d(cout, cout, 3, 1, p, bias=True, init='torch'), _4=BatchNorm2d(cout))
+        self.block = Named(_0=Conv2d(cin, cout, 3, 1, p, bias=True, init='torch', bn=True), _1=BatchNorm2d(cout),
+                           _3=Conv2d(cout, cout, 3, 1, p, bias=True, init='torch', bn=True), _4=BatchNorm2d(cout))
         self.drop = Dropout(dropout or 0.0)
 
     def forward(self, x):

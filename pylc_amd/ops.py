@@ -191,7 +191,7 @@ class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil):
+    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False):
         L.init()
         x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
@@ -218,16 +218,29 @@ class Conv2dFn(torch.autograd.Function):
             ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
                                 4.0 * (b * h * wd * cin + cout * r * s * cin + b * oh * ow * cout))
             ev[0].record()
-        check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
+        sums = None
+        if want_stats:
+            if cout % 4:
+                raise L.PylcError('fused BatchNorm statistics need Cout % 4 == 0')
+            part = torch.empty(lib.pylc_conv2d_fwd_stats_floats(C.byref(d)), device=x.device)
+            rows = C.c_int(0)
+            check(lib.pylc_conv2d_fwd_stats(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), ptr(part), C.byref(rows), stream()))
+            sums = torch.empty(2 * cout + 1, device=x.device)            # [sum | sumsq | count slot for SyncBN]
+            check(lib.pylc_bn_stats_from_partial(ptr(part), rows.value, cout, ptr(sums), stream()))
+        else:
+            check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
         if ev is not None:
             ev[1].record()
         ctx.save_for_backward(x, w_k)
         ctx.geom = (stride, pad, dil, cin_w, bias is not None)
         ctx.w_param, ctx.b_param = w, bias
+        if want_stats:
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
@@ -297,11 +310,17 @@ class Conv2dFn(torch.autograd.Function):
                 db = _deliver_grad(bias, tgt)
             else:
                 db = sums[:cout].clone()
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil)
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
+    """want_stats: also produce the per-channel (sum, sum of squares) of y in the conv epilogue and attach them to the
+    returned tensor as `_pylc_sums` for the BatchNorm that consumes it (ops.bn_act picks them up)."""
+    if want_stats:
+        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True)
+        y._pylc_sums = sums
+        return y
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -368,7 +387,7 @@ class BnActFn(torch.autograd.Function):
     [sum, sumsq, count]); eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None):
         L.init()
         y = as_nhwc(y)
         b, c, h, w = y.shape
@@ -380,9 +399,12 @@ class BnActFn(torch.autograd.Function):
         mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
         n_global = float(m)
         if training:
-            sums = torch.empty(2 * c + 1, device=dev)
-            ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
-            check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
+            if pre_sums is not None and pre_sums.numel() == 2 * c + 1:
+                sums = pre_sums                      # produced by the conv epilogue (ops.conv2d(want_stats=True))
+            else:
+                sums = torch.empty(2 * c + 1, device=dev)
+                ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
+                check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
             if group is not None:
                 sums[2 * c] = float(m)
                 dist.all_reduce(sums, group=group)
@@ -455,12 +477,13 @@ class BnActFn(torch.autograd.Function):
                     dbeta = _deliver_grad(beta, tb)
                 else:
                     dbeta = local_sums[c:].clone()
-        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
            group=None, clamp_eps=False):
-    return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps)
+    pre = getattr(y, '_pylc_sums', None) if training else None
+    return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre)
 
 
 class ReluFn(torch.autograd.Function):

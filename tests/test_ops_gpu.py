@@ -346,3 +346,20 @@ def test_adamw_clip(dev):
         check(lib.pylc_adamw_step(ptr(p), ptr(gs), ptr(m), ptr(v), n, ptr(out2), 1e-4, 0.9, 0.999, 1e-8, 5e-5, step, stream()))
         assert abs(out2[0].item() - norm_ref.item()) < 1e-5 * norm_ref.item()
         assert (p.cpu() - pr.detach()).abs().max().item() < 2e-7
+
+
+@pytest.mark.parametrize('shape', [(64, 128, 3, 1, 2, 30, 26), (4, 64, 7, 2, 2, 40, 40), (256, 256, 1, 1, 8, 64, 64), (128, 48, 1, 1, 3, 17, 9)])
+def test_conv_fused_bn_statistics(dev, shape, conv_mode):
+    """Per-channel (sum, sum of squares) emitted by the conv epilogue == the same reduction over the stored output."""
+    from pylc_amd import ops
+    cin, cout, k, stride, b, h, w = shape
+    x = rnd(61, b, cin, h, w)
+    wt = rnd(62, cout, cin if cin != 4 else 3, k, k, scale=0.1)
+    xd = to_dev_nhwc(x, dev) if cin != 4 else ops.pack_nchw(x[:, :3].to(dev), 4)
+    y = ops.conv2d(xd, to_dev_nhwc(wt, dev), None, stride, k // 2, 1, want_stats=True)
+    sums = y._pylc_sums
+    yd = y.double()
+    ref_s, ref_ss = yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))
+    assert rel_err(sums[:cout], ref_s) < 1e-5 and rel_err(sums[cout:2 * cout], ref_ss) < 1e-5
+    plain = ops.conv2d(xd, to_dev_nhwc(wt, dev), None, stride, k // 2, 1)
+    assert torch.equal(plain, y)
