@@ -398,6 +398,9 @@ class BnActFn(torch.autograd.Function):
         coef = torch.empty(4 * c, device=dev)            # mean | invstd | scale | shift
         mean, invstd, scale, shift = coef[:c], coef[c:2 * c], coef[2 * c:3 * c], coef[3 * c:]
         n_global = float(m)
+        if training and m == 1 and group is None:
+            # torch.nn.BatchNorm2d's behaviour (the ASPP image-pool branch normalises over the batch only: B must be > 1)
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(y.shape),))
         if training:
             if pre_sums is not None and pre_sums.numel() == 2 * c + 1:
                 sums = pre_sums                      # produced by the conv epilogue (ops.conv2d(want_stats=True))

@@ -208,3 +208,27 @@ def test_epoch_driver_matches_reference(dev, tmp_path):
     assert [round(v[1], 12) for v in model.loss.lr] == [round(v[1], 12) for v in g['lr']]
     d = os.path.join(str(tmp_path), model.model_id())
     assert sorted(os.listdir(d)) == ['checkpoint.pth', model.model_id() + '.pth']
+
+
+def test_ragged_tile_sizes_and_batch_one(dev):
+    """Non-square, odd-sized tiles (no reference fixture: checked against the CPU oracle), and batch size 1."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import runtime
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    runtime.dropout_enabled = False
+    cfg = ostep.StepConfig('deeplab', 'resnet', 9, 3, dropout=False)
+    x = D.tiles(77, 2, 3, 83, 107)
+    w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=8), cfg, x.clone())
+    want = ostep.test_step({k: v.clone() for k, v in w.items()}, cfg, x.clone())
+    model = Model(Meta(), dev).build()
+    model.net.load_state_dict(w)
+    model.net.eval()
+    got = model.test(x)[0].float().cpu()
+    assert tuple(got.shape) == (2, 9, 83, 107)
+    assert (got - want).abs().max().item() < LOGIT_TOL
+    one = model.test(x[:1])[0]                           # eval mode works at batch 1
+    assert (one.float().cpu() - ostep.test_step({k: v.clone() for k, v in w.items()}, cfg, x[:1].clone())).abs().max().item() < LOGIT_TOL
+    with pytest.raises(ValueError):                      # training at batch 1: the image-pool BatchNorm has one value per channel
+        model.train(x[:1], D.blob_masks(78, 1, 83, 107, 9))
