@@ -53,15 +53,35 @@ typedef struct PylcConvDesc {
     int OH, OW;             /* output height / width = floor((H + 2*pad - dil*(R-1) - 1)/stride) + 1 */
     int x_pitch;            /* floats between input pixels  (>= Cin)                          */
     int y_pitch;            /* floats between output pixels (>= Cout)                         */
+    /* Operand ranges, used by conv precision mode 2 only (ignored otherwise, may be NULL): DEVICE scalars holding
+     * the IEEE bit pattern of a float >= max|element| of x / the weights / dy (pylc_amax produces them; any upper
+     * bound within a few binades of the true maximum is as good).  fwd reads x_amax and w_amax, dgrad dy_amax and
+     * w_amax, wgrad dy_amax and x_amax. */
+    const unsigned int* x_amax;
+    const unsigned int* w_amax;
+    const unsigned int* dy_amax;
 } PylcConvDesc;
 
 /* Arithmetic of the dense conv kernels (process-wide):
  *   0 = v_mfma_f32_32x32x2_f32: bit-exact fp32 fmaf chain, 157 TFLOP/s matrix peak;
  *   1 = "bf16x6" (default): each fp32 operand is split exactly into three bf16 pieces in LDS and every product is
  *       formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-grade
- *       accuracy (error <= the fp32 chain's, tests/test_ops_gpu.py::test_conv_precision_modes) at 16/6 the rate. */
+ *       accuracy (error <= the fp32 chain's, tests/test_ops_gpu.py::test_conv_precision_modes) at 16/6 the rate;
+ *   2 = "f16x3": each fp32 operand is scaled by an exact power of two taken from the tensor's max magnitude
+ *       (PylcConvDesc.*_amax) and split into two fp16 pieces h0 = rn(s*x), h1 = rn(2^11 (s*x - h0)); a product is
+ *       a0b0 + 2^-11 (a1b0 + a0b1) on v_mfma_f32_32x32x16_f16, the cross terms in their own fp32 accumulator (the
+ *       single-precision-recovery scheme of Ootomo & Yokota, IJHPCA 2022, moved to CDNA4).  Operand error <= 2^-23 |x|
+ *       for every element within 2^29 of the tensor maximum (fp16 subnormals are honoured by the MFMA, measured), the
+ *       dropped a1b1 term <= 2^-22 |ab|; measured error vs fp64 is below the fp32 chain's.  3 MFMAs instead of 6. */
 int pylc_set_conv_precision(int mode);
 int pylc_get_conv_precision(void);
+
+/* out_bits[0] = IEEE bits of max|x[r*pitch + c]| over r < rows, c < roundup4(cols) when that fits the pitch (else
+ * c < cols): the operand range for precision mode 2.  pylc_amax_segments does the same for `count` contiguous
+ * segments base[offsets[s] .. offsets[s+1]) in one launch (all parameters of a flat arena); offsets is a DEVICE
+ * array of count+1 entries. */
+int pylc_amax(const float* x, long long rows, int cols, int pitch, unsigned int* out_bits, void* stream);
+int pylc_amax_segments(const float* base, const long long* offsets, int count, unsigned int* out_bits, void* stream);
 
 /* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */

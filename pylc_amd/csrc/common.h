@@ -51,6 +51,18 @@ __device__ inline float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Fold this thread's running max |value| into the device scalar `out` (float bit pattern, compared as unsigned: valid
+// for non-negative floats).  Max is order-independent, so the atomics keep the result deterministic; the plain read
+// first skips the atomic once the stored bound is already large enough.
+__device__ inline void amax_commit(float m, unsigned* out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
+
 // out[c] = sum_r partial[r][c] for r < nrows, accumulated in fp64 in a fixed order (deterministic).
 // Launch with 256 threads and grid = cdiv(ncols, 8): 8 columns x 32 row lanes per block.
 __global__ __launch_bounds__(256) static void column_sum_kernel(const float* __restrict__ partial, int nrows, int ncols,

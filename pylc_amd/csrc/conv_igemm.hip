@@ -25,6 +25,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int LDB = 80;   // bf16x6 mode: bytes per LDS row per plane (32 bf16 = 64 B + 16 B pad)
 
 // Exact 3-way split of four fp32 values into bf16 planes by truncation: x = x0 + x1 + x2, each piece the top 16 bits of
@@ -46,6 +50,26 @@ __device__ __forceinline__ void split3(const float (&x)[4], uint2& p0, uint2& p1
 __device__ __forceinline__ void split3(const float __attribute__((ext_vector_type(4))) v, uint2& p0, uint2& p1, uint2& p2) {
     const float x[4] = {v.x, v.y, v.z, v.w};
     split3(x, p0, p1, p2);
+}
+
+// 2-way fp16 split of four scaled fp32 values: h0 = rn16(s*x), h1 = rn16(s*x - h0); s*x = h0 + h1 up to 2^-22 |s*x|
+// (absolute floor 2^-25: fp16 subnormals).  s is a power of two chosen from the tensor's max magnitude, so s*x is exact.
+__device__ __forceinline__ void split2(const f32x4 v, float s, uint2& p0, uint2& p1) {
+    const f32x2 lo = {v.x * s, v.y * s}, hi = {v.z * s, v.w * s};
+    const f16x2 l0 = __builtin_convertvector(lo, f16x2), h0 = __builtin_convertvector(hi, f16x2);
+    const f16x2 l1 = __builtin_convertvector((lo - __builtin_convertvector(l0, f32x2)) * 2048.f, f16x2);
+    const f16x2 h1 = __builtin_convertvector((hi - __builtin_convertvector(h0, f32x2)) * 2048.f, f16x2);
+    p0.x = __builtin_bit_cast(unsigned, l0); p0.y = __builtin_bit_cast(unsigned, h0);
+    p1.x = __builtin_bit_cast(unsigned, l1); p1.y = __builtin_bit_cast(unsigned, h1);
+}
+
+// power-of-two scale that maps a tensor with max magnitude `amax` (given as float bits) into [2^14, 2^15): exact to apply
+// and to undo, keeps the fp16 pieces clear of overflow with the low piece inside the (sub)normal range for 40 binades.
+__device__ __forceinline__ float pow2_scale_for(unsigned amax_bits) {
+    int e = (int)((amax_bits >> 23) & 0xFFu);                  // biased exponent of amax (0: zero / denormal)
+    int se = 127 + 14 - (e - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
 }
 
 constexpr int BK = 32;    // reduction depth per LDS stage
@@ -73,6 +97,8 @@ struct GatherGemmArgs {
     int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
     int accumulate;
     int tiles_n;
+    const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
+    const unsigned* amax_w;
     float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)
 };
 
@@ -136,15 +162,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
     const int S = ntaps * nchunks;
 
     f32x16 acc[MT][NT];
+    f32x16 acc_lo[PREC == 2 ? MT : 1][PREC == 2 ? NT : 1];      // PREC 2: the two cross terms, carried at 2^11 x their value
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (PREC == 2) acc_lo[i][j][r] = 0.f;
+            }
 
     f32x4 ra[A_IT], rb[B_IT];
-    f32x4 ra2[PREC == 1 ? A_IT : 1], rb2[PREC == 1 ? B_IT : 1];     // second in-flight tile (bf16x6: prefetch distance 2)
+    float scale_a = 1.f, scale_b = 1.f;                              // PREC 2: power-of-two operand scales
+    f32x4 ra2[PREC != 0 ? A_IT : 1], rb2[PREC != 0 ? B_IT : 1];     // second in-flight tile (bf16x6: prefetch distance 2)
     int ld_tap = -1, ld_chunk = nchunks - 1;     // position of the NEXT tile to load (advanced before use)
 
     auto advance = [&]() {
@@ -239,28 +270,41 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
             }
         }
     } else {
-        // single LDS stage of three bf16 planes per operand; rows padded to 80 B -> conflict-free ds_read_b128
+        // single LDS stage of NPL 16-bit planes per operand; rows padded to 80 B -> conflict-free ds_read_b128
+        constexpr int NPL = PREC == 2 ? 2 : 3;
         char* lds = reinterpret_cast<char*>(smem);
         char* pA0 = lds;                               // plane p of A at pA0 + p * BM * LDB
-        char* pB0 = lds + 3 * BM * LDB;                // plane p of B at pB0 + p * BN * LDB
+        char* pB0 = lds + NPL * BM * LDB;              // plane p of B at pB0 + p * BN * LDB
+        if constexpr (PREC == 2) {
+            scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
+            scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
+        }
         auto store_tile_from = [&](const f32x4* xa, const f32x4* xb) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                uint2 q0, q1, q2;
-                split3(xa[i], q0, q1, q2);
                 char* d = pA0 + (r0 + RPI * i) * LDB + 8 * v;
+                uint2 q0, q1, q2;
+                if constexpr (PREC == 2) {
+                    split2(xa[i], scale_a, q0, q1);
+                } else {
+                    split3(xa[i], q0, q1, q2);
+                    *reinterpret_cast<uint2*>(d + 2 * BM * LDB) = q2;
+                }
                 *reinterpret_cast<uint2*>(d) = q0;
                 *reinterpret_cast<uint2*>(d + BM * LDB) = q1;
-                *reinterpret_cast<uint2*>(d + 2 * BM * LDB) = q2;
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                uint2 q0, q1, q2;
-                split3(xb[i], q0, q1, q2);
                 char* d = pB0 + (r0 + RPI * i) * LDB + 8 * v;
+                uint2 q0, q1, q2;
+                if constexpr (PREC == 2) {
+                    split2(xb[i], scale_b, q0, q1);
+                } else {
+                    split3(xb[i], q0, q1, q2);
+                    *reinterpret_cast<uint2*>(d + 2 * BN * LDB) = q2;
+                }
                 *reinterpret_cast<uint2*>(d) = q0;
                 *reinterpret_cast<uint2*>(d + BN * LDB) = q1;
-                *reinterpret_cast<uint2*>(d + 2 * BN * LDB) = q2;
             }
         };
         const char* ra_base = pA0 + (wave_m * WM + (lane & 31)) * LDB + 16 * (lane >> 5);
@@ -268,21 +312,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         auto compute = [&]() {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[MT][3], fb[NT][3];
+                bf16x8 fa[MT][NPL], fb[NT][NPL];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         fa[i][pl] = *reinterpret_cast<const bf16x8*>(ra_base + pl * BM * LDB + i * 32 * LDB + 32 * ks);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         fb[j][pl] = *reinterpret_cast<const bf16x8*>(rb_base + pl * BN * LDB + j * 32 * LDB + 32 * ks);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
+                        if constexpr (PREC == 2) {
+                            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[i][0]), a1 = __builtin_bit_cast(f16x8, fa[i][1]);
+                            const f16x8 b0 = __builtin_bit_cast(f16x8, fb[j][0]), b1 = __builtin_bit_cast(f16x8, fb[j][1]);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+                            continue;
+                        }
                         // smallest terms first
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
@@ -296,8 +348,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         if (S > 0) {
             // two register sets: the global loads of tile s+2 are issued before the MFMAs of tile s, so every load has
             // a full step (>= 1536 matrix-pipe cycles plus the partner block's step) to land before it is consumed
+            constexpr bool ONE_SET = PREC == 2 && BM == 256 && BN == 64;    // 128 accumulator registers + 8 A vectors per set: one set fits
             advance();
             load_tile_into(ra, rb);
+            if constexpr (ONE_SET) {
+                for (int s = 0; s < S; ++s) {
+                    if (s > 0) __syncthreads();
+                    store_tile_from(ra, rb);
+                    __syncthreads();
+                    if (s + 1 < S) { advance(); load_tile_into(ra, rb); }
+                    compute();
+                }
+            } else {
             if (S > 1) { advance(); load_tile_into(ra2, rb2); }
             for (int s = 0; s < S; s += 2) {
                 if (s > 0) __syncthreads();      // every wave has finished reading the previous tile
@@ -312,6 +374,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                     if (s + 3 < S) { advance(); load_tile_into(ra2, rb2); }
                     compute();
                 }
+            }
             }
             __syncthreads();                     // LDS is reused for the epilogue's row table
         }
@@ -334,6 +397,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
     // values just computed cost 2 FMAs per element here instead of a separate full read of y
     float* sred = reinterpret_cast<float*>(smem) + 1024;          // [BM/WM][BN][2], past the row table
     const bool do_stats = a.stats != nullptr;
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;     // exact (powers of two); applied one after the other
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
@@ -347,7 +411,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                 const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const long long off = rowoff[row];
                 if (nok && off >= 0) {
-                    float val = acc[i][j][r] + bv;
+                    float val = acc[i][j][r];
+                    if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                    val += bv;
                     float* dst = a.y + off + n;
                     if (a.accumulate) val += *dst;
                     *dst = val;
@@ -397,6 +463,8 @@ struct WgradArgs {
     int tiles_n, tiles_c;   // tiles over cout / (cin or taps*4)
     int splits, m_per_split;
     long long slab_stride;
+    const unsigned* amax_dy;   // f16x3: device scalars with the float bits of max|dy| and max|x|
+    const unsigned* amax_x;
 };
 
 template <int BN, int BC, int WN, int WC, bool CIN4>
@@ -541,8 +609,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BN, int BC, int WN, int WC, bool CIN4>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a) {
+template <int BN, int BC, int WN, int WC, bool CIN4, int PREC>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) {
+    constexpr int NPL = PREC == 2 ? 2 : 3;
     constexpr int WAVES_C = BC / WC;
     constexpr int NT = WN / 32, CT = WC / 32;
     constexpr int VA = BN / 4, RA = 256 / VA, IA = 32 / RA;
@@ -551,8 +620,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
     constexpr int PLA = 32 * ROWA, PLB = 32 * ROWB;          // bytes per plane
     static_assert((BN / WN) * (BC / WC) == 4, "4 waves per block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* sA = reinterpret_cast<char*>(smem);               // 3 planes of dy
-    char* sB = sA + 3 * PLA;                                 // 3 planes of gathered x
+    char* sA = reinterpret_cast<char*>(smem);               // NPL planes of dy
+    char* sB = sA + NPL * PLA;                               // NPL planes of gathered x
 
     const int T = a.TR * a.TS;
     int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -584,12 +653,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
     const bool a_col_ok = n0 + 4 * va < a.N_ld;
 
     f32x16 acc[NT][CT];
+    f32x16 acc_lo[PREC == 2 ? NT : 1][PREC == 2 ? CT : 1];     // f16x3: the two cross terms, carried at 2^11 x their value
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (PREC == 2) acc_lo[i][j][r] = 0.f;
+            }
+    float scale_a = 1.f, scale_b = 1.f;
+    if constexpr (PREC == 2) {
+        scale_a = a.amax_dy ? pow2_scale_for(*a.amax_dy) : 1.f;
+        scale_b = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
+    }
 
     f32x4 ra[IA], rb[IB];
     auto load_tile = [&](int s) {
@@ -617,21 +695,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            uint2 q0, q1, q2;
-            split3(ra[i], q0, q1, q2);
             char* d = sA + (pra + RA * i) * ROWA + 8 * va;
+            uint2 q0, q1, q2;
+            if constexpr (PREC == 2) {
+                split2(ra[i], scale_a, q0, q1);
+            } else {
+                split3(ra[i], q0, q1, q2);
+                *reinterpret_cast<uint2*>(d + 2 * PLA) = q2;
+            }
             *reinterpret_cast<uint2*>(d) = q0;
             *reinterpret_cast<uint2*>(d + PLA) = q1;
-            *reinterpret_cast<uint2*>(d + 2 * PLA) = q2;
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            uint2 q0, q1, q2;
-            split3(rb[i], q0, q1, q2);
             char* d = sB + (prb + RB * i) * ROWB + 8 * vb;
+            uint2 q0, q1, q2;
+            if constexpr (PREC == 2) {
+                split2(rb[i], scale_b, q0, q1);
+            } else {
+                split3(rb[i], q0, q1, q2);
+                *reinterpret_cast<uint2*>(d + 2 * PLB) = q2;
+            }
             *reinterpret_cast<uint2*>(d) = q0;
             *reinterpret_cast<uint2*>(d + PLB) = q1;
-            *reinterpret_cast<uint2*>(d + 2 * PLB) = q2;
         }
     };
     // transpose-read addressing: group g = lane>>4 covers channels 16*(g&1).., reduction half h = g>>1
@@ -648,19 +734,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
             if (s + 1 < S) load_tile(s + 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[NT][3], fb[CT][3];
+                bf16x8 fa[NT][NPL], fb[CT][NPL];
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
+                    for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
 #pragma unroll
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
+                    for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int j = 0; j < CT; ++j) {
+                        if constexpr (PREC == 2) {
+                            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[i][0]), a1 = __builtin_bit_cast(f16x8, fa[i][1]);
+                            const f16x8 b0 = __builtin_bit_cast(f16x8, fb[j][0]), b1 = __builtin_bit_cast(f16x8, fb[j][1]);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+                            continue;
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
@@ -672,6 +766,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
         }
     }
 
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
     float* out = a.out + (size_t)split * a.slab_stride;
     const int col_limit = CIN4 ? T * 4 : a.Cin;
     const int col_base = CIN4 ? 0 : tap * a.Cin;
@@ -684,7 +779,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x6_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wave_n * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = acc[i][j][r];
+                float val = acc[i][j][r];
+                if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = val;
             }
         }
     }
@@ -723,12 +820,12 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 // -------------------------------------------------------------------------------------------------
 template <int BM, int BN, int PREC>
 constexpr size_t gg_smem() {
-    return PREC == 0 ? (size_t)2 * (BM + BN) * LDT * sizeof(float) : (size_t)3 * (BM + BN) * LDB;
+    return PREC == 0 ? (size_t)2 * (BM + BN) * LDT * sizeof(float) : (size_t)(PREC == 2 ? 2 : 3) * (BM + BN) * LDB;
 }
 template <int BN, int BC>
 constexpr size_t wg_smem() { return (size_t)2 * 32 * (BN + BC) * sizeof(float); }
-template <int BN, int BC>
-constexpr size_t wg16_smem() { return (size_t)3 * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
+template <int BN, int BC, int PREC>
+constexpr size_t wg16_smem() { return (size_t)(PREC == 2 ? 2 : 3) * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
 
 int g_big_tile = 1;
 int g_conv_precision = 1;      // 0 = fp32 MFMA, 1 = bf16x6 (default); see pylc_set_conv_precision
@@ -757,13 +854,13 @@ static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     }
     if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false, PREC>(a, st);
     if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false, PREC>(a, st);
-    if (PREC == 1 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192)
+    if (PREC != 0 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192)
         return launch_gg<256, 128, 64, 64, false, PREC>(a, st);      // 8 waves: halves LDS-write bytes per MFMA
     return launch_gg<128, 128, 64, 64, false, PREC>(a, st);
 }
 
 static int dispatch_gg(GatherGemmArgs& a, bool cin4, hipStream_t st) {
-    return g_conv_precision == 0 ? dispatch_gg_p<0>(a, cin4, st) : dispatch_gg_p<1>(a, cin4, st);
+    return g_conv_precision == 0 ? dispatch_gg_p<0>(a, cin4, st) : g_conv_precision == 2 ? dispatch_gg_p<2>(a, cin4, st) : dispatch_gg_p<1>(a, cin4, st);
 }
 
 template <typename K>
@@ -776,20 +873,27 @@ int conv_init() {
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 0>, gg_smem<BM, BN, 0>()));                  \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 1>, gg_smem<BM, BN, 1>()));                 \
-    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 1>, gg_smem<BM, BN, 1>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 1>, gg_smem<BM, BN, 1>()));                  \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 2>, gg_smem<BM, BN, 2>()));                 \
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 2>, gg_smem<BM, BN, 2>()));
     PYLC_OPT_GG(128, 128, 64, 64)
     PYLC_OPT_GG(256, 64, 64, 64)
     PYLC_OPT_GG(128, 32, 32, 32)
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, true>, wg_smem<64, 64>()));
-    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<128, 128, 64, 64, false>, wg16_smem<128, 128>()));
-    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<64, 64, 32, 32, false>, wg16_smem<64, 64>()));
-    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<32, 128, 32, 32, false>, wg16_smem<32, 128>()));
-    PYLC_HIP(opt_in_lds(wgrad_bf16x6_kernel<64, 64, 32, 32, true>, wg16_smem<64, 64>()));
+#define PYLC_OPT_WG(P)                                                                                                \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P>, wg16_smem<128, 128, P>()));                 \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P>, wg16_smem<64, 64, P>()));                     \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P>, wg16_smem<32, 128, P>()));                   \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, true, P>, wg16_smem<64, 64, P>()));
+    PYLC_OPT_WG(1)
+    PYLC_OPT_WG(2)
+#undef PYLC_OPT_WG
     return PYLC_OK;
 }
 
@@ -817,7 +921,7 @@ static inline int roundup4(int v) { return (v + 3) & ~3; }
 using namespace pylc;
 
 extern "C" int pylc_set_conv_precision(int mode) {
-    PYLC_REQUIRE(mode == 0 || mode == 1, "conv precision mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+    PYLC_REQUIRE(mode >= 0 && mode <= 2, "conv precision mode must be 0 (fp32 MFMA), 1 (bf16x6) or 2 (f16x3)");
     g_conv_precision = mode;
     return PYLC_OK;
 }
@@ -852,6 +956,8 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     PYLC_REQUIRE(x && w && y, "null pointer");
     GatherGemmArgs a{};
     a.stats = stats;
+    PYLC_REQUIRE(g_conv_precision != 2 || (d->x_amax && d->w_amax), "f16x3 mode: conv2d_fwd needs x_amax and w_amax in the descriptor");
+    a.amax_x = d->x_amax; a.amax_w = d->w_amax;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
     a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
@@ -875,6 +981,8 @@ extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const f
     const int Kp = roundup4(d->Cout);       // reduction runs over output channels, padded to 4 (zero weights / zero dy)
     PYLC_REQUIRE(Kp <= d->y_pitch, "dy pitch %d must cover roundup4(Cout)=%d", d->y_pitch, Kp);
     GatherGemmArgs a{};
+    PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->w_amax), "f16x3 mode: conv2d_dgrad needs dy_amax and w_amax in the descriptor");
+    a.amax_x = d->dy_amax; a.amax_w = d->w_amax;
     a.x = dy; a.w = w_crsk; a.bias = nullptr; a.y = dx;
     a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
     a.N = d->Cin; a.N_store = d->Cin;
@@ -975,8 +1083,14 @@ template <int BN, int BC, int WN, int WC, bool CIN4>
 static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
     if (g_conv_precision == 1) {
-        const size_t lds16 = wg16_smem<BN, BC>();
-        hipLaunchKernelGGL((wgrad_bf16x6_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        const size_t lds16 = wg16_smem<BN, BC, 1>();
+        hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
+    if (g_conv_precision == 2) {
+        const size_t lds16 = wg16_smem<BN, BC, 2>();
+        hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2>), dim3((unsigned)grid), dim3(256), lds16, st, a);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }
@@ -1008,6 +1122,8 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     a.out_row_stride = T * d->Cin;
     a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c; a.splits = p.splits; a.m_per_split = p.m_per_split;
     a.slab_stride = p.slab;
+    PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->x_amax), "f16x3 mode: conv2d_wgrad needs dy_amax and x_amax in the descriptor");
+    a.amax_dy = d->dy_amax; a.amax_x = d->x_amax;
     const long long grid = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T) * p.splits;
     int rc;
     switch (p.cfg) {

@@ -1,0 +1,72 @@
+// Operand ranges for the f16x3 conv arithmetic (conv precision mode 2): max |element| of a tensor as a device scalar.
+// The conv kernels derive an exact power-of-two scale from it (conv_igemm.hip: pow2_scale_for), so the value only has
+// to be an upper bound within a few binades of the true maximum.
+#include "common.h"
+
+namespace pylc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void amax_rows_kernel(const float* __restrict__ x, long long rows, int cols4, int pitch,
+                                                         unsigned* __restrict__ out) {
+    // cols4 float4 columns per row; consecutive threads walk consecutive float4s of the flattened (row, col4) space
+    const long long total = rows * cols4;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * pitch + 4 * c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    amax_commit(m, out);
+}
+
+__global__ __launch_bounds__(256) void amax_flat_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    amax_commit(m, out);
+}
+
+// one row of blocks per segment: segment s = base[offsets[s] .. offsets[s+1])
+__global__ __launch_bounds__(256) void amax_segments_kernel(const float* __restrict__ base, const long long* __restrict__ offsets,
+                                                             unsigned* __restrict__ out) {
+    const int s = blockIdx.x;
+    const long long b = offsets[s], e = offsets[s + 1];
+    float m = 0.f;
+    for (long long i = b + (long long)blockIdx.y * 256 + threadIdx.x; i < e; i += (long long)gridDim.y * 256) m = fmaxf(m, fabsf(base[i]));
+    amax_commit(m, out + s);
+}
+
+}  // namespace pylc
+
+using namespace pylc;
+
+extern "C" int pylc_amax(const float* x, long long rows, int cols, int pitch, unsigned int* out_bits, void* stream) {
+    PYLC_REQUIRE(x && out_bits, "amax: null pointer");
+    PYLC_REQUIRE(rows > 0 && cols > 0 && pitch >= cols, "amax: bad shape rows=%lld cols=%d pitch=%d", rows, cols, pitch);
+    hipStream_t st = as_stream(stream);
+    PYLC_HIP(hipMemsetAsync(out_bits, 0, sizeof(unsigned), st));
+    const int c4 = (cols + 3) & ~3;
+    if (pitch % 4 == 0 && c4 <= pitch && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // pad channels inside the pitch belong to the same buffer (zeros, or a neighbouring concat slice: still a bound)
+        const long long total = rows * (c4 / 4);
+        const int blocks = (int)(cdiv<long long>(total, 256 * 4) < 2048 ? cdiv<long long>(total, 256 * 4) : 2048);
+        hipLaunchKernelGGL(amax_rows_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, rows, c4 / 4, pitch, out_bits);
+    } else {
+        PYLC_REQUIRE(pitch == cols, "amax: a pitched tensor needs a 16-byte aligned base and pitch %% 4 == 0");
+        const long long n = rows * cols;
+        const int blocks = (int)(cdiv<long long>(n, 256 * 8) < 2048 ? cdiv<long long>(n, 256 * 8) : 2048);
+        hipLaunchKernelGGL(amax_flat_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, n, out_bits);
+    }
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_amax_segments(const float* base, const long long* offsets, int count, unsigned int* out_bits, void* stream) {
+    PYLC_REQUIRE(base && offsets && out_bits && count > 0, "amax_segments: bad arguments");
+    hipStream_t st = as_stream(stream);
+    PYLC_HIP(hipMemsetAsync(out_bits, 0, sizeof(unsigned) * (size_t)count, st));
+    hipLaunchKernelGGL(amax_segments_kernel, dim3((unsigned)count, 16), dim3(256), 0, st, base, offsets, out_bits);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PylcError(RuntimeError):
@@ -20,7 +20,8 @@ class PylcError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'dil',
-                                       'OH', 'OW', 'x_pitch', 'y_pitch')]
+                                       'OH', 'OW', 'x_pitch', 'y_pitch')] + \
+               [(n, C.c_void_p) for n in ('x_amax', 'w_amax', 'dy_amax')]     # operand ranges (precision mode 2)
 
 
 class DwDesc(C.Structure):
@@ -41,6 +42,8 @@ SIGNATURES = {
     'pylc_init': (_I, []),
     'pylc_set_conv_precision': (_I, [_I]),
     'pylc_get_conv_precision': (_I, []),
+    'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
+    'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     'pylc_conv2d_fwd_stats_floats': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd_stats': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(_I), _P]),
@@ -117,6 +120,9 @@ def init():
     global _initialised
     if not _initialised:
         check(lib.pylc_init())
+        mode = os.environ.get('PYLC_CONV_PRECISION')
+        if mode is not None:
+            check(lib.pylc_set_conv_precision(int(mode)))
         _initialised = True
 
 

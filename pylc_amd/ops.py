@@ -187,11 +187,48 @@ def _deliver_grad(param, g):
     return g
 
 
+def ranges_needed():
+    """True when the conv kernels run the f16x3 arithmetic (precision mode 2), which scales every operand by a power of
+    two taken from its max magnitude."""
+    return lib.pylc_get_conv_precision() == 2
+
+
+def tag_amax(t, amax):
+    """Attach a device scalar holding (the float bits of) an upper bound of max|t| to `t`; trusted only while the
+    tensor's version counter is unchanged (in-place autograd accumulation bumps it)."""
+    t._pylc_amax = (amax, t._version)
+
+
+def amax_of(t):
+    """Device int32[1] with the float bits of max|t| for an NHWC activation / gradient: the producer's tag when one is
+    attached and still valid, else one read pass over the tensor."""
+    tag = getattr(t, '_pylc_amax', None)
+    if tag is not None and tag[1] == t._version:
+        return tag[0]
+    t = as_nhwc(t)
+    b, c, h, w = t.shape
+    out = torch.empty(1, dtype=torch.int32, device=t.device)
+    check(lib.pylc_amax(ptr(t), b * h * w, c, pitch_of(t), ptr(out), stream()))
+    tag_amax(t, out)
+    return out
+
+
+def weight_amax(w):
+    """Range of a conv filter: the flat arena's per-parameter table when the parameter lives in one (refreshed by
+    FlatArena.refresh_ranges), else computed here."""
+    tab = getattr(w, '_pylc_wamax', None)
+    if tab is not None:
+        return tab
+    out = torch.empty(1, dtype=torch.int32, device=w.device)
+    check(lib.pylc_amax(ptr(w), 1, w.numel(), w.numel(), ptr(out), stream()))
+    return out
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False):
+    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None):
         L.init()
         x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
@@ -213,6 +250,8 @@ class Conv2dFn(torch.autograd.Function):
         yp = _r4(cout)
         y = empty_nhwc(b, cout, oh, ow, x.device, yp)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
+        d.x_amax, d.w_amax = ptr(x_amax), ptr(w_amax)
+        ctx.ranges = (x_amax, w_amax)
         ev = None
         if _timer is not None and _is_dominant_tile(b * oh * ow, yp, cin, r * s):
             ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
@@ -253,6 +292,13 @@ class Conv2dFn(torch.autograd.Function):
             t.copy_(dy)
             dy, yp = t, _r4(cout)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, pitch_of(x), yp)
+        x_amax, w_amax = ctx.ranges
+        dy_amax = None
+        if ranges_needed():
+            if x_amax is None or w_amax is None:
+                raise L.PylcError('conv backward in f16x3 mode, but the forward ran without operand ranges')
+            dy_amax = amax_of(dy)
+            d.x_amax, d.w_amax, d.dy_amax = ptr(x_amax), ptr(w_amax), ptr(dy_amax)
         st = stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -282,6 +328,9 @@ class Conv2dFn(torch.autograd.Function):
                 x.record_stream(side)
                 dy.record_stream(side)
                 w_k.record_stream(side)
+                if dy_amax is not None:
+                    dy_amax.record_stream(side)
+                    x_amax.record_stream(side)
             with torch.cuda.stream(side) if side is not None else _nullcontext():
                 sst = stream()
                 nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
@@ -310,17 +359,21 @@ class Conv2dFn(torch.autograd.Function):
                 db = _deliver_grad(bias, tgt)
             else:
                 db = sums[:cout].clone()
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
     """want_stats: also produce the per-channel (sum, sum of squares) of y in the conv epilogue and attach them to the
     returned tensor as `_pylc_sums` for the BatchNorm that consumes it (ops.bn_act picks them up)."""
+    xa = wa = None
+    if ranges_needed():
+        L.init()
+        xa, wa = amax_of(x), weight_amax(w)
     if want_stats:
-        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True)
+        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa)
         y._pylc_sums = sums
         return y
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False)
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa)
 
 
 # ----------------------------------------------------------------------------------------------

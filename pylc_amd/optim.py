@@ -41,6 +41,20 @@ class FlatArena:
             p.data = dst
             p._pylc_grad = torch.as_strided(self.g, p.shape, p.stride(), o)
             p.grad = p._pylc_grad
+        # per-parameter max magnitude (float bits), the filter range of the f16x3 conv arithmetic: one launch refreshes all
+        self.amax = torch.zeros(len(params), dtype=torch.int32, device=dev)
+        self._segments = torch.tensor(offs + [total], dtype=torch.int64, device=dev)
+        for i, p in enumerate(params):
+            p._pylc_wamax = self.amax[i:i + 1]
+        module.register_load_state_dict_post_hook(lambda *_: self.refresh_ranges())
+        self.refresh_ranges()
+
+    def refresh_ranges(self):
+        """Recompute every parameter's max magnitude.  Call after anything that changes parameter values (the optimiser
+        steps here do; Model refreshes at the start of each step as well)."""
+        if self.p.is_cuda:
+            L.init()
+            check(lib.pylc_amax_segments(ptr(self.p), ptr(self._segments), len(self.params), ptr(self.amax), stream()))
 
     def zero_grad(self):
         self.g.zero_()
@@ -89,6 +103,7 @@ class FlatAdamW(_FlatOptimizer):
         self.steps += 1
         check(lib.pylc_adamw_step(ptr(a.p), ptr(a.g), ptr(self.m), ptr(self.v), a.numel, ptr(coef), self.lr,
                                   self.betas[0], self.betas[1], self.eps, self.wd, self.steps, stream()))
+        a.refresh_ranges()
 
     def state_dict(self):
         return {'kind': 'flat_adamw', 'steps': self.steps, 'lr': self.lr, 'm': self.m, 'v': self.v}
@@ -112,6 +127,7 @@ class FlatSGD(_FlatOptimizer):
         coef = self._clip()
         self.steps += 1
         check(lib.pylc_sgd_step(ptr(a.p), ptr(a.g), ptr(self.buf), a.numel, ptr(coef), self.lr, self.momentum, self.steps, stream()))
+        a.refresh_ranges()
 
     def state_dict(self):
         return {'kind': 'flat_sgd', 'steps': self.steps, 'lr': self.lr, 'buf': self.buf}

@@ -322,8 +322,14 @@ def golden_driver(out_dir):
     print('  train entries %s, valid entries %s, max|diff| vs oracle driver %.3g, best events %s' % ([r[0] for r in rt], [r[0] for r in rv], err, best))
     assert err < 1e-3 and best == log.best_events
     assert abs(ref.get_lr() - 1e-4 * 0.9 ** n_epochs) < 1e-12
+    # conditioning of the 6-step trajectory: the same (bit-pinned) algorithm with a different fp32 summation order
+    torch.set_num_threads(1)
+    log1 = oracle.run_training({k: v.clone() for k, v in w.items()}, cfg, tr, va, n_epochs, report=report)
+    torch.set_num_threads(8)
+    cond = max(abs(a - b) for A, B in ((log1.train, log.train), (log1.valid, log.valid)) for ra, rb in zip(A, B) for a, b in zip(ra, rb))
+    print('  conditioning (1 thread vs 8 threads, same algorithm): max|diff| %.3g' % cond)
     with open(os.path.join(out_dir, 'driver.json'), 'w') as fh:
-        json.dump({'train': rt, 'valid': rv, 'best_events': best, 'best_dice': float(ref.loss.best_dice),
+        json.dump({'train': rt, 'valid': rv, 'best_events': best, 'best_dice': float(ref.loss.best_dice), 'conditioning': cond,
                    'lr': f(ref.loss.lr), 'final_lr': ref.get_lr(),
                    'config': {'n_classes': n_cls, 'b': b, 'hw': hw, 'n_epochs': n_epochs, 'report': report, 'weight_salt': 6,
                               'train_seeds': [700, 701, 702], 'valid_seeds': [800, 801]}}, fh)

@@ -199,11 +199,15 @@ def test_epoch_driver_matches_reference(dev, tmp_path):
     orig = model.save
     model.save = lambda d: (best_seen.append(bool(model.loss.is_best)), orig(d))
     train.trainer(model, tr, va, c['n_epochs'], save_dir=str(tmp_path))
+    # the reference algorithm itself moves by g['conditioning'] (2.1e-3) over these 6 steps when only its fp32 summation
+    # order changes (1 vs 8 threads, tests/golden/make_golden.py): entries are compared to 3x that
+    tol = max(2e-3, 3 * g['conditioning'])
     for mine, ref in ((model.loss.train, g['train']), (model.loss.valid, g['valid'])):
         assert [r[0] for r in mine] == [r[0] for r in ref]
+        print('epoch driver: max |loss - reference| per log entry', [max(abs(x - y) for x, y in zip(a[1:], b[1:])) for a, b in zip(mine, ref)])
         for a, b in zip(mine, ref):
-            assert max(abs(x - y) for x, y in zip(a[1:], b[1:])) < 2e-3, (a, b)
-    assert best_seen == g['best_events'] and abs(model.loss.best_dice - g['best_dice']) < 2e-3
+            assert max(abs(x - y) for x, y in zip(a[1:], b[1:])) < tol, (a, b)
+    assert best_seen == g['best_events'] and abs(model.loss.best_dice - g['best_dice']) < tol
     assert abs(model.get_lr() - g['final_lr']) < 1e-12 and model.epoch == c['n_epochs']
     assert [round(v[1], 12) for v in model.loss.lr] == [round(v[1], 12) for v in g['lr']]
     d = os.path.join(str(tmp_path), model.model_id())

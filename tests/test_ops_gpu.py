@@ -41,7 +41,7 @@ CONV_CASES = [
     (128, 64, 3, 1, 0, 1, 1, 20, 20, True),
     (728, 728, 1, 1, 0, 1, 1, 8, 8, False),       # Xception pointwise (Cin % 32 != 0)
     (32, 2048, 1, 1, 0, 1, 4, 1, 1, False),       # ASPP image-pool branch: 1x1 spatial
-    # >= 192 tiles of 256x128: these dispatch to the wave-specialised 8-wave kernel (fwd and dgrad)
+    # >= 192 tiles of 256x128: these dispatch to the 8-wave 256x128 tile (fwd and dgrad)
     (128, 128, 3, 1, 1, 1, 4, 112, 112, False),
     (72, 256, 3, 1, 12, 12, 8, 64, 64, False),    # atrous with tap skipping, Cin % 16 != 0
     (256, 256, 1, 1, 0, 1, 8, 64, 64, True),
@@ -49,7 +49,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[1, 0], ids=['bf16x6', 'f32mfma'])
+@pytest.fixture(params=[2, 1, 0], ids=['f16x3', 'bf16x6', 'f32mfma'])
 def conv_mode(request):
     from pylc_amd.lib import lib, check
     prev = lib.pylc_get_conv_precision()
@@ -59,8 +59,8 @@ def conv_mode(request):
 
 
 def test_conv_precision_modes(dev):
-    """The bf16x6 split must be as accurate as the exact-fp32 matrix pipe: both are compared with an fp64 CPU
-    convolution on the same data, with errors measured relative to sum|a*b| (the natural fp32 error scale)."""
+    """The split arithmetics (bf16x6, f16x3) must be as accurate as the exact-fp32 matrix pipe: all are compared with an
+    fp64 CPU convolution on the same data, with errors measured relative to sum|a*b| (the natural fp32 error scale)."""
     from pylc_amd import ops
     from pylc_amd.lib import lib, check
     b, cin, cout, hw = 2, 256, 256, 24
@@ -71,15 +71,74 @@ def test_conv_precision_modes(dev):
     ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
     scale = F.conv2d(x.double().abs(), wt.double().abs(), None, 1, 1)
     errs = {}
-    for mode in (0, 1):
+    prev = lib.pylc_get_conv_precision()
+    for mode in (0, 1, 2):
         check(lib.pylc_set_conv_precision(mode))
         y = ops.conv2d(to_dev_nhwc(x, dev), to_dev_nhwc(wt, dev), None, 1, 1, 1).double().cpu()
         e = ((y - ref).abs() / scale)
         errs[mode] = (e.mean().item(), e.max().item())
-    check(lib.pylc_set_conv_precision(1))
-    print('conv error / sum|ab|: f32-mfma mean %.3g max %.3g | bf16x6 mean %.3g max %.3g' % (errs[0] + errs[1]))
-    assert errs[0][1] < 1e-6 and errs[1][1] < 1e-6              # a few fp32 ulps of sum|ab|
+    check(lib.pylc_set_conv_precision(prev))
+    print('conv error / sum|ab|: f32-mfma mean %.3g max %.3g | bf16x6 mean %.3g max %.3g | f16x3 mean %.3g max %.3g' % (errs[0] + errs[1] + errs[2]))
+    assert errs[0][1] < 1e-6 and errs[1][1] < 1e-6 and errs[2][1] < 1e-6      # a few fp32 ulps of sum|ab|
     assert errs[1][0] < 1.5 * errs[0][0] + 1e-9                 # bf16x6 is no worse than the fp32 chain on average
+    assert errs[2][0] < 1.5 * errs[0][0] + 1e-9                 # nor is f16x3
+
+
+def test_conv_f16x3_dynamic_range(dev):
+    """f16x3 scales by the tensor maximum, so its guarantee is per tensor: every pixel whose values lie within 2^29 of
+    the largest one keeps fp32-grade relative accuracy (the gradient of a well-classified pixel next to a misclassified
+    one), smaller ones degrade gracefully towards an absolute floor of 2^-51 of the maximum.  1x1 conv: each output pixel
+    depends on one input pixel, so the error can be read per pixel."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib, check
+    b, cin, cout, hw = 1, 256, 128, 32
+    g = torch.Generator().manual_seed(7)
+    expo = torch.linspace(0, -14, hw * hw).reshape(1, 1, hw, hw)         # pixel magnitudes from 1 down to 1e-14
+    x = torch.randn(b, cin, hw, hw, generator=g) * 10.0 ** expo
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * 0.05
+    ref = F.conv2d(x.double(), wt.double())
+    scale = F.conv2d(x.double().abs(), wt.double().abs())
+    prev = lib.pylc_get_conv_precision()
+    out = {}
+    for mode in (0, 2):
+        check(lib.pylc_set_conv_precision(mode))
+        out[mode] = ops.conv2d(to_dev_nhwc(x, dev), to_dev_nhwc(wt, dev), None, 1, 0, 1).double().cpu()
+    check(lib.pylc_set_conv_precision(prev))
+    rel = {m: ((out[m] - ref).abs() / scale).amax(dim=1).flatten() for m in out}       # per pixel, worst channel
+    mag = (10.0 ** expo).flatten()
+    inside = mag >= 2.0 ** -24          # elements ~N(0, mag) vs a tensor maximum of ~4.5: comfortably inside the 2^28 window
+    print('per-pixel error / sum|ab|, pixels within 2^24 of the largest: f32-mfma %.3g, f16x3 %.3g; f16x3 at 1e-12 of the max: %.3g'
+          % (rel[0][inside].max(), rel[2][inside].max(), rel[2][(mag < 2e-12) & (mag > 5e-13)].max()))
+    assert rel[2][inside].max() < 1e-6
+    assert rel[2][inside].max() < 2.0 * rel[0][inside].max()
+    amax = x.abs().max().item()
+    floor = 2.0 ** -50 * amax * wt.abs().sum(dim=1).max().item()          # absolute error bound for the tiny pixels
+    assert ((out[2] - ref).abs().amax(dim=1).flatten()[~inside] < floor + 1e-6 * scale.amax(dim=1).flatten()[~inside]).all()
+
+
+def test_amax_kernels(dev):
+    """pylc_amax / pylc_amax_segments return the exact bit pattern of max|x| (pitched NHWC views included)."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib, check, ptr, stream
+    x = rnd(5, 2, 20, 9, 7)
+    x[1, 3, 4, 5] = -37.5
+    xd = to_dev_nhwc(x, dev)
+    got = ops.amax_of(xd)
+    assert got.view(torch.float32).item() == 37.5
+    buf = ops.zeros_nhwc(2, 48, 9, 7, dev)                      # a concat buffer: the view's pitch is 48
+    view = buf[:, 8:28]
+    view.copy_(xd)
+    assert ops.amax_of(view).view(torch.float32).item() == 37.5
+    odd = to_dev_nhwc(rnd(6, 1, 9, 5, 5), dev)                  # 9 channels in a 12-float pitch
+    assert ops.amax_of(odd).view(torch.float32).item() == odd.abs().max().item()
+    flat = torch.randn(1000, device=dev)
+    offs = torch.tensor([0, 4, 300, 1000], dtype=torch.int64, device=dev)
+    out = torch.empty(3, dtype=torch.int32, device=dev)
+    check(lib.pylc_amax_segments(ptr(flat), ptr(offs), 3, ptr(out), stream()))
+    want = [flat[0:4].abs().max().item(), flat[4:300].abs().max().item(), flat[300:].abs().max().item()]
+    assert out.view(torch.float32).tolist() == want
+    xd.add_(1.0)                                                # an in-place change invalidates the cached range
+    assert ops.amax_of(xd).view(torch.float32).item() == xd.abs().max().item()
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
