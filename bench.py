@@ -6,10 +6,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline     : the dominant kernel = the 256x128-tile gather-GEMM (implicit-GEMM conv fwd + dgrad, bf16x6
+  roofline     : the dominant kernel = the 256x128-tile gather-GEMM (implicit-GEMM conv fwd + dgrad, f16x3 split
                  arithmetic); achieved = algorithmic fp32 FLOPs (2*M*N*K with all taps counted) / its launch time
-                 measured live with HIP events on the launch stream over the timed region; peak = dense bf16 MFMA
-                 peak 2500 TFLOP/s / 6 (six bf16 MFMA terms per fp32 product; MI355X_MICROARCH.md).
+                 measured live with HIP events on the launch stream over the timed region; peak = dense 16-bit MFMA
+                 peak 2500 TFLOP/s / 3 (three fp16 MFMA terms per fp32 product; MI355X_MICROARCH.md).
   cpu_baseline : the CPU oracle (a restatement pinned bit-exactly to the reference) timed on the host cores on a
                  bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); the exact-fp32 matrix pipe peaks at 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md); the exact-fp32 matrix pipe peaks at 157.3
 # algorithmic fwd+bwd work per tile, DeepLabV3+/ResNet101 @512^2, 9 classes
 GFLOP_PER_TILE_ALL = 531.40
 GFLOP_PER_TILE_3X3 = 366.0
@@ -107,6 +107,7 @@ def main():
 
     for _ in range(args.warmup):
         model.train(x, y)
+    ops.amax_passes[:] = [0, 0]
     timer = None
     if not args.no_kernel_timing:
         timer = ops.KernelTimer()
@@ -141,6 +142,8 @@ def main():
                                'bs=%d/GPU (BASELINE.json configs[2])' % (args.tile, args.tile, args.classes, args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'net_tflops_algorithmic': value * GFLOP_PER_TILE_ALL / 1e3 / world,
+                   'conv_arithmetic': {0: 'f32 MFMA', 1: 'bf16x6 split', 2: 'f16x3 split'}[pylc_amd.lib.lib.pylc_get_conv_precision()],
+                   'standalone_range_passes_per_step': ops.amax_passes[0] / args.steps,
                    'last_loss': [float(v) for v in losses[-1]] if losses else None},
     }
     if timer is not None:

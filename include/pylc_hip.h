@@ -145,10 +145,11 @@ int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, con
 /* Eval mode: scale/shift from running statistics. */
 int pylc_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma,
                         const float* beta, float eps, int C, float* scale, float* shift, void* stream);
-/* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out. */
+/* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out.  amax_out (may be NULL)
+ * receives the bit pattern of max|out| -- the x_amax of the conv that consumes `out` (precision mode 2) at no extra pass. */
 int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift,
                   const float* residual, int res_pitch, float* out, int out_pitch,
-                  long long M, int C, int relu, void* stream);
+                  long long M, int C, int relu, unsigned int* amax_out, void* stream);
 /* Backward, training mode.  g = dout * (out > 0 if relu).  sums[0:C] = sum g * xhat (= dgamma),
  * sums[C:2C] = sum g (= dbeta), xhat = (y - mean) * invstd  -- parameter order, so `sums` may point straight at the
  * adjacent (gamma, beta) gradient slots of a flat arena. */
@@ -156,12 +157,13 @@ int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int 
                        const float* y, int y_pitch, const float* mean, const float* invstd,
                        long long M, int C, int relu, float* sums /*[2C]*/, float* workspace, void* stream);
 /* dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) with the (all-reduced) sums and GLOBAL n.
- * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout. */
+ * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout.  amax_dy (may be NULL)
+ * receives the bit pattern of max|dy| (the dy_amax of the preceding conv's dgrad / wgrad in precision mode 2). */
 int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch,
                       const float* y, int y_pitch, const float* mean, const float* invstd,
                       const float* gamma, const float* sums, double n,
                       long long M, int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch,
-                      void* stream);
+                      unsigned int* amax_dy, void* stream);
 /* Plain ReLU forward / backward on [M][C] (Xception's stand-alone ReLUs, xception.py:83-84,199-232). */
 int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream);
 int pylc_relu_bwd(const float* dout, int dout_pitch, const float* out, int out_pitch, float* dx, int dx_pitch,

@@ -105,21 +105,25 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const fl
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_pitch,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ res, int res_pitch, float* __restrict__ out,
-                                                       int out_pitch, int relu, Slab g) {
+                                                       int out_pitch, int relu, Slab g, unsigned* __restrict__ amax_out) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
-    if (ty >= g.RL) return;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
-    for (int cv = tx; cv < g.CV; cv += g.cols) {
-        const f32x4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
-        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            f32x4 v = ld4(y + r * y_pitch + 4 * cv) * sc + sh;
-            if (res != nullptr) v += ld4(res + r * res_pitch + 4 * cv);
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            st4(out + r * out_pitch + 4 * cv, v);
+    float amax = 0.f;
+    if (ty < g.RL) {
+        for (int cv = tx; cv < g.CV; cv += g.cols) {
+            const f32x4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
+            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+                f32x4 v = ld4(y + r * y_pitch + 4 * cv) * sc + sh;
+                if (res != nullptr) v += ld4(res + r * res_pitch + 4 * cv);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                st4(out + r * out_pitch + 4 * cv, v);
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
         }
     }
+    if (amax_out != nullptr) amax_commit(amax, amax_out);      // range of the output for the f16x3 conv that consumes it
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
@@ -128,27 +132,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float inv_n, int C, int relu, float* __restrict__ dy, int dy_pitch,
-                                                           float* __restrict__ g_out, int g_pitch, Slab g) {
+                                                           float* __restrict__ g_out, int g_pitch, Slab g,
+                                                           unsigned* __restrict__ amax_dy) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
-    if (ty >= g.RL) return;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
-    for (int cv = tx; cv < g.CV; cv += g.cols) {
-        const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
-        const f32x4 k = ld4(gamma + 4 * cv) * is;
-        const f32x4 sgx = ld4(sums + 4 * cv) * inv_n, sg = ld4(sums + C + 4 * cv) * inv_n;
-        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
-            if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
-            const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
-            if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, gg);
-            st4(dy + r * dy_pitch + 4 * cv, k * (gg - sg - xh * sgx));
+    float amax = 0.f;
+    if (ty < g.RL) {
+        for (int cv = tx; cv < g.CV; cv += g.cols) {
+            const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
+            const f32x4 k = ld4(gamma + 4 * cv) * is;
+            const f32x4 sgx = ld4(sums + 4 * cv) * inv_n, sg = ld4(sums + C + 4 * cv) * inv_n;
+            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
+                f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
+                if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
+                const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
+                if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, gg);
+                const f32x4 v = k * (gg - sg - xh * sgx);
+                st4(dy + r * dy_pitch + 4 * cv, v);
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
         }
     }
+    if (amax_dy != nullptr) amax_commit(amax, amax_dy);
 }
 
-// MODE 0: out = max(x, 0).  MODE 1: dx = dout * (out > 0).
 template <int MODE>
 __global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ a, int a_pitch, const float* __restrict__ o, int o_pitch,
                                                    float* __restrict__ dst, int dst_pitch, Slab g) {
@@ -248,14 +257,15 @@ extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float
 }
 
 extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
-                             float* out, int out_pitch, long long M, int C, int relu, void* stream) {
+                             float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, void* stream) {
     if (int rc = check_mc(M, C, y_pitch, "bn_apply")) return rc;
     if (int rc = check_mc(M, C, out_pitch, "bn_apply(out)")) return rc;
     PYLC_REQUIRE(y && scale && shift && out, "bn_apply: null pointer");
     PYLC_REQUIRE(residual == nullptr || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
     const Slab g = make_slab(M, C);
+    if (amax_out != nullptr) PYLC_HIP(hipMemsetAsync(amax_out, 0, sizeof(unsigned), as_stream(stream)));
     hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch, out,
-                       out_pitch, relu, g);
+                       out_pitch, relu, g, amax_out);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -279,15 +289,16 @@ extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float
 
 extern "C" int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
                                  const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
-                                 int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, void* stream) {
+                                 int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy, void* stream) {
     if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_apply")) return rc;
     if (int rc = check_mc(M, C, dy_pitch, "bn_bwd_apply(dy)")) return rc;
     PYLC_REQUIRE(dout && y && mean && invstd && gamma && sums && dy && n > 0, "bn_bwd_apply: bad arguments");
     PYLC_REQUIRE(!relu || (out && out_pitch >= C), "bn_bwd_apply: relu needs `out`");
     PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
     const Slab g = make_slab(M, C);
+    if (amax_dy != nullptr) PYLC_HIP(hipMemsetAsync(amax_dy, 0, sizeof(unsigned), as_stream(stream)));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
-                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g);
+                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

@@ -828,7 +828,7 @@ template <int BN, int BC, int PREC>
 constexpr size_t wg16_smem() { return (size_t)(PREC == 2 ? 2 : 3) * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
 
 int g_big_tile = 1;
-int g_conv_precision = 1;      // 0 = fp32 MFMA, 1 = bf16x6 (default); see pylc_set_conv_precision
+int g_conv_precision = 2;      // 0 = fp32 MFMA, 1 = bf16x6, 2 = f16x3 (default); see pylc_set_conv_precision
 
 static thread_local int g_last_bm = 128;      // M-tile height of the most recent gather-GEMM launch on this thread
 

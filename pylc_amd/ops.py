@@ -78,16 +78,18 @@ def _r4(c):
 class KernelTimer:
     """HIP-event timing of the dominant kernel's launches on the stream they are launched on.
 
-    Only launches that dispatch to gather_gemm_kernel<256,128,64,64,false,1> (pylc_amd/csrc/conv_igemm.hip dispatch_gg_p:
-    bf16x6 arithmetic, stored Cout > 64, not the thin-input mode, >= 192 tiles of 256x128) are bracketed; FLOPs are
-    algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 6 bf16 MFMA FLOPs per algorithmic
-    FLOP, so its roofline is the dense bf16 MFMA peak / 6."""
+    Only launches that dispatch to gather_gemm_kernel<256,128,64,64,false,P> (pylc_amd/csrc/conv_igemm.hip dispatch_gg_p:
+    split arithmetic P = 2 (f16x3) or 1 (bf16x6), stored Cout > 64, not the thin-input mode, >= 192 tiles of 256x128)
+    are bracketed; FLOPs are algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 3 (f16x3) or
+    6 (bf16x6) 16-bit MFMA FLOPs per algorithmic FLOP, so its roofline is the dense 16-bit MFMA peak / 3 (or / 6)."""
 
-    KERNEL = 'gather_gemm_kernel<256,128,64,64,false,1>'
+    TERMS = {1: 6, 2: 3}
 
     def __init__(self):
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
+        self.mode = lib.pylc_get_conv_precision()
+        self.KERNEL = 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,7 +97,7 @@ class KernelTimer:
         self.alg_bytes += nbytes
         return a, b
 
-    def roofline(self, peak_bf16_tflops=2500.0):
+    def roofline(self, peak_16bit_tflops=2500.0):
         torch.cuda.synchronize()
         tot_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in self.records)
         flops = sum(r[2] for r in self.records)
@@ -105,14 +107,18 @@ class KernelTimer:
             e = by.setdefault(kind, [0.0, 0.0, 0])
             e[0] += a.elapsed_time(b); e[1] += f; e[2] += n
         ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        peak = peak_bf16_tflops / 6.0
+        terms = self.TERMS.get(self.mode, 6)
+        peak = peak_16bit_tflops / terms
+        arith = ('3-term scaled fp16 split ("f16x3": a0b0 + 2^-11 (a1b0 + a0b1), cross terms in their own fp32 accumulator) '
+                 'on v_mfma_f32_32x32x16_f16' if self.mode == 2 else
+                 '6-term bf16 split ("bf16x6") on v_mfma_f32_32x32x16_bf16')
         return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                 'kernel': self.KERNEL, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1),
                 'kernel_time_ms_total': tot_ms, 'algorithmic_bytes_per_launch': self.alg_bytes / max(launches, 1),
-                'note': 'achieved = algorithmic fp32 FLOP/s; arithmetic = 6-term bf16 split (fp32-grade accuracy) on '
-                        'v_mfma_f32_32x32x16_bf16, so peak = dense bf16 MFMA peak (2500 TFLOP/s) / 6; executed MFMA '
-                        'rate = 6 x achieved; the exact-fp32 matrix pipe peaks at 157.3 TFLOP/s',
-                'mfma_executed_tflops': 6.0 * ach,
+                'note': 'achieved = algorithmic fp32 FLOP/s; arithmetic = %s with fp32-grade accuracy (measured error vs fp64 '
+                        'no larger than the fp32 FMA chain\'s), so peak = dense 16-bit MFMA peak (2500 TFLOP/s) / %d; executed '
+                        'MFMA rate = %d x achieved; the exact-fp32 matrix pipe peaks at 157.3 TFLOP/s' % (arith, terms, terms),
+                'mfma_executed_tflops': terms * ach,
                 'by_kind': {k: {'ms': v[0], 'tflops': v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0, 'launches': v[2]}
                             for k, v in by.items()}}
 
@@ -126,8 +132,8 @@ def set_kernel_timer(t):
 
 
 def _is_dominant_tile(m, n_store, cin, taps):
-    """Mirror of dispatch_gg_p<1> in conv_igemm.hip: does this launch run the 256x128 8-wave bf16x6 kernel?"""
-    if lib.pylc_get_conv_precision() != 1 or n_store <= 64 or (cin == 4 and taps > 1):
+    """Mirror of dispatch_gg_p in conv_igemm.hip: does this launch run the 256x128 8-wave split-arithmetic kernel?"""
+    if lib.pylc_get_conv_precision() == 0 or n_store <= 64 or (cin == 4 and taps > 1):
         return False
     return ((m + 255) // 256) * ((n_store + 127) // 128) >= 192
 
@@ -187,6 +193,9 @@ def _deliver_grad(param, g):
     return g
 
 
+amax_passes = [0, 0]      # [stand-alone range passes, elements read]: diagnostics for the producer-side fusion
+
+
 def ranges_needed():
     """True when the conv kernels run the f16x3 arithmetic (precision mode 2), which scales every operand by a power of
     two taken from its max magnitude."""
@@ -209,6 +218,8 @@ def amax_of(t):
     b, c, h, w = t.shape
     out = torch.empty(1, dtype=torch.int32, device=t.device)
     check(lib.pylc_amax(ptr(t), b * h * w, c, pitch_of(t), ptr(out), stream()))
+    amax_passes[0] += 1
+    amax_passes[1] += t.numel()
     tag_amax(t, out)
     return out
 
@@ -440,7 +451,8 @@ class BnActFn(torch.autograd.Function):
     [sum, sumsq, count]); eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None,
+                want_amax=False):
         L.init()
         y = as_nhwc(y)
         b, c, h, w = y.shape
@@ -476,15 +488,20 @@ class BnActFn(torch.autograd.Function):
         if residual is not None:
             res = as_nhwc(residual)
         out = empty_nhwc(b, c, h, w, dev)
+        amax = torch.empty(1, dtype=torch.int32, device=dev) if want_amax else None
         check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
-                                ptr(out), c, m, c, int(relu), st))
+                                ptr(out), c, m, c, int(relu), ptr(amax), st))
         ctx.save_for_backward(y, out if relu else None, coef)
         ctx.cfg = (relu, training, group, n_global, residual is not None)
         ctx.g_param, ctx.b_param = gamma, beta
+        ctx.want_amax = want_amax
+        if want_amax:
+            ctx.mark_non_differentiable(amax)
+            return out, amax
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         y, out, coef = ctx.saved_tensors
         relu, training, group, n_global, has_res = ctx.cfg
         gamma, beta = ctx.g_param, ctx.b_param
@@ -513,9 +530,12 @@ class BnActFn(torch.autograd.Function):
             sums_apply = sums
         dy = empty_nhwc(b, c, h, w, dev)
         g_out = empty_nhwc(b, c, h, w, dev) if (has_res and ctx.needs_input_grad[5]) else None
+        amax_dy = torch.empty(1, dtype=torch.int32, device=dev) if ctx.want_amax else None
         check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
                                     ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
-                                    ptr(g_out), c if g_out is not None else 0, st))
+                                    ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), st))
+        if amax_dy is not None:
+            tag_amax(dy, amax_dy)       # the conv backward that receives dy reuses it (when autograd hands the tensor on unchanged)
         dgamma = dbeta = None
         if direct:
             _deliver_grad(gamma, tg)
@@ -533,12 +553,16 @@ class BnActFn(torch.autograd.Function):
                     dbeta = _deliver_grad(beta, tb)
                 else:
                     dbeta = local_sums[c:].clone()
-        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None, None
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
            group=None, clamp_eps=False):
     pre = getattr(y, '_pylc_sums', None) if training else None
+    if ranges_needed():
+        out, amax = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre, True)
+        tag_amax(out, amax)
+        return out
     return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre)
 
 

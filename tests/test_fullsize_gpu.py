@@ -58,6 +58,7 @@ def test_config5_xception_1024_gray_bs8(dev):
         first = tot if first is None else first
         assert _finite(model)
     assert tot < first
+    model.net.eval()                      # test.py:41 switches to eval before Model.test (a batch of 1 cannot train BatchNorm)
     logits = model.test(x[:1])[0]
     assert tuple(logits.shape) == (1, 11, 1024, 1024)
     # Dice is bounded in [0, 1]; the three reported terms recombine to the optimised total (loss.py:112)

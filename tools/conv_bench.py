@@ -23,7 +23,7 @@ SHAPES = [  # name, cin, cout, k, stride, pad, dil, B, H
 ]
 which = [a for a in sys.argv[1:] if a in ('fwd', 'dgrad', 'wgrad')] or ['fwd', 'dgrad', 'wgrad']
 L.init()
-mode = int(os.environ.get('PYLC_MODE', '1'))
+mode = int(os.environ.get('PYLC_MODE', '2'))
 check(lib.pylc_set_conv_precision(mode))
 big = int(os.environ.get('PYLC_BIG', '1'))
 lib.pylc_debug_set_big_tile(big)
@@ -38,6 +38,9 @@ for name, cin, cout, k, stride, pad, dil, b, h in SHAPES:
     dy = torch.randn(b, d.OH, d.OW, cout, device=dev).permute(0, 3, 1, 2)
     wt = torch.empty((cin, k * k, (cout + 3) & ~3), device=dev)
     check(lib.pylc_weight_transpose(ptr(w), ptr(wt), cout, k * k, cin, stream()))
+    if mode == 2:                                 # operand ranges of the f16x3 arithmetic (kept alive in `rng`)
+        rng = (ops.amax_of(x), ops.weight_amax(w), ops.amax_of(dy))
+        d.x_amax, d.w_amax, d.dy_amax = (ptr(t) for t in rng)
     dx = ops.empty_nhwc(b, cin, h, h, dev)
     dw = torch.empty((cout, k, k, cin), device=dev)
     nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))

@@ -11,6 +11,8 @@ def conv(x, w, mode, k=1, pad=0):
     b, cin, h, _ = x.shape; cout = w.shape[0]
     d = ops._conv_desc(x, cin, cout, k, k, 1, pad, 1, cin, (cout + 3) & ~3)
     y = ops.empty_nhwc(b, cout, d.OH, d.OW, dev)
+    rng = (ops.amax_of(x), ops.weight_amax(w))
+    d.x_amax, d.w_amax = ptr(rng[0]), ptr(rng[1])
     check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
     torch.cuda.synchronize()
     return y
