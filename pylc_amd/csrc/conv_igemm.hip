@@ -52,13 +52,18 @@ __device__ __forceinline__ void split3(const float __attribute__((ext_vector_typ
     split3(x, p0, p1, p2);
 }
 
-// 2-way fp16 split of four scaled fp32 values: h0 = rn16(s*x), h1 = rn16(s*x - h0); s*x = h0 + h1 up to 2^-22 |s*x|
-// (absolute floor 2^-25: fp16 subnormals).  s is a power of two chosen from the tensor's max magnitude, so s*x is exact.
+// 2-way fp16 split of four scaled fp32 values: h0 = rn16(s*x), h1 = rn16(2048 (s*x - h0)); s*x = h0 + h1/2048 up to
+// 2^-23 |s*x|.  s is a power of two chosen from the tensor's max magnitude, so s*x is exact.
+// Scalar f32 ops on purpose: packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) issues at a third of the rate beside MFMAs
+// (MI355X_MICROARCH.md, constants table); the residual is one mixed-precision FMA per element (v_fma_mix_f32).  Measured
+// alternatives: v_fma_mixlo/hi_f16 (multiply + convert in one, 3 instead of 4 instructions per element) is slower.
 __device__ __forceinline__ void split2(const f32x4 v, float s, uint2& p0, uint2& p1) {
+    const float s2 = s * 2048.f;
     const f32x2 lo = {v.x * s, v.y * s}, hi = {v.z * s, v.w * s};
     const f16x2 l0 = __builtin_convertvector(lo, f16x2), h0 = __builtin_convertvector(hi, f16x2);
-    const f16x2 l1 = __builtin_convertvector((lo - __builtin_convertvector(l0, f32x2)) * 2048.f, f16x2);
-    const f16x2 h1 = __builtin_convertvector((hi - __builtin_convertvector(h0, f32x2)) * 2048.f, f16x2);
+    const f32x2 rl = {__builtin_fmaf((float)l0.x, -2048.f, v.x * s2), __builtin_fmaf((float)l0.y, -2048.f, v.y * s2)};
+    const f32x2 rh = {__builtin_fmaf((float)h0.x, -2048.f, v.z * s2), __builtin_fmaf((float)h0.y, -2048.f, v.w * s2)};
+    const f16x2 l1 = __builtin_convertvector(rl, f16x2), h1 = __builtin_convertvector(rh, f16x2);
     p0.x = __builtin_bit_cast(unsigned, l0); p0.y = __builtin_bit_cast(unsigned, h0);
     p1.x = __builtin_bit_cast(unsigned, l1); p1.y = __builtin_bit_cast(unsigned, h1);
 }
@@ -99,6 +104,9 @@ struct GatherGemmArgs {
     int tiles_n;
     const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
     const unsigned* amax_w;
+    long long x_bytes, w_bytes;   // extents of the x / w buffers (raw buffer loads of the ping-pong kernel)
+    int dbg_flags;           // debug builds of the ping-pong kernel: 1 = skip MFMAs, 2 = raise priority in store/load segments
+    unsigned long long* dbg; // debug builds of the ping-pong kernel: per-segment clock stamps of block 0 (else null)
     float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)
 };
 
@@ -333,15 +341,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                             acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
                             acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
-                            continue;
+                        } else {
+                            // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NPL - 1], fb[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NPL - 1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                         }
-                        // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                     }
             }
         };
@@ -424,6 +432,333 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         }
         if (do_stats) {
             cs += __shfl_xor(cs, 32, 64);                           // lanes l and l+32 hold the same column
+            css += __shfl_xor(css, 32, 64);
+            if (lane < 32) {
+                float* d = sred + ((wave_m * BN) + wave_n * WN + j * 32 + lane) * 2;
+                d[0] = cs;
+                d[1] = css;
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int n = n0 + tid;
+            if (n < a.N_store) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
+                float* dst = a.stats + (size_t)(tile / a.tiles_n) * 2 * a.N_store;
+                dst[n] = sm;
+                dst[a.N_store + n] = sq;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// f16x3 gather-GEMM, 256x128 tile, ping-pong schedule
+// -------------------------------------------------------------------------------------------------
+// Same arithmetic and epilogue as gather_gemm_kernel<256,128,64,64,false,2>; different main loop.  A 512-thread block
+// puts two waves on each SIMD (waves w and w+4).  The two halves of the block run the identical per-step work -- (C) 16
+// fragment reads + 24 MFMAs on the current LDS stage, (S) split + store of their share of the next tile into the other
+// stage -- half a step apart: while waves 0-3 are in C (matrix pipe), their SIMD partners 4-7 are in S (VALU, LDS
+// stores, global loads), then they swap.  The matrix pipe and the VALU of every SIMD are busy in the same interval
+// instead of one after the other (MI355X_MICROARCH.md, "Two waves per SIMD").  LDS stores are 16 bytes per lane (8
+// reduction elements of one plane): wide stores keep their rate with one storing wave per SIMD.
+__device__ __attribute__((aligned(16))) float g_zero_page[8];      // zero-initialised: where masked-off lanes load from
+
+constexpr int PP_BM = 256, PP_BN = 128;
+constexpr int PP_STAGE = 2 * (PP_BM + PP_BN) * LDB;      // bytes per LDS stage (two fp16 planes per operand)
+
+__device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s, uint4& p0, uint4& p1) {
+    uint2 a0, a1, b0, b1;
+    split2(lo, s, a0, a1);
+    split2(hi, s, b0, b1);
+    p0 = make_uint4(a0.x, a0.y, b0.x, b0.y);
+    p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
+}
+
+template <bool STAMPS>
+__global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
+    constexpr int BM = PP_BM, BN = PP_BN, WM = 64, WN = 64, MT = 2, NT = 2, WAVES_N = 2;
+    // STAMPS: waves 0 and 4 of block 0 record s_memtime at every segment boundary into LDS (dumped to a.dbg at the end)
+    int n_stamp = 0;
+#define PP_STAMP()                                                                                                     \
+    if constexpr (STAMPS) {                                                                                            \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && n_stamp < 256) {                                            \
+            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 2 * PP_STAGE)[(threadIdx.x >> 8) * 256 + n_stamp] = \
+                __builtin_amdgcn_s_memtime();                                                                          \
+            ++n_stamp;                                                                                                 \
+        }                                                                                                              \
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int grp = wave >> 2;                    // 0: waves 0-3, 1: their SIMD partners 4-7
+    const int tg = tid & 255, v = tg & 3, lr = tg >> 2;      // loader: 4 lanes x 8 elements per 32-deep row, 64 rows per pass
+    const int arow0 = 128 * grp + lr;             // this thread stages A rows arow0, arow0 + 64 and B row brow
+    const int brow = 64 * grp + lr;
+
+    int rowh[2], roww[2], rowpix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + arow0 + 64 * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int q = mm % a.Q, t = mm / a.Q;
+        const int p = t % a.P, b = t / a.P;
+        rowh[i] = ok ? p * a.in_sh : -(1 << 28);
+        roww[i] = q * a.in_sw;
+        rowpix[i] = b * a.IH * a.IW;
+    }
+    const int T = a.TR * a.TS;
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    unsigned long long tapmask = ~0ull;
+    if (T > 1) {
+        tapmask = 0;
+        for (int t = 0; t < T; ++t) {
+            const int dh = a.dh0 + (t / a.TS) * a.dh_step, dw = a.dw0 + (t % a.TS) * a.dw_step;
+            int any = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                any |= ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);
+            if (__syncthreads_or(any)) tapmask |= 1ull << t;
+        }
+    }
+    const int ntaps = __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
+    const int S = ntaps * nchunks;
+
+    f32x16 acc[MT][NT], acc_lo[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc_lo[i][j][r] = 0.f; }
+    const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
+    const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
+
+    struct Regs { f32x4 a[2][2]; f32x4 b[2]; };
+    Regs R0, R1;
+    // reduction position of the next tile to load: tap (ld_tr, ld_ts) -- kept as counters, no division in the loop -- and chunk
+    int ld_tap = -1, ld_tr = 0, ld_ts = -1, ld_chunk = nchunks - 1;
+    auto advance = [&]() {
+        if (++ld_chunk == nchunks) {
+            ld_chunk = 0;
+            do {
+                ++ld_tap;
+                if (++ld_ts == a.TS) { ld_ts = 0; ++ld_tr; }
+            } while (!((tapmask >> ld_tap) & 1ull));
+        }
+    };
+    // Operands are fetched with raw buffer loads: a lane that is masked off (padding tap, row past M, channel past Cin,
+    // filter row past N, tile past the end of the reduction) gets an offset beyond the buffer and the hardware returns
+    // zeros.  No branches around loads (the loop body stays straight-line, so the compiler waits with a counted vmcnt for
+    // exactly the register set it consumes while the other set stays in flight), no 64-bit address arithmetic, and the
+    // per-row part of the offset is computed once.
+    constexpr unsigned OOB = 0x80000000u;                 // >= num_records (launch_gg_pp only takes buffers below 2 GiB)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    unsigned xoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)       // byte offset of (row's pixel at tap offset (0,0), channel 8v); garbage for invalid rows (masked by rowh)
+        xoff[i] = ((unsigned)(rowpix[i] + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * v) * 4u;
+    const int bn = n0 + brow;
+    const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride + 8u * v) * 4u : OOB;
+    auto ldx = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4& lo, f32x4& hi) {
+        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0));
+    };
+    auto load = [&](Regs& R, bool valid) {
+        if (valid) advance();
+        const int tr = ld_tr, ts = ld_ts;
+        const int dh = a.dh0 + tr * a.dh_step, dw = a.dw0 + ts * a.dw_step;
+        const int woff = a.w_off0 + tr * a.w_step_r + ts * a.w_step_s;
+        const bool cok = valid && ld_chunk * BK + 8 * v < a.Cin;                  // Cin % 8 == 0 on this path
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * BK) * 4);     // wave-uniform, may be "negative"
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = rowh[i] + dh, wi = roww[i] + dw;
+            const bool ok = cok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+            ldx(rx, ok ? xoff[i] + tapdelta : OOB, 0u, R.a[i][0], R.a[i][1]);
+        }
+        ldx(rw, cok ? woff_row : OOB, (unsigned)((woff + ld_chunk * BK) * 4), R.b[0], R.b[1]);
+    };
+    // stage layout: A plane 0 [256][LDB] | A plane 1 | B plane 0 [128][LDB] | B plane 1
+    char* st_a = lds + arow0 * LDB + 16 * v;
+    char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * v;
+    auto store = [&](int stage, const Regs& R) {
+        char* base_a = st_a + stage * PP_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint4 p0, p1;
+            split2x8(R.a[i][0], R.a[i][1], scale_a, p0, p1);
+            *reinterpret_cast<uint4*>(base_a + 64 * i * LDB) = p0;
+            *reinterpret_cast<uint4*>(base_a + 64 * i * LDB + BM * LDB) = p1;
+        }
+        uint4 p0, p1;
+        split2x8(R.b[0], R.b[1], scale_b, p0, p1);
+        char* base_b = st_b + stage * PP_STAGE;
+        *reinterpret_cast<uint4*>(base_b) = p0;
+        *reinterpret_cast<uint4*>(base_b + BN * LDB) = p1;
+    };
+    const char* ra_base = lds + (wave_m * WM + (lane & 31)) * LDB + 16 * (lane >> 5);
+    const char* rb_base = lds + 2 * BM * LDB + (wave_n * WN + (lane & 31)) * LDB + 16 * (lane >> 5);
+    auto compute = [&](int stage) {
+        const char* pa = ra_base + stage * PP_STAGE;
+        const char* pb = rb_base + stage * PP_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 fa[MT][2], fb[NT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 32 * LDB + 32 * ks);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + 32 * ks);
+            if (a.dbg_flags & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc_lo[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+            if (a.dbg_flags & 2) __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    if (S > 0) {
+        // Tiles t >= S are zero tiles (all lanes read the zero page): an odd S runs one harmless extra step and the
+        // steady-state loop needs no tail conditions.
+        load(R0, true);                                   // tile 0
+        load(R1, 1 < S);                                  // tile 1
+        store(0, R0);
+        if (grp == 1) load(R0, 2 < S);                    // tile 2 (the first half fetches it in its first segment)
+        __syncthreads();
+        // hipcc is free to sink MFMAs below an s_barrier (nothing orders them against it), which would smear each wave's
+        // compute segment into its own store segment and undo the ping-pong: pin every segment boundary
+#define PP_SYNC()                                \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __syncthreads();                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+        // Each half alternates a compute segment (fragment reads + 24 MFMAs on the current stage, with the address
+        // arithmetic and the buffer loads of a later tile issued in the MFMA gaps: an MFMA holds the vector issue port for
+        // 8 of its 32 cycles) and a store segment (split + LDS stores of the next tile).  Invariant at the top of pair s:
+        // tile s complete in stage 0, stage 1 free; first half: tile s+1 in R1; second half: tile s+1 in R1, tile s+2 in R0.
+        const bool lic = a.dbg_flags & 4;        // experiment: issue the loads inside the compute segments instead of after the stores
+        if (grp == 0) {
+            if (!lic) load(R0, 2 < S);
+            for (int s = 0; s < S; s += 2) {
+                PP_STAMP();
+                compute(0);
+                if (lic) load(R0, s + 2 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                store(1, R1);
+                if (!lic) load(R1, s + 3 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                compute(1);
+                if (lic) load(R1, s + 3 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                store(0, R0);
+                if (!lic) load(R0, s + 4 < S);
+                PP_STAMP();
+                PP_SYNC();
+            }
+        } else {
+            for (int s = 0; s < S; s += 2) {
+                PP_STAMP();
+                store(1, R1);
+                if (!lic) load(R1, s + 3 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                compute(0);
+                if (lic) load(R1, s + 3 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                store(0, R0);
+                if (!lic) load(R0, s + 4 < S);
+                PP_STAMP();
+                PP_SYNC();
+                PP_STAMP();
+                compute(1);
+                if (lic) load(R0, s + 4 < S);
+                PP_STAMP();
+                PP_SYNC();
+            }
+        }
+#undef PP_SYNC
+        if constexpr (STAMPS) {
+            if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && a.dbg != nullptr)
+                for (int k = 0; k < 256; ++k)
+                    a.dbg[(threadIdx.x >> 8) * 256 + k] = k < n_stamp
+                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 2 * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
+            __syncthreads();
+        }
+    }
+#undef PP_STAMP
+
+    // ---- epilogue (as gather_gemm_kernel) ----
+    long long* rowoff = reinterpret_cast<long long*>(smem);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < a.M) {
+            const int q = m % a.Q, t = m / a.Q;
+            const int p = t % a.P, b = t / a.P;
+            off = ((long long)(b * a.OH + p * a.out_sh + a.oh0) * a.OW + q * a.out_sw + a.ow0) * a.y_pitch;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    float* sred = reinterpret_cast<float*>(smem) + 1024;
+    const bool do_stats = a.stats != nullptr;
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
+        const bool nok = n < a.N_store;
+        const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+        float cs = 0.f, css = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const long long off = rowoff[row];
+                if (nok && off >= 0) {
+                    float val = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b + bv;
+                    float* dst = a.y + off + n;
+                    if (a.accumulate) val += *dst;
+                    *dst = val;
+                    cs += val;
+                    css += val * val;
+                }
+            }
+        }
+        if (do_stats) {
+            cs += __shfl_xor(cs, 32, 64);
             css += __shfl_xor(css, 32, 64);
             if (lane < 32) {
                 float* d = sred + ((wave_m * BN) + wave_n * WN + j * 32 + lane) * 2;
@@ -753,14 +1088,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) 
                             acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
                             acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
-                            continue;
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NPL - 1], fb[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NPL - 1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                     }
             }
         }
@@ -827,7 +1162,9 @@ constexpr size_t wg_smem() { return (size_t)2 * 32 * (BN + BC) * sizeof(float); 
 template <int BN, int BC, int PREC>
 constexpr size_t wg16_smem() { return (size_t)(PREC == 2 ? 2 : 3) * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
 
-int g_big_tile = 1;
+int g_big_tile = 2;      // 0: 128x128 tiles only, 1: 256x128 8-wave tile (lock-step schedule), 2: 256x128 ping-pong kernel for f16x3
+int g_pp_flags = 0;
+unsigned long long* g_pp_stamps = nullptr;      // debug: see pylc_debug_pp_stamps
 int g_conv_precision = 2;      // 0 = fp32 MFMA, 1 = bf16x6, 2 = f16x3 (default); see pylc_set_conv_precision
 
 static thread_local int g_last_bm = 128;      // M-tile height of the most recent gather-GEMM launch on this thread
@@ -845,6 +1182,20 @@ static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
     return PYLC_OK;
 }
 
+static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
+    g_last_bm = PP_BM;
+    const int tiles_m = cdiv(a.M, PP_BM);
+    a.tiles_n = cdiv(a.N_store, PP_BN);
+    const long long grid = (long long)tiles_m * a.tiles_n;
+    PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
+    if (a.dbg != nullptr)
+        hipLaunchKernelGGL(gather_gemm_pp_kernel<true>, dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+    else
+        hipLaunchKernelGGL(gather_gemm_pp_kernel<false>, dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
 template <int PREC>
 static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     if (cin4) {
@@ -854,8 +1205,12 @@ static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     }
     if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false, PREC>(a, st);
     if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false, PREC>(a, st);
-    if (PREC != 0 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192)
+    if (PREC != 0 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192) {
+        if (PREC == 2 && g_big_tile == 2 && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) && a.w_bytes > 0 &&
+            a.w_bytes < (1ll << 31))
+            return launch_gg_pp(a, st);
         return launch_gg<256, 128, 64, 64, false, PREC>(a, st);      // 8 waves: halves LDS-write bytes per MFMA
+    }
     return launch_gg<128, 128, 64, 64, false, PREC>(a, st);
 }
 
@@ -881,6 +1236,8 @@ int conv_init() {
     PYLC_OPT_GG(128, 32, 32, 32)
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
+    PYLC_HIP(opt_in_lds(gather_gemm_pp_kernel<false>, 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds(gather_gemm_pp_kernel<true>, 2 * PP_STAGE + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
@@ -928,6 +1285,11 @@ extern "C" int pylc_set_conv_precision(int mode) {
 
 extern "C" int pylc_get_conv_precision(void) { return g_conv_precision; }
 
+// profiling aid (tools/pp_stamps.py): the next forward convs that take the ping-pong kernel record per-segment clock
+// stamps of block 0 (waves 0 and 4) into `buf` (2 x 256 uint64, device memory); NULL switches it off
+extern "C" int pylc_debug_pp_stamps(unsigned long long* buf) { g_pp_stamps = buf; return PYLC_OK; }
+extern "C" int pylc_debug_pp_flags(int flags) { g_pp_flags = flags; return PYLC_OK; }
+
 // tuning knob (tools/conv_bench.py): allow / forbid the 256x128 8-wave tile
 extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
 
@@ -956,9 +1318,13 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     PYLC_REQUIRE(x && w && y, "null pointer");
     GatherGemmArgs a{};
     a.stats = stats;
+    a.dbg = g_pp_stamps;
+    a.dbg_flags = g_pp_flags;
     PYLC_REQUIRE(g_conv_precision != 2 || (d->x_amax && d->w_amax), "f16x3 mode: conv2d_fwd needs x_amax and w_amax in the descriptor");
     a.amax_x = d->x_amax; a.amax_w = d->w_amax;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
+    a.w_bytes = (long long)d->Cout * d->R * d->S * d->Cin * 4;
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
     a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
     a.in_sh = a.in_sw = d->stride;
@@ -984,6 +1350,8 @@ extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const f
     PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->w_amax), "f16x3 mode: conv2d_dgrad needs dy_amax and w_amax in the descriptor");
     a.amax_x = d->dy_amax; a.amax_w = d->w_amax;
     a.x = dy; a.w = w_crsk; a.bias = nullptr; a.y = dx;
+    a.x_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + Kp) * 4;
+    a.w_bytes = (long long)d->Cin * d->R * d->S * Kp * 4;
     a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
     a.N = d->Cin; a.N_store = d->Cin;
     a.OH = d->H; a.OW = d->W; a.y_pitch = d->x_pitch;

@@ -123,6 +123,9 @@ def init():
         mode = os.environ.get('PYLC_CONV_PRECISION')
         if mode is not None:
             check(lib.pylc_set_conv_precision(int(mode)))
+        big = os.environ.get('PYLC_BIG_TILE')          # tuning / A-B knob, see pylc_debug_set_big_tile
+        if big is not None:
+            lib.pylc_debug_set_big_tile(int(big))
         _initialised = True
 
 

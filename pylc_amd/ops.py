@@ -78,9 +78,9 @@ def _r4(c):
 class KernelTimer:
     """HIP-event timing of the dominant kernel's launches on the stream they are launched on.
 
-    Only launches that dispatch to gather_gemm_kernel<256,128,64,64,false,P> (pylc_amd/csrc/conv_igemm.hip dispatch_gg_p:
-    split arithmetic P = 2 (f16x3) or 1 (bf16x6), stored Cout > 64, not the thin-input mode, >= 192 tiles of 256x128)
-    are bracketed; FLOPs are algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 3 (f16x3) or
+    Only launches that dispatch to the 256x128-tile kernel (pylc_amd/csrc/conv_igemm.hip dispatch_gg_p: gather_gemm_pp_kernel
+    for the f16x3 arithmetic, gather_gemm_kernel<256,128,64,64,false,1> for bf16x6; stored Cout > 64, not the thin-input
+    mode, >= 192 tiles of 256x128, reduction channels % 8 == 0) are bracketed; FLOPs are algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 3 (f16x3) or
     6 (bf16x6) 16-bit MFMA FLOPs per algorithmic FLOP, so its roofline is the dense 16-bit MFMA peak / 3 (or / 6)."""
 
     TERMS = {1: 6, 2: 3}
@@ -89,7 +89,7 @@ class KernelTimer:
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
-        self.KERNEL = 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
+        self.KERNEL = 'gather_gemm_pp_kernel<false>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -134,6 +134,8 @@ def set_kernel_timer(t):
 def _is_dominant_tile(m, n_store, cin, taps):
     """Mirror of dispatch_gg_p in conv_igemm.hip: does this launch run the 256x128 8-wave split-arithmetic kernel?"""
     if lib.pylc_get_conv_precision() == 0 or n_store <= 64 or (cin == 4 and taps > 1):
+        return False
+    if lib.pylc_get_conv_precision() == 2 and cin % 8:
         return False
     return ((m + 255) // 256) * ((n_store + 127) // 128) >= 192
 
@@ -241,6 +243,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None):
         L.init()
+        ctx.set_materialize_grads(False)      # the auxiliary outputs (statistics, ranges) carry no gradient: no zero fills
         x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
         cin = x.shape[1]
@@ -291,6 +294,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        if dy is None:
+            return (None,) * 9
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
@@ -454,6 +459,7 @@ class BnActFn(torch.autograd.Function):
     def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None,
                 want_amax=False):
         L.init()
+        ctx.set_materialize_grads(False)
         y = as_nhwc(y)
         b, c, h, w = y.shape
         m = b * h * w
@@ -502,6 +508,8 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused):
+        if dout is None:
+            return (None,) * 14
         y, out, coef = ctx.saved_tensors
         relu, training, group, n_global, has_res = ctx.cfg
         gamma, beta = ctx.g_param, ctx.b_param

@@ -27,6 +27,7 @@ mode = int(os.environ.get('PYLC_MODE', '2'))
 check(lib.pylc_set_conv_precision(mode))
 big = int(os.environ.get('PYLC_BIG', '1'))
 lib.pylc_debug_set_big_tile(big)
+lib.pylc_debug_pp_flags(int(os.environ.get('PP_FLAGS', '0')))
 print('conv precision mode', mode, 'big tile', big)
 dev = torch.device('cuda:0')
 rounds = 7

@@ -9,7 +9,9 @@ kind = sys.argv[1]
 cin, cout, k, stride, pad, dil, b, h = [int(v) for v in sys.argv[2:10]]
 reps = int(sys.argv[10]) if len(sys.argv) > 10 else 3
 L.init()
-check(lib.pylc_set_conv_precision(int(os.environ.get('PYLC_MODE', '1'))))
+mode = int(os.environ.get('PYLC_MODE', '2'))
+check(lib.pylc_set_conv_precision(mode))
+lib.pylc_debug_set_big_tile(int(os.environ.get('PYLC_BIG', '1')))
 dev = torch.device('cuda:0')
 x = torch.randn(b, h, h, cin, device=dev).permute(0, 3, 1, 2)
 w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).permute(0, 3, 1, 2)
@@ -18,6 +20,9 @@ y = ops.empty_nhwc(b, cout, d.OH, d.OW, dev)
 dy = torch.randn(b, d.OH, d.OW, cout, device=dev).permute(0, 3, 1, 2)
 wt = torch.empty((cin, k * k, (cout + 3) & ~3), device=dev)
 check(lib.pylc_weight_transpose(ptr(w), ptr(wt), cout, k * k, cin, stream()))
+if mode == 2:
+    rng = (ops.amax_of(x), ops.weight_amax(w), ops.amax_of(dy))
+    d.x_amax, d.w_amax, d.dy_amax = (ptr(t) for t in rng)
 dx = ops.empty_nhwc(b, cin, h, h, dev)
 dw = torch.empty((cout, k, k, cin), device=dev)
 nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
