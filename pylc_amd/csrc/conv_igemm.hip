@@ -800,6 +800,7 @@ struct WgradArgs {
     long long slab_stride;
     const unsigned* amax_dy;   // f16x3: device scalars with the float bits of max|dy| and max|x|
     const unsigned* amax_x;
+    long long x_bytes, dy_bytes;   // buffer extents (FAST path: raw buffer loads)
 };
 
 template <int BN, int BC, int WN, int WC, bool CIN4>
@@ -944,7 +945,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BN, int BC, int WN, int WC, bool CIN4, int PREC>
+// FAST (chosen by launch_wg when OW % 32 == 0, not the thin-input mode, both tensors below 4 GiB): every 32-pixel reduction
+// tile then lies inside one output row, so the whole gather geometry of a tile is wave-uniform (scalar unit, updated by
+// counters) and the per-lane work per row is one add, one compare and one select; operands come through raw buffer loads
+// (out-of-range lanes read zeros, no branches, no 64-bit address arithmetic).  The general path recomputes (b, p, q) per
+// row with integer divisions every step, which cost more vector issue slots than the operand split itself.
+template <int BN, int BC, int WN, int WC, bool CIN4, int PREC, bool FAST>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) {
     constexpr int NPL = PREC == 2 ? 2 : 3;
     constexpr int WAVES_C = BC / WC;
@@ -1005,7 +1011,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) 
     }
 
     f32x4 ra[IA], rb[IB];
+    // FAST-path state: tile position as wave-uniform counters, per-thread constant offsets
+    constexpr unsigned OOB = 0xFFFFFFF0u;                 // >= num_records: the load returns zeros
+    int f_mb = m_begin, f_q0 = 0, f_p = 0, f_b = 0;
+    unsigned f_va[FAST ? IA : 1], f_tx[FAST ? IB : 1];
+    int f_wc[FAST ? IB : 1];
+    __amdgpu_buffer_rsrc_t rdy, rx;
+    if constexpr (FAST) {
+        rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(unsigned)a.x_bytes, 0x00020000);
+        f_q0 = m_begin % a.Q;
+        const int t = m_begin / a.Q;
+        f_p = t % a.P;
+        f_b = t / a.P;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch + n0 + 4 * va) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch + c0 + 4 * vb) * 4u;
+            f_wc[i] = (prb + RB * i) * a.in_sw + dw;
+        }
+    }
     auto load_tile = [&](int s) {
+        if constexpr (FAST) {
+            // tile = 32 consecutive output pixels of row (f_b, f_p) starting at column f_q0
+            const int hi = f_p * a.in_sh + dh;
+            const bool row_ok = b_col_ok && (unsigned)hi < (unsigned)a.IH;
+            const unsigned delta = (unsigned)((((f_b * a.IH + hi) * a.IW + f_q0 * a.in_sw + dw) * a.x_pitch) * 4);
+            const int wq = f_q0 * a.in_sw;
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const bool ok = row_ok && (unsigned)(f_wc[i] + wq) < (unsigned)a.IW;
+                // delta already contains dw: the thread constant is the row's pixel step only
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? f_tx[i] + delta : OOB, 0, 0));
+            }
+            const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 4u;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, f_va[i], soff, 0));
+            f_mb += 32;
+            f_q0 += 32;
+            if (f_q0 == a.Q) {
+                f_q0 = 0;
+                if (++f_p == a.P) { f_p = 0; ++f_b; }
+            }
+            return;
+        }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const int mb = m_begin + s * 32;
 #pragma unroll
@@ -1164,6 +1214,7 @@ constexpr size_t wg16_smem() { return (size_t)(PREC == 2 ? 2 : 3) * 32 * (wg_row
 
 int g_big_tile = 2;      // 0: 128x128 tiles only, 1: 256x128 8-wave tile (lock-step schedule), 2: 256x128 ping-pong kernel for f16x3
 int g_pp_flags = 0;
+int g_wgrad_fast = 1;           // A/B knob (pylc_debug_pp_flags bit 8 clears it)
 unsigned long long* g_pp_stamps = nullptr;      // debug: see pylc_debug_pp_stamps
 int g_conv_precision = 2;      // 0 = fp32 MFMA, 1 = bf16x6, 2 = f16x3 (default); see pylc_set_conv_precision
 
@@ -1244,10 +1295,13 @@ int conv_init() {
     PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, true>, wg_smem<64, 64>()));
 #define PYLC_OPT_WG(P)                                                                                                \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P>, wg16_smem<128, 128, P>()));                 \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P>, wg16_smem<64, 64, P>()));                     \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P>, wg16_smem<32, 128, P>()));                   \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, true, P>, wg16_smem<64, 64, P>()));
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, false>, wg16_smem<128, 128, P>()));          \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, false>, wg16_smem<64, 64, P>()));              \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, false>, wg16_smem<32, 128, P>()));            \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, true>, wg16_smem<128, 128, P>()));           \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, true>, wg16_smem<64, 64, P>()));               \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, true>, wg16_smem<32, 128, P>()));             \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, true, P, false>, wg16_smem<64, 64, P>()));
     PYLC_OPT_WG(1)
     PYLC_OPT_WG(2)
 #undef PYLC_OPT_WG
@@ -1288,7 +1342,7 @@ extern "C" int pylc_get_conv_precision(void) { return g_conv_precision; }
 // profiling aid (tools/pp_stamps.py): the next forward convs that take the ping-pong kernel record per-segment clock
 // stamps of block 0 (waves 0 and 4) into `buf` (2 x 256 uint64, device memory); NULL switches it off
 extern "C" int pylc_debug_pp_stamps(unsigned long long* buf) { g_pp_stamps = buf; return PYLC_OK; }
-extern "C" int pylc_debug_pp_flags(int flags) { g_pp_flags = flags; return PYLC_OK; }
+extern "C" int pylc_debug_pp_flags(int flags) { g_pp_flags = flags; g_wgrad_fast = !(flags & 8); return PYLC_OK; }
 
 // tuning knob (tools/conv_bench.py): allow / forbid the 256x128 8-wave tile
 extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
@@ -1450,15 +1504,18 @@ extern "C" size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d) {
 template <int BN, int BC, int WN, int WC, bool CIN4>
 static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
+    const bool fast = !CIN4 && g_wgrad_fast && a.Q % 32 == 0 && a.x_bytes < 0xFFFFFFF0ll && a.dy_bytes < 0xFFFFFFF0ll;
     if (g_conv_precision == 1) {
         const size_t lds16 = wg16_smem<BN, BC, 1>();
-        hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        if (fast) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1, !CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        else hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1, false>), dim3((unsigned)grid), dim3(256), lds16, st, a);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }
     if (g_conv_precision == 2) {
         const size_t lds16 = wg16_smem<BN, BC, 2>();
-        hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        if (fast) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2, !CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
+        else hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2, false>), dim3((unsigned)grid), dim3(256), lds16, st, a);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }
@@ -1491,6 +1548,8 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c; a.splits = p.splits; a.m_per_split = p.m_per_split;
     a.slab_stride = p.slab;
     PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->x_amax), "f16x3 mode: conv2d_wgrad needs dy_amax and x_amax in the descriptor");
+    a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
+    a.dy_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + a.N_ld) * 4;
     a.amax_dy = d->dy_amax; a.amax_x = d->x_amax;
     const long long grid = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T) * p.splits;
     int rc;
