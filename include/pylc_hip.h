@@ -152,10 +152,14 @@ int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* 
                   long long M, int C, int relu, unsigned int* amax_out, void* stream);
 /* Backward, training mode.  g = dout * (out > 0 if relu).  sums[0:C] = sum g * xhat (= dgamma),
  * sums[C:2C] = sum g (= dbeta), xhat = (y - mean) * invstd  -- parameter order, so `sums` may point straight at the
- * adjacent (gamma, beta) gradient slots of a flat arena. */
+ * adjacent (gamma, beta) gradient slots of a flat arena.
+ * The ReLU mask: from `out` when given; with out == NULL and (scale, shift) = the forward's coefficients it is
+ * recomputed as y*scale + shift > 0 (bit-identical to the forward, valid when the forward had NO residual input) --
+ * one tensor less to read in both backward kernels. */
 int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch,
                        const float* y, int y_pitch, const float* mean, const float* invstd,
-                       long long M, int C, int relu, float* sums /*[2C]*/, float* workspace, void* stream);
+                       long long M, int C, int relu, float* sums /*[2C]*/, float* workspace,
+                       const float* scale, const float* shift, void* stream);
 /* dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) with the (all-reduced) sums and GLOBAL n.
  * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout.  amax_dy (may be NULL)
  * receives the bit pattern of max|dy| (the dy_amax of the preceding conv's dgrad / wgrad in precision mode 2). */
@@ -163,7 +167,7 @@ int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int o
                       const float* y, int y_pitch, const float* mean, const float* invstd,
                       const float* gamma, const float* sums, double n,
                       long long M, int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch,
-                      unsigned int* amax_dy, void* stream);
+                      unsigned int* amax_dy, const float* scale, const float* shift, void* stream);
 /* Plain ReLU forward / backward on [M][C] (Xception's stand-alone ReLUs, xception.py:83-84,199-232). */
 int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream);
 int pylc_relu_bwd(const float* dout, int dout_pitch, const float* out, int out_pitch, float* dx, int dx_pitch,

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                                                         const float* __restrict__ out, int out_pitch,
                                                         const float* __restrict__ y, int y_pitch,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int relu, Slab g, int C, float* __restrict__ partial) {
+                                                        int relu, Slab g, int C, float* __restrict__ partial,
+                                                        const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
     __shared__ f32x4 red[2][256];
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
@@ -38,7 +39,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         if (active) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+            const bool remask = MODE == 1 && relu && out == nullptr;      // ReLU mask recomputed from y: out = max(y*scale + shift, 0)
             if (MODE == 1) { mu = ld4(mean + 4 * cv); is = ld4(invstd + 4 * cv); }
+            if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
             for (long long r = r_begin + ty; r < r_end; r += g.RL) {
                 if (MODE == 0) {
                     const f32x4 v = ld4(a + r * a_pitch + 4 * cv);
@@ -46,8 +50,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                     s1 += v * v;
                 } else {
                     f32x4 gg = ld4(a + r * a_pitch + 4 * cv);
-                    if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
-                    const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
+                    const f32x4 yv = ld4(y + r * y_pitch + 4 * cv);
+                    if (remask) gg = relu_mask(gg, yv * sc + sh);          // the forward's own expression: identical bits
+                    else if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
+                    const f32x4 xh = (yv - mu) * is;
                     s0 += gg;
                     s1 += gg * xh;
                 }
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float inv_n, int C, int relu, float* __restrict__ dy, int dy_pitch,
                                                            float* __restrict__ g_out, int g_pitch, Slab g,
-                                                           unsigned* __restrict__ amax_dy) {
+                                                           unsigned* __restrict__ amax_dy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
@@ -144,10 +151,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
             const f32x4 k = ld4(gamma + 4 * cv) * is;
             const f32x4 sgx = ld4(sums + 4 * cv) * inv_n, sg = ld4(sums + C + 4 * cv) * inv_n;
+            const bool remask = relu && out == nullptr;
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+            if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
             for (long long r = r_begin + ty; r < r_end; r += g.RL) {
                 f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
-                if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
-                const f32x4 xh = (ld4(y + r * y_pitch + 4 * cv) - mu) * is;
+                const f32x4 yv = ld4(y + r * y_pitch + 4 * cv);
+                if (remask) gg = relu_mask(gg, yv * sc + sh);
+                else if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
+                const f32x4 xh = (yv - mu) * is;
                 if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, gg);
                 const f32x4 v = k * (gg - sg - xh * sgx);
                 st4(dy + r * dy_pitch + 4 * cv, v);
@@ -272,15 +284,16 @@ extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, co
 
 extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
                                   const float* mean, const float* invstd, long long M, int C, int relu, float* sums, float* workspace,
-                                  void* stream) {
+                                  const float* scale, const float* shift, void* stream) {
     if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_reduce")) return rc;
     if (int rc = check_mc(M, C, y_pitch, "bn_bwd_reduce(y)")) return rc;
     PYLC_REQUIRE(dout && y && mean && invstd && sums && workspace, "bn_bwd_reduce: null pointer");
-    PYLC_REQUIRE(!relu || (out && out_pitch >= C && out_pitch % 4 == 0), "bn_bwd_reduce: relu needs `out`");
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C && out_pitch % 4 == 0) || (!out && scale && shift),
+                 "bn_bwd_reduce: relu needs `out`, or scale and shift to recompute the mask from y");
     const Slab g = make_slab(M, C);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
-                       relu, g, C, workspace);
+                       relu, g, C, workspace, scale, shift);
     PYLC_LAUNCH_CHECK();
     hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
@@ -289,16 +302,18 @@ extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float
 
 extern "C" int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
                                  const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
-                                 int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy, void* stream) {
+                                 int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy,
+                                 const float* scale, const float* shift, void* stream) {
     if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_apply")) return rc;
     if (int rc = check_mc(M, C, dy_pitch, "bn_bwd_apply(dy)")) return rc;
     PYLC_REQUIRE(dout && y && mean && invstd && gamma && sums && dy && n > 0, "bn_bwd_apply: bad arguments");
-    PYLC_REQUIRE(!relu || (out && out_pitch >= C), "bn_bwd_apply: relu needs `out`");
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C) || (!out && scale && shift),
+                 "bn_bwd_apply: relu needs `out`, or scale and shift to recompute the mask from y");
     PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
     const Slab g = make_slab(M, C);
     if (amax_dy != nullptr) PYLC_HIP(hipMemsetAsync(amax_dy, 0, sizeof(unsigned), as_stream(stream)));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
-                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy);
+                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

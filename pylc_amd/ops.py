@@ -497,7 +497,9 @@ class BnActFn(torch.autograd.Function):
         amax = torch.empty(1, dtype=torch.int32, device=dev) if want_amax else None
         check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
                                 ptr(out), c, m, c, int(relu), ptr(amax), st))
-        ctx.save_for_backward(y, out if relu else None, coef)
+        # ReLU mask in backward: without a residual it is recomputed from y (y*scale + shift > 0, the forward's own
+        # expression), so `out` is neither kept alive for it nor read again
+        ctx.save_for_backward(y, out if (relu and residual is not None) else None, coef)
         ctx.cfg = (relu, training, group, n_global, residual is not None)
         ctx.g_param, ctx.b_param = gamma, beta
         ctx.want_amax = want_amax
@@ -519,6 +521,7 @@ class BnActFn(torch.autograd.Function):
         dev = y.device
         st = stream()
         mean, invstd = coef[:c], coef[c:2 * c]
+        scale, shift = (coef[2 * c:3 * c], coef[3 * c:]) if (relu and out is None) else (None, None)
         # [dgamma | dbeta] go straight into the flat gradient arena when gamma/beta own adjacent slots there
         tg, tb = _grad_target(gamma), _grad_target(beta)
         direct = (tg is not None and tb is not None and tb.data_ptr() == tg.data_ptr() + 4 * c
@@ -527,7 +530,7 @@ class BnActFn(torch.autograd.Function):
         ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
         op = pitch_of(out) if out is not None else 0
         check(lib.pylc_bn_bwd_reduce(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
-                                     m, c, int(relu), ptr(sums), ptr(ws), st))
+                                     m, c, int(relu), ptr(sums), ptr(ws), ptr(scale), ptr(shift), st))
         local_sums = sums
         if training and group is not None:
             sums = local_sums.clone()          # parameter grads stay local (the gradient all-reduce sums them later)
@@ -541,7 +544,7 @@ class BnActFn(torch.autograd.Function):
         amax_dy = torch.empty(1, dtype=torch.int32, device=dev) if ctx.want_amax else None
         check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
                                     ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
-                                    ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), st))
+                                    ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), st))
         if amax_dy is not None:
             tag_amax(dy, amax_dy)       # the conv backward that receives dy reuses it (when autograd hands the tensor on unchanged)
         dgamma = dbeta = None
