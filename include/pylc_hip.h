@@ -60,6 +60,11 @@ typedef struct PylcConvDesc {
     const unsigned int* x_amax;
     const unsigned int* w_amax;
     const unsigned int* dy_amax;
+    /* Optional prepared filter (precision mode 2, pylc_weight_prepare): two fp16 planes in the forward layout
+     * [2][Cout][R*S][Cin] (read by fwd) and in the dgrad layout [2][Cin][R*S][roundup4(Cout)] (read by dgrad), split
+     * with the scale that w_amax implies.  NULL = the kernels split the fp32 filter themselves. */
+    const void* w_planes;
+    const void* w_planes_t;
 } PylcConvDesc;
 
 /* Arithmetic of the dense conv kernels (process-wide):
@@ -81,6 +86,20 @@ int pylc_get_conv_precision(void);
  * segments base[offsets[s] .. offsets[s+1]) in one launch (all parameters of a flat arena); offsets is a DEVICE
  * array of count+1 entries. */
 int pylc_amax(const float* x, long long rows, int cols, int pitch, unsigned int* out_bits, void* stream);
+/* Prepare the f16x3 filter planes of `count` conv filters in ONE launch (after every optimiser step, once the ranges
+ * are refreshed): entry i describes a KRSC filter base[src_offset ..] of shape [K][RS][C], whose range is
+ * amax[amax_index]; its planes go to planes[fwd_offset ..] (2*K*RS*C halves) and planes[t_offset ..]
+ * (2*C*RS*roundup4(K) halves).  `table` is a DEVICE array; total_tiles = the sum that continues tile_begin. */
+typedef struct PylcWPrepEntry {
+    long long src_offset;      /* floats from `base`   */
+    long long fwd_offset;      /* halves from `planes` */
+    long long t_offset;        /* halves from `planes` */
+    long long tile_begin;      /* running sum of RS * ceil(K/32) * ceil(C/32) over the preceding entries */
+    int K, RS, C;
+    int amax_index;
+} PylcWPrepEntry;
+int pylc_weight_prepare(const float* base, const PylcWPrepEntry* table, int count, long long total_tiles,
+                        const unsigned int* amax, void* planes, void* stream);
 int pylc_amax_segments(const float* base, const long long* offsets, int count, unsigned int* out_bits, void* stream);
 
 /* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
@@ -97,6 +116,8 @@ int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, const float* w_
  * pylc_weight_transpose.  accumulate != 0 adds into dx instead of overwriting it. */
 int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx,
                       int accumulate, void* stream);
+/* 0 when pylc_conv2d_dgrad(d, ...) only reads d->w_planes_t (w_crsk may then be NULL and the transpose be skipped). */
+int pylc_conv2d_dgrad_needs_f32_weights(const PylcConvDesc* d);
 /* dw (KRSC) = sum over pixels of dy (x) x.  workspace: pylc_conv2d_wgrad_workspace(d) bytes
  * (deterministic split-K slabs, reduced in a fixed order).  dbias (may be NULL) = sum_pixels dy. */
 size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d);

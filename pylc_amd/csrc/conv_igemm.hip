@@ -105,7 +105,10 @@ struct GatherGemmArgs {
     const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
     const unsigned* amax_w;
     long long x_bytes, w_bytes;   // extents of the x / w buffers (raw buffer loads of the ping-pong kernel)
-    int dbg_flags;           // debug builds of the ping-pong kernel: 1 = skip MFMAs, 2 = raise priority in store/load segments
+    const void* w_planes;         // optional: the filter already split into two fp16 planes (pylc_weight_prepare), same
+                                  // indexing as w, plane 1 at + w_plane_stride halves; scaled with the amax behind amax_w
+    long long w_plane_stride;
+    int dbg_flags;           // tools/pp_stamps.py: 16 = finer stamps inside the store segment (STAMPS build only)
     unsigned long long* dbg; // debug builds of the ping-pong kernel: per-segment clock stamps of block 0 (else null)
     float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)
 };
@@ -479,7 +482,7 @@ __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s
     p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
 }
 
-template <bool STAMPS>
+template <bool STAMPS, bool BPL>
 __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
     constexpr int BM = PP_BM, BN = PP_BN, WM = 64, WN = 64, MT = 2, NT = 2, WAVES_N = 2;
     // STAMPS: waves 0 and 4 of block 0 record s_memtime at every segment boundary into LDS (dumped to a.dbg at the end)
@@ -564,13 +567,18 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     // per-row part of the offset is computed once.
     constexpr unsigned OOB = 0x80000000u;                 // >= num_records (launch_gg_pp only takes buffers below 2 GiB)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    // BPL: the filter comes pre-split (two fp16 planes of 2 bytes per element, prepared once per optimiser step), so the
+    // B tile is copied to LDS without any arithmetic; otherwise fp32 filters are split here like the activations
+    const __amdgpu_buffer_rsrc_t rw = BPL
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
     unsigned xoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)       // byte offset of (row's pixel at tap offset (0,0), channel 8v); garbage for invalid rows (masked by rowh)
         xoff[i] = ((unsigned)(rowpix[i] + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * v) * 4u;
     const int bn = n0 + brow;
-    const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride + 8u * v) * 4u : OOB;
+    const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride + 8u * v) * (BPL ? 2u : 4u) : OOB;
+    const unsigned plane1 = (unsigned)(a.w_plane_stride * 2);
     auto ldx = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4& lo, f32x4& hi) {
         lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
         hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0));
@@ -588,22 +596,39 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             const bool ok = cok && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
             ldx(rx, ok ? xoff[i] + tapdelta : OOB, 0u, R.a[i][0], R.a[i][1]);
         }
-        ldx(rw, cok ? woff_row : OOB, (unsigned)((woff + ld_chunk * BK) * 4), R.b[0], R.b[1]);
+        if constexpr (BPL) {       // 8 halves of plane 0 and of plane 1
+            const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2);
+            R.b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row : OOB, so, 0));
+            R.b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row + plane1 : OOB, so, 0));
+        } else {
+            ldx(rw, cok ? woff_row : OOB, (unsigned)((woff + ld_chunk * BK) * 4), R.b[0], R.b[1]);
+        }
     };
     // stage layout: A plane 0 [256][LDB] | A plane 1 | B plane 0 [128][LDB] | B plane 1
     char* st_a = lds + arow0 * LDB + 16 * v;
     char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * v;
     auto store = [&](int stage, const Regs& R) {
         char* base_a = st_a + stage * PP_STAGE;
+        if constexpr (STAMPS) {
+            if (a.dbg_flags & 16) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); PP_STAMP(); }     // fine timeline: loads landed
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uint4 p0, p1;
             split2x8(R.a[i][0], R.a[i][1], scale_a, p0, p1);
             *reinterpret_cast<uint4*>(base_a + 64 * i * LDB) = p0;
             *reinterpret_cast<uint4*>(base_a + 64 * i * LDB + BM * LDB) = p1;
+            if constexpr (STAMPS) {
+                if (a.dbg_flags & 16) { __builtin_amdgcn_sched_barrier(0); PP_STAMP(); }               // item i split + stored (stamp drains LDS)
+            }
         }
         uint4 p0, p1;
-        split2x8(R.b[0], R.b[1], scale_b, p0, p1);
+        if constexpr (BPL) {
+            p0 = __builtin_bit_cast(uint4, R.b[0]);
+            p1 = __builtin_bit_cast(uint4, R.b[1]);
+        } else {
+            split2x8(R.b[0], R.b[1], scale_b, p0, p1);
+        }
         char* base_b = st_b + stage * PP_STAGE;
         *reinterpret_cast<uint4*>(base_b) = p0;
         *reinterpret_cast<uint4*>(base_b + BN * LDB) = p1;
@@ -626,7 +651,6 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + 32 * ks);
-            if (a.dbg_flags & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -635,7 +659,6 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                     acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc_lo[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
                 }
-            if (a.dbg_flags & 2) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         load(R0, true);                                   // tile 0
         load(R1, 1 < S);                                  // tile 1
         store(0, R0);
-        if (grp == 1) load(R0, 2 < S);                    // tile 2 (the first half fetches it in its first segment)
+        load(R0, 2 < S);                                  // tile 2
         __syncthreads();
         // hipcc is free to sink MFMAs below an s_barrier (nothing orders them against it), which would smear each wave's
         // compute segment into its own store segment and undo the ping-pong: pin every segment boundary
@@ -655,32 +678,29 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         __syncthreads();                         \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
-        // Each half alternates a compute segment (fragment reads + 24 MFMAs on the current stage, with the address
-        // arithmetic and the buffer loads of a later tile issued in the MFMA gaps: an MFMA holds the vector issue port for
-        // 8 of its 32 cycles) and a store segment (split + LDS stores of the next tile).  Invariant at the top of pair s:
-        // tile s complete in stage 0, stage 1 free; first half: tile s+1 in R1; second half: tile s+1 in R1, tile s+2 in R0.
-        const bool lic = a.dbg_flags & 4;        // experiment: issue the loads inside the compute segments instead of after the stores
+        // Each half alternates a compute segment (fragment reads + 24 MFMAs on the current stage) and a store segment (split +
+        // LDS stores of the next tile, then the buffer loads of the tile after next into the register set just freed).
+        // Invariant at the top of pair s: tile s complete in stage 0, stage 1 free, tile s+1 in R1, tile s+2 in flight into R0.
+        // (Measured alternatives: loads issued inside the compute segments, s_setprio around the MFMA cluster or around the
+        // store segment -- all slower or neutral.)
         if (grp == 0) {
-            if (!lic) load(R0, 2 < S);
             for (int s = 0; s < S; s += 2) {
                 PP_STAMP();
                 compute(0);
-                if (lic) load(R0, s + 2 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 store(1, R1);
-                if (!lic) load(R1, s + 3 < S);
+                load(R1, s + 3 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 compute(1);
-                if (lic) load(R1, s + 3 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 store(0, R0);
-                if (!lic) load(R0, s + 4 < S);
+                load(R0, s + 4 < S);
                 PP_STAMP();
                 PP_SYNC();
             }
@@ -688,22 +708,20 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             for (int s = 0; s < S; s += 2) {
                 PP_STAMP();
                 store(1, R1);
-                if (!lic) load(R1, s + 3 < S);
+                load(R1, s + 3 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 compute(0);
-                if (lic) load(R1, s + 3 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 store(0, R0);
-                if (!lic) load(R0, s + 4 < S);
+                load(R0, s + 4 < S);
                 PP_STAMP();
                 PP_SYNC();
                 PP_STAMP();
                 compute(1);
-                if (lic) load(R0, s + 4 < S);
                 PP_STAMP();
                 PP_SYNC();
             }
@@ -1233,16 +1251,25 @@ static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
     return PYLC_OK;
 }
 
+// geometry / size conditions of the ping-pong kernel (on top of: f16x3 mode, stored N > 64, >= 192 tiles of 256x128)
+static bool takes_pp(const GatherGemmArgs& a) {
+    return g_big_tile == 2 && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) && a.w_bytes > 0 && a.w_bytes < (1ll << 31);
+}
+
 static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     g_last_bm = PP_BM;
     const int tiles_m = cdiv(a.M, PP_BM);
     a.tiles_n = cdiv(a.N_store, PP_BN);
     const long long grid = (long long)tiles_m * a.tiles_n;
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
-    if (a.dbg != nullptr)
-        hipLaunchKernelGGL(gather_gemm_pp_kernel<true>, dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+    if (a.dbg != nullptr && a.w_planes != nullptr)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+    else if (a.dbg != nullptr)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+    else if (a.w_planes != nullptr)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     else
-        hipLaunchKernelGGL(gather_gemm_pp_kernel<false>, dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -1257,9 +1284,7 @@ static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false, PREC>(a, st);
     if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false, PREC>(a, st);
     if (PREC != 0 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192) {
-        if (PREC == 2 && g_big_tile == 2 && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) && a.w_bytes > 0 &&
-            a.w_bytes < (1ll << 31))
-            return launch_gg_pp(a, st);
+        if (PREC == 2 && takes_pp(a)) return launch_gg_pp(a, st);
         return launch_gg<256, 128, 64, 64, false, PREC>(a, st);      // 8 waves: halves LDS-write bytes per MFMA
     }
     return launch_gg<128, 128, 64, 64, false, PREC>(a, st);
@@ -1287,8 +1312,10 @@ int conv_init() {
     PYLC_OPT_GG(128, 32, 32, 32)
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
-    PYLC_HIP(opt_in_lds(gather_gemm_pp_kernel<false>, 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds(gather_gemm_pp_kernel<true>, 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true>), 2 * PP_STAGE + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
@@ -1379,6 +1406,7 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
     a.w_bytes = (long long)d->Cout * d->R * d->S * d->Cin * 4;
+    a.w_planes = d->w_planes; a.w_plane_stride = (long long)d->Cout * d->R * d->S * d->Cin;
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
     a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
     a.in_sh = a.in_sw = d->stride;
@@ -1394,9 +1422,26 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     return PYLC_OK;
 }
 
+// 1 when pylc_conv2d_dgrad(d, ...) will read the fp32 transposed filter (w_crsk), 0 when the prepared planes in
+// d->w_planes_t are all it touches (f16x3 mode, stride 1, a geometry that dispatches to the ping-pong kernel)
+extern "C" int pylc_conv2d_dgrad_needs_f32_weights(const PylcConvDesc* d) {
+    if (check_desc(d)) return 1;
+    if (g_conv_precision != 2 || d->stride != 1 || d->w_planes_t == nullptr) return 1;
+    const int Kp = roundup4(d->Cout);
+    GatherGemmArgs a{};
+    a.Cin = Kp;
+    a.x_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + Kp) * 4;
+    a.w_bytes = (long long)d->Cin * d->R * d->S * Kp * 4;
+    const long long M = (long long)d->B * d->H * d->W;
+    const bool big = d->Cin > 64 && g_big_tile && cdiv<long long>(M, 256) * cdiv(d->Cin, 128) >= 192;
+    return (big && takes_pp(a)) ? 0 : 1;
+}
+
 extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate, void* stream) {
     if (int rc = check_desc(d)) return rc;
-    PYLC_REQUIRE(dy && w_crsk && dx, "null pointer");
+    PYLC_REQUIRE(dy && dx, "null pointer");
+    PYLC_REQUIRE(w_crsk || (d->w_planes_t && !pylc_conv2d_dgrad_needs_f32_weights(d)),
+                 "conv2d_dgrad: this geometry needs the fp32 transposed filter (pylc_conv2d_dgrad_needs_f32_weights)");
     hipStream_t st = as_stream(stream);
     const int Kp = roundup4(d->Cout);       // reduction runs over output channels, padded to 4 (zero weights / zero dy)
     PYLC_REQUIRE(Kp <= d->y_pitch, "dy pitch %d must cover roundup4(Cout)=%d", d->y_pitch, Kp);
@@ -1406,6 +1451,7 @@ extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const f
     a.x = dy; a.w = w_crsk; a.bias = nullptr; a.y = dx;
     a.x_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + Kp) * 4;
     a.w_bytes = (long long)d->Cin * d->R * d->S * Kp * 4;
+    a.w_planes = d->w_planes_t; a.w_plane_stride = (long long)d->Cin * d->R * d->S * Kp;
     a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
     a.N = d->Cin; a.N_store = d->Cin;
     a.OH = d->H; a.OW = d->W; a.y_pitch = d->x_pitch;

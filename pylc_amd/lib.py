@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class PylcError(RuntimeError):
@@ -21,7 +21,13 @@ class PylcError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'dil',
                                        'OH', 'OW', 'x_pitch', 'y_pitch')] + \
-               [(n, C.c_void_p) for n in ('x_amax', 'w_amax', 'dy_amax')]     # operand ranges (precision mode 2)
+               [(n, C.c_void_p) for n in ('x_amax', 'w_amax', 'dy_amax',      # operand ranges (precision mode 2)
+                                          'w_planes', 'w_planes_t')]           # prepared filter planes (optional)
+
+
+class WPrepEntry(C.Structure):
+    _fields_ = [('src_offset', C.c_longlong), ('fwd_offset', C.c_longlong), ('t_offset', C.c_longlong),
+                ('tile_begin', C.c_longlong), ('K', C.c_int), ('RS', C.c_int), ('C', C.c_int), ('amax_index', C.c_int)]
 
 
 class DwDesc(C.Structure):
@@ -44,6 +50,8 @@ SIGNATURES = {
     'pylc_get_conv_precision': (_I, []),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
+    'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),
+    'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     'pylc_conv2d_fwd_stats_floats': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd_stats': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(_I), _P]),

@@ -177,8 +177,7 @@ class Model:
     # ---- the three hot-path entry points ---------------------------------------------------------------------
     def train(self, x, y):
         """One optimisation step (model.py:282-336)."""
-        self.net.train()
-        self.arena.refresh_ranges()
+        self.net.train()       # (parameter ranges / prepared filters are current: refreshed by every optimiser step and state load)
         x4 = self.pack_input(x)
         y = self.crop_target(y.to(self.device, non_blocking=True).long())
         y_hat = self.net(x4)

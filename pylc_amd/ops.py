@@ -7,6 +7,7 @@ kernels; if libpylc_hip.so is missing, importing ``pylc_amd.lib`` already failed
 """
 import ctypes as C
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -167,7 +168,7 @@ _side_streams = {}
 def _side_stream(device):
     key = torch.device(device).index
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        _side_streams[key] = torch.cuda.Stream(device=device)      # (stream priorities made no measurable difference)
     return _side_streams[key]
 
 
@@ -266,6 +267,9 @@ class Conv2dFn(torch.autograd.Function):
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
         d.x_amax, d.w_amax = ptr(x_amax), ptr(w_amax)
         ctx.ranges = (x_amax, w_amax)
+        planes = getattr(w, '_pylc_planes', None) if (w_amax is not None and w_k is w) else None
+        if planes is not None:
+            d.w_planes = ptr(planes[0])
         ev = None
         if _timer is not None and _is_dominant_tile(b * oh * ow, yp, cin, r * s):
             ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
@@ -315,14 +319,19 @@ class Conv2dFn(torch.autograd.Function):
                 raise L.PylcError('conv backward in f16x3 mode, but the forward ran without operand ranges')
             dy_amax = amax_of(dy)
             d.x_amax, d.w_amax, d.dy_amax = ptr(x_amax), ptr(w_amax), ptr(dy_amax)
+            planes = getattr(w, '_pylc_planes', None) if w_k is w else None
+            if planes is not None:
+                d.w_planes_t = ptr(planes[1])
         st = stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             kp = _r4(cout)
-            wt = torch.empty((cin, r * s, kp), device=x.device, dtype=torch.float32)
-            check(lib.pylc_weight_transpose(ptr(w_k), ptr(wt), cout, r * s, cin, st))
             dx = empty_nhwc(*x.shape, device=x.device)
             d.x_pitch = cin
+            wt = None
+            if lib.pylc_conv2d_dgrad_needs_f32_weights(C.byref(d)):      # else the prepared planes are all the kernel reads
+                wt = torch.empty((cin, r * s, kp), device=x.device, dtype=torch.float32)
+                check(lib.pylc_weight_transpose(ptr(w_k), ptr(wt), cout, r * s, cin, st))
             ev = None
             n_launch = 1 if stride == 1 else min(r, 2) * min(s, 2)     # one launch per non-empty output parity class
             if _timer is not None and _is_dominant_tile(x.shape[0] * x.shape[2] * x.shape[3] // n_launch, cin, kp, 2):

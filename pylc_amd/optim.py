@@ -46,15 +46,41 @@ class FlatArena:
         self._segments = torch.tensor(offs + [total], dtype=torch.int64, device=dev)
         for i, p in enumerate(params):
             p._pylc_wamax = self.amax[i:i + 1]
+        # prepared conv filters for the f16x3 arithmetic: two fp16 planes per filter in the forward (KRSC) and the dgrad
+        # (CRSK) layout, rebuilt from the fp32 master weights by ONE launch whenever the ranges are refreshed
+        entries, halves, tiles = [], 0, 0
+        for i, (p, o) in enumerate(zip(params, offs)):
+            if p.dim() == 4 and p.shape[1] % 4 == 0 and p.shape[1] > 1 and p.permute(0, 2, 3, 1).is_contiguous():
+                k, c, r, s_ = p.shape
+                kp = (k + 3) & ~3
+                e = L.WPrepEntry(o, halves, halves + 2 * k * r * s_ * c, tiles, k, r * s_, c, i)
+                tiles += r * s_ * ((k + 31) // 32) * ((c + 31) // 32)
+                halves += 2 * k * r * s_ * c + 2 * c * r * s_ * kp
+                halves = (halves + 7) & ~7          # 16-byte aligned plane sets
+                entries.append((p, e))
+        self.planes = torch.zeros(max(halves, 8), dtype=torch.float16, device=dev)
+        self._n_prep, self._prep_tiles = len(entries), tiles
+        if entries and self.p.is_cuda:
+            import ctypes as C
+            arr = (L.WPrepEntry * len(entries))(*[e for _, e in entries])
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self._prep_table = raw.to(dev)
+            for p, e in entries:
+                k, c, r, s_ = p.shape
+                p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
+                                  self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
         module.register_load_state_dict_post_hook(lambda *_: self.refresh_ranges())
         self.refresh_ranges()
 
     def refresh_ranges(self):
-        """Recompute every parameter's max magnitude.  Call after anything that changes parameter values (the optimiser
-        steps here do; Model refreshes at the start of each step as well)."""
+        """Recompute every parameter's max magnitude and rebuild the prepared filter planes from it.  Call after anything
+        that changes parameter values (the optimiser steps here do; Model refreshes at the start of each step as well)."""
         if self.p.is_cuda:
             L.init()
             check(lib.pylc_amax_segments(ptr(self.p), ptr(self._segments), len(self.params), ptr(self.amax), stream()))
+            if self._n_prep:
+                check(lib.pylc_weight_prepare(ptr(self.p), ptr(self._prep_table), self._n_prep, self._prep_tiles, ptr(self.amax),
+                                              ptr(self.planes), stream()))
 
     def zero_grad(self):
         self.g.zero_()

@@ -122,6 +122,7 @@ def broadcast_parameters(arena, group=None, src=0):
     """Make every rank start from rank `src`'s parameters (replicas must be identical)."""
     for lo, hi in bucket_ranges(arena.numel):
         dist.broadcast(arena.p[lo:hi], src, group=group)
+    arena.refresh_ranges()          # parameter ranges and prepared conv filters follow the new values
 
 
 def barrier():

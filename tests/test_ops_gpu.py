@@ -422,3 +422,38 @@ def test_conv_fused_bn_statistics(dev, shape, conv_mode):
     assert rel_err(sums[:cout], ref_s) < 1e-5 and rel_err(sums[cout:2 * cout], ref_ss) < 1e-5
     plain = ops.conv2d(xd, to_dev_nhwc(wt, dev), None, stride, k // 2, 1)
     assert torch.equal(plain, y)
+
+
+def test_prepared_filter_planes_match_inline_split(dev):
+    """FlatArena prepares every conv filter once per step as two fp16 planes (forward and dgrad layouts); the conv kernels
+    that copy those planes must give bit-identical results to the ones that split the fp32 filter themselves."""
+    from pylc_amd import ops, layers
+    from pylc_amd.lib import lib, check
+    from pylc_amd.optim import FlatArena
+    if lib.pylc_get_conv_precision() != 2:
+        pytest.skip('prepared planes belong to the f16x3 arithmetic')
+    torch.manual_seed(3)
+    for cin, cout, k, pad, b, hw in ((64, 128, 3, 1, 16, 64), (256, 136, 1, 0, 8, 128)):
+        conv = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
+        x = to_dev_nhwc(rnd(11, b, cin, hw, hw), dev).requires_grad_(True)
+        dy = to_dev_nhwc(rnd(12, b, cout, hw, hw), dev)
+        y0 = conv(x)
+        y0.backward(dy)
+        dx0, dw0 = x.grad.clone(), conv.weight.grad.clone()
+        x.grad = None
+        arena = FlatArena(conv)                      # re-homes the weight and attaches the prepared planes
+        assert getattr(conv.weight, '_pylc_planes', None) is not None
+        y1 = conv(x)
+        y1.backward(dy)
+        ops.sync_side_streams()
+        assert torch.equal(y0, y1) and torch.equal(dx0, x.grad)
+        assert torch.equal(dw0, conv.weight.grad)
+        # the planes follow the weights: change them, refresh, compare against a fresh inline split
+        with torch.no_grad():
+            conv.weight.mul_(3.0)
+        arena.refresh_ranges()
+        y2 = conv(x)
+        ref = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
+        with torch.no_grad():
+            ref.weight.copy_(conv.weight)
+        assert torch.equal(y2, ref(x))

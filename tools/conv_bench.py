@@ -25,7 +25,7 @@ which = [a for a in sys.argv[1:] if a in ('fwd', 'dgrad', 'wgrad')] or ['fwd', '
 L.init()
 mode = int(os.environ.get('PYLC_MODE', '2'))
 check(lib.pylc_set_conv_precision(mode))
-big = int(os.environ.get('PYLC_BIG', '1'))
+big = int(os.environ.get('PYLC_BIG', '2'))
 lib.pylc_debug_set_big_tile(big)
 lib.pylc_debug_pp_flags(int(os.environ.get('PP_FLAGS', '0')))
 print('conv precision mode', mode, 'big tile', big)
@@ -42,6 +42,15 @@ for name, cin, cout, k, stride, pad, dil, b, h in SHAPES:
     if mode == 2:                                 # operand ranges of the f16x3 arithmetic (kept alive in `rng`)
         rng = (ops.amax_of(x), ops.weight_amax(w), ops.amax_of(dy))
         d.x_amax, d.w_amax, d.dy_amax = (ptr(t) for t in rng)
+    if mode == 2 and os.environ.get('PYLC_PLANES'):          # prepared filter planes (what FlatArena does once per step)
+        kp = (cout + 3) & ~3
+        e = L.WPrepEntry(0, 0, 2 * cout * k * k * cin, 0, cout, k * k, cin, 0)
+        tab = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).clone().to(dev)
+        planes = torch.zeros(2 * cout * k * k * cin + 2 * cin * k * k * kp, dtype=torch.float16, device=dev)
+        tiles = k * k * ((cout + 31) // 32) * ((cin + 31) // 32)
+        check(lib.pylc_weight_prepare(ptr(w), ptr(tab), 1, tiles, ptr(rng[1]), ptr(planes), stream()))
+        d.w_planes = planes.data_ptr()
+        d.w_planes_t = planes.data_ptr() + 2 * (2 * cout * k * k * cin)
     dx = ops.empty_nhwc(b, cin, h, h, dev)
     dw = torch.empty((cout, k, k, cin), device=dev)
     nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))

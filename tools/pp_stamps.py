@@ -15,6 +15,12 @@ w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).permute(0, 3, 1, 2)
 d = ops._conv_desc(x, cin, cout, k, k, 1, pad, 1, cin, cout)
 rng = (ops.amax_of(x), ops.weight_amax(w))
 d.x_amax, d.w_amax = ptr(rng[0]), ptr(rng[1])
+if os.environ.get('PYLC_PLANES'):
+    e = L.WPrepEntry(0, 0, 2 * cout * k * k * cin, 0, cout, k * k, cin, 0)
+    tab = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).clone().to(dev)
+    planes = torch.zeros(2 * cout * k * k * cin + 2 * cin * k * k * ((cout + 3) & ~3), dtype=torch.float16, device=dev)
+    check(lib.pylc_weight_prepare(ptr(w), ptr(tab), 1, k * k * ((cout + 31) // 32) * ((cin + 31) // 32), ptr(rng[1]), ptr(planes), stream()))
+    d.w_planes = planes.data_ptr()
 y = ops.empty_nhwc(b, cout, d.OH, d.OW, dev)
 buf = torch.zeros(512, dtype=torch.int64, device=dev)
 for _ in range(2):
@@ -26,8 +32,11 @@ check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
 torch.cuda.synchronize()
 lib.pylc_debug_pp_stamps(None)
 t = buf.cpu().view(2, 256)
-names = {0: ['compute0+load', 'bar', 'store1', 'bar', 'compute1+load', 'bar', 'store0', 'bar'],
-         1: ['store1', 'bar', 'compute0+load', 'bar', 'store0', 'bar', 'compute1+load', 'bar']}
+names = {0: ['compute0', 'bar', 'store1+load', 'bar', 'compute1', 'bar', 'store0+load', 'bar'],
+         1: ['store1+load', 'bar', 'compute0', 'bar', 'store0+load', 'bar', 'compute1', 'bar']}
+if int(os.environ.get('PP_FLAGS', '0')) & 16:
+    names = {0: ['compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar'],
+             1: ['vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar']}
 for g in (0, 1):
     ts = [int(v) for v in t[g] if v != 0]
     base = ts[0]
