@@ -1190,14 +1190,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) 
     }
 }
 
-// dw[i] = sum_s slab[s][i] in a fixed order (deterministic).
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n4,
-                                     int splits, long long slab_stride) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
-        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_stride + 4 * i);
-        *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
+// dw[i] = sum_s slab[s][i] in a fixed order (deterministic).  A block covers 32 float4 columns x 8 split lanes: lane j adds
+// slabs j, j+8, j+16, ... (independent loads in flight instead of one dependent chain of up to 256), then the 8 partial sums
+// are combined in lane order through LDS.  The association is fixed by (splits), not by timing.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, long long n4,
+                                                            int splits, long long slab_stride) {
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long long base = (long long)blockIdx.x * 32; base < n4; base += (long long)gridDim.x * 32) {
+        const long long i = base + col;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4)
+            for (int k = sl; k < splits; k += 8) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_stride + 4 * i);
+        red[sl][col] = s;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) s += red[j][col];
+            *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -1608,7 +1620,7 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     if (rc) return rc;
     if (p.splits > 1) {
         const long long n4 = p.slab / 4;
-        const int blocks = (int)(cdiv<long long>(n4, 256) < 2048 ? cdiv<long long>(n4, 256) : 2048);
+        const int blocks = (int)(cdiv<long long>(n4, 32) < 4096 ? cdiv<long long>(n4, 32) : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(workspace), dw, n4,
                            p.splits, p.slab);
         PYLC_LAUNCH_CHECK();

@@ -131,9 +131,12 @@ def init():
         mode = os.environ.get('PYLC_CONV_PRECISION')
         if mode is not None:
             check(lib.pylc_set_conv_precision(int(mode)))
-        big = os.environ.get('PYLC_BIG_TILE')          # tuning / A-B knob, see pylc_debug_set_big_tile
+        big = os.environ.get('PYLC_BIG_TILE')          # tuning / A-B knobs, see pylc_debug_set_big_tile / pylc_debug_pp_flags
         if big is not None:
             lib.pylc_debug_set_big_tile(int(big))
+        flags = os.environ.get('PYLC_DEBUG_FLAGS')
+        if flags is not None:
+            lib.pylc_debug_pp_flags(int(flags))
         _initialised = True
 
 

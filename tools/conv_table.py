@@ -13,7 +13,7 @@ def wrap(name):
         dd = d._obj
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record(); rc = fn(d, *a); a1.record()
-        key = (name.replace('pylc_conv2d_', ''), dd.Cin, dd.Cout, dd.R, dd.stride, dd.dil, dd.H, dd.OH)
+        key = (name.replace('pylc_conv2d_', '').replace('fwd_stats', 'fwd'), dd.Cin, dd.Cout, dd.R, dd.stride, dd.dil, dd.H, dd.OH)
         flops = 2.0 * dd.B * dd.OH * dd.OW * dd.Cout * dd.R * dd.S * dd.Cin
         recs.append((key, a0, a1, flops))
         return rc
@@ -21,10 +21,12 @@ def wrap(name):
 import pylc_amd.ops as ops
 class Shim:
     def __getattr__(self, n):
-        if n in ('pylc_conv2d_fwd', 'pylc_conv2d_dgrad', 'pylc_conv2d_wgrad'):
+        if n in ('pylc_conv2d_fwd', 'pylc_conv2d_fwd_stats', 'pylc_conv2d_dgrad', 'pylc_conv2d_wgrad'):
             return wrap(n)
         return getattr(L.lib, n)
 ops.lib = Shim()
+from pylc_amd.runtime import runtime
+runtime.wgrad_side_stream = not os.environ.get('PYLC_SERIAL')      # PYLC_SERIAL=1: wgrad on the main stream (un-overlapped kernel times)
 dev = torch.device('cuda:0')
 model = Model(Meta(report=10**9), dev).build()
 x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (32, 3, 512, 512)).astype(np.float32)).to(dev)
@@ -39,6 +41,8 @@ for key, a0, a1, fl in recs:
     e = agg[key]; e[0] += 1; e[1] += a0.elapsed_time(a1); e[2] += fl
 tot = sum(v[1] for v in agg.values()) / STEPS
 print('total conv ms/step %.1f' % tot)
+for kind in ('fwd', 'dgrad', 'wgrad'):
+    print('   %s %.1f ms/step' % (kind, sum(v[1] for k, v in agg.items() if k[0] == kind) / STEPS))
 print('%-7s %5s %5s k s d  %4s->%-4s %6s %8s %8s' % ('kind', 'cin', 'cout', 'H', 'OH', 'n/step', 'ms/step', 'TF/s'))
 for key, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     kind, cin, cout, r, s, d, h, oh = key
