@@ -48,6 +48,9 @@ SIGNATURES = {
     'pylc_init': (_I, []),
     'pylc_set_conv_precision': (_I, [_I]),
     'pylc_get_conv_precision': (_I, []),
+    'pylc_debug_set_big_tile': (_I, [_I]),
+    'pylc_debug_pp_flags': (_I, [_I]),
+    'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
     'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),

@@ -2,6 +2,7 @@
 equivalent state in the `defaults` singleton, config.py:329, which SURVEY.md appendix D.12 says the
 build must replace with explicit arguments)."""
 import itertools
+import os
 
 
 class _Runtime:
@@ -9,7 +10,8 @@ class _Runtime:
         self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
-        self.wgrad_side_stream = True  # run conv wgrad kernels on a second HIP stream (overlaps BN backward)
+        # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)
+        self.wgrad_side_stream = not os.environ.get('PYLC_NO_SIDE_STREAM')
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         self.seed = 0x5EED
