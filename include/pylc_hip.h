@@ -163,11 +163,17 @@ int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, con
                      float eps, float momentum, int clamp_eps,
                      float* running_mean, float* running_var,      /* may be NULL (no update) */
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* pylc_bn_stats_from_partial + pylc_bn_finalize in one launch (single-GPU path: nothing to all-reduce in between);
+ * `partial` / n_rows as produced by pylc_conv2d_fwd_stats.  Bit-identical to the two-launch path. */
+int pylc_bn_finalize_from_partial(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
+                                  float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
+                                  float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* Eval mode: scale/shift from running statistics. */
 int pylc_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma,
                         const float* beta, float eps, int C, float* scale, float* shift, void* stream);
-/* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out.  amax_out (may be NULL)
- * receives the bit pattern of max|out| -- the x_amax of the conv that consumes `out` (precision mode 2) at no extra pass. */
+/* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out.  amax_out (may be NULL) is
+ * max-accumulated with the bit pattern of max|out| -- the x_amax of the conv that consumes `out` (precision mode 2) at no
+ * extra pass; the caller provides it ZERO-INITIALISED (or holding a lower bound). */
 int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift,
                   const float* residual, int res_pitch, float* out, int out_pitch,
                   long long M, int C, int relu, unsigned int* amax_out, void* stream);
@@ -182,8 +188,9 @@ int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int 
                        long long M, int C, int relu, float* sums /*[2C]*/, float* workspace,
                        const float* scale, const float* shift, void* stream);
 /* dy = gamma*invstd*(g - sum_g/n - xhat*sum_gx/n) with the (all-reduced) sums and GLOBAL n.
- * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout.  amax_dy (may be NULL)
- * receives the bit pattern of max|dy| (the dy_amax of the preceding conv's dgrad / wgrad in precision mode 2). */
+ * If g_out != NULL it receives g (the gradient of the residual branch). dy may alias dout.  amax_dy (may be NULL,
+ * zero-initialised by the caller) is max-accumulated with the bit pattern of max|dy| (the dy_amax of the preceding
+ * conv's dgrad / wgrad in precision mode 2). */
 int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int out_pitch,
                       const float* y, int y_pitch, const float* mean, const float* invstd,
                       const float* gamma, const float* sums, double n,

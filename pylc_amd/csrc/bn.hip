@@ -98,6 +98,46 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int
     }
 }
 
+// bn_finalize fed directly by the conv epilogue's per-tile partials: the fp64 column combine (column_sum_kernel's
+// arithmetic, 8 channels x 32 row lanes per block, fixed order) and the coefficient math in one launch.
+__global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* __restrict__ partial, int nrows, double n, int C,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                  float momentum, int clamp_eps, float* running_mean, float* running_var,
+                                                                  float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double red[2][32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int r = ty; r < nrows; r += 32) {
+            a0 += (double)partial[(size_t)r * 2 * C + c];
+            a1 += (double)partial[(size_t)r * 2 * C + C + c];
+        }
+    red[0][ty][tx] = a0;
+    red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s0 += red[0][k][tx]; s1 += red[1][k][tx]; }
+    const double sum = (double)(float)s0, sumsq = (double)(float)s1;      // the two-launch path rounds the sums to fp32 in between
+    const double mu = sum / n;
+    double var = sumsq / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
+    const float mu_f = (float)mu, is_f = (float)is;
+    mean[c] = mu_f;
+    invstd[c] = is_f;
+    const float sc = gamma[c] * is_f;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu_f * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu_f;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +300,18 @@ extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float*
     return PYLC_OK;
 }
 
+extern "C" int pylc_bn_finalize_from_partial(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
+                                             float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
+                                             float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    PYLC_REQUIRE(partial && n_rows > 0 && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0,
+                 "bn_finalize_from_partial: bad arguments");
+    PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_from_partial: running stats must both be set or both NULL");
+    hipLaunchKernelGGL(bn_finalize_partial_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, n, C, gamma, beta, eps,
+                       momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
 extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,
                                    float* shift, void* stream) {
     PYLC_REQUIRE(rm && rv && gamma && beta && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
@@ -275,7 +327,6 @@ extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, co
     PYLC_REQUIRE(y && scale && shift && out, "bn_apply: null pointer");
     PYLC_REQUIRE(residual == nullptr || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
     const Slab g = make_slab(M, C);
-    if (amax_out != nullptr) PYLC_HIP(hipMemsetAsync(amax_out, 0, sizeof(unsigned), as_stream(stream)));
     hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch, out,
                        out_pitch, relu, g, amax_out);
     PYLC_LAUNCH_CHECK();
@@ -311,7 +362,6 @@ extern "C" int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float*
                  "bn_bwd_apply: relu needs `out`, or scale and shift to recompute the mask from y");
     PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
     const Slab g = make_slab(M, C);
-    if (amax_dy != nullptr) PYLC_HIP(hipMemsetAsync(amax_dy, 0, sizeof(unsigned), as_stream(stream)));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
                        mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift);
     PYLC_LAUNCH_CHECK();

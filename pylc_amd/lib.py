@@ -71,6 +71,7 @@ SIGNATURES = {
     'pylc_bn_stats_from_partial': (_I, [_P, _I, _I, _P, _P]),
     'pylc_bn_finalize': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'pylc_bn_finalize_from_partial': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P, _P]),
     'pylc_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P]),
     'pylc_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _D, _LL, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),

@@ -198,6 +198,21 @@ def _deliver_grad(param, g):
 
 amax_passes = [0, 0]      # [stand-alone range passes, elements read]: diagnostics for the producer-side fusion
 
+_amax_pools = {}          # device index -> [zeroed int32 pool, next free slot]
+
+
+def amax_slot(device):
+    """A zero-initialised device scalar for a kernel that max-accumulates a tensor's range into it (pylc_bn_apply,
+    pylc_bn_bwd_apply).  Slots are views of a pool that is zeroed once per 4096 slots instead of one memset per use."""
+    key = torch.device(device).index
+    pool = _amax_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]      # the old pool lives on while tags reference it
+        _amax_pools[key] = pool
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
 
 def ranges_needed():
     """True when the conv kernels run the f16x3 arithmetic (precision mode 2), which scales every operand by a power of
@@ -282,8 +297,7 @@ class Conv2dFn(torch.autograd.Function):
             part = torch.empty(lib.pylc_conv2d_fwd_stats_floats(C.byref(d)), device=x.device)
             rows = C.c_int(0)
             check(lib.pylc_conv2d_fwd_stats(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), ptr(part), C.byref(rows), stream()))
-            sums = torch.empty(2 * cout + 1, device=x.device)            # [sum | sumsq | count slot for SyncBN]
-            check(lib.pylc_bn_stats_from_partial(ptr(part), rows.value, cout, ptr(sums), stream()))
+            sums = part[:rows.value * 2 * cout].view(rows.value, 2 * cout)      # per-tile partials; the BatchNorm combines them
         else:
             check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(y), stream()))
         if ev is not None:
@@ -482,18 +496,25 @@ class BnActFn(torch.autograd.Function):
             # torch.nn.BatchNorm2d's behaviour (the ASPP image-pool branch normalises over the batch only: B must be > 1)
             raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(y.shape),))
         if training:
-            if pre_sums is not None and pre_sums.numel() == 2 * c + 1:
-                sums = pre_sums                      # produced by the conv epilogue (ops.conv2d(want_stats=True))
+            partial = pre_sums if (pre_sums is not None and pre_sums.dim() == 2 and pre_sums.shape[1] == 2 * c) else None
+            if partial is not None and group is None:
+                # statistics came out of the conv epilogue as per-tile partials: combine + coefficients in one launch
+                check(lib.pylc_bn_finalize_from_partial(ptr(partial), partial.shape[0], n_global, c, ptr(gamma), ptr(beta), eps, momentum,
+                                                        int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
+                                                        ptr(scale), ptr(shift), st))
             else:
-                sums = torch.empty(2 * c + 1, device=dev)
-                ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
-                check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
-            if group is not None:
-                sums[2 * c] = float(m)
-                dist.all_reduce(sums, group=group)
-                n_global = float(m) * dist.get_world_size(group)      # equal shards (drop_last loader)
-            check(lib.pylc_bn_finalize(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
-                                       ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st))
+                sums = torch.empty(2 * c + 1, device=dev)                 # [sum | sumsq | count slot for SyncBN]
+                if partial is not None:
+                    check(lib.pylc_bn_stats_from_partial(ptr(partial), partial.shape[0], c, ptr(sums), st))
+                else:
+                    ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
+                    check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
+                if group is not None:
+                    sums[2 * c] = float(m)
+                    dist.all_reduce(sums, group=group)
+                    n_global = float(m) * dist.get_world_size(group)      # equal shards (drop_last loader)
+                check(lib.pylc_bn_finalize(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
+                                           ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st))
         else:
             check(lib.pylc_bn_eval_coeffs(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
                                           ptr(scale), ptr(shift), st))
@@ -503,7 +524,7 @@ class BnActFn(torch.autograd.Function):
         if residual is not None:
             res = as_nhwc(residual)
         out = empty_nhwc(b, c, h, w, dev)
-        amax = torch.empty(1, dtype=torch.int32, device=dev) if want_amax else None
+        amax = amax_slot(dev) if want_amax else None
         check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
                                 ptr(out), c, m, c, int(relu), ptr(amax), st))
         # ReLU mask in backward: without a residual it is recomputed from y (y*scale + shift > 0, the forward's own
@@ -550,7 +571,7 @@ class BnActFn(torch.autograd.Function):
             sums_apply = sums
         dy = empty_nhwc(b, c, h, w, dev)
         g_out = empty_nhwc(b, c, h, w, dev) if (has_res and ctx.needs_input_grad[5]) else None
-        amax_dy = torch.empty(1, dtype=torch.int32, device=dev) if ctx.want_amax else None
+        amax_dy = amax_slot(dev) if ctx.want_amax else None
         check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
                                     ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
                                     ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), st))

@@ -416,12 +416,25 @@ def test_conv_fused_bn_statistics(dev, shape, conv_mode):
     wt = rnd(62, cout, cin if cin != 4 else 3, k, k, scale=0.1)
     xd = to_dev_nhwc(x, dev) if cin != 4 else ops.pack_nchw(x[:, :3].to(dev), 4)
     y = ops.conv2d(xd, to_dev_nhwc(wt, dev), None, stride, k // 2, 1, want_stats=True)
-    sums = y._pylc_sums
+    part = y._pylc_sums                                  # per-tile partials [rows][2*cout]
+    sums = part.double().sum(0)
     yd = y.double()
     ref_s, ref_ss = yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))
     assert rel_err(sums[:cout], ref_s) < 1e-5 and rel_err(sums[cout:2 * cout], ref_ss) < 1e-5
     plain = ops.conv2d(xd, to_dev_nhwc(wt, dev), None, stride, k // 2, 1)
     assert torch.equal(plain, y)
+    # the one-launch combine + coefficients equals the two-launch path bit for bit
+    from pylc_amd.lib import lib, check, ptr, stream
+    g, be = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    n = float(y.shape[0] * y.shape[2] * y.shape[3])
+    a = [torch.empty(cout, device=dev) for _ in range(4)]
+    bb = [torch.empty(cout, device=dev) for _ in range(4)]
+    two = torch.empty(2 * cout, device=dev)
+    check(lib.pylc_bn_stats_from_partial(ptr(part), part.shape[0], cout, ptr(two), stream()))
+    check(lib.pylc_bn_finalize(ptr(two), n, cout, ptr(g), ptr(be), 1e-5, 0.1, 0, None, None, *[ptr(t) for t in a], stream()))
+    check(lib.pylc_bn_finalize_from_partial(ptr(part), part.shape[0], n, cout, ptr(g), ptr(be), 1e-5, 0.1, 0, None, None,
+                                            *[ptr(t) for t in bb], stream()))
+    assert all(torch.equal(u, v) for u, v in zip(a, bb))
 
 
 def test_prepared_filter_planes_match_inline_split(dev):

@@ -25,7 +25,7 @@ for (b, c, h) in ((32, 256, 128), (32, 64, 128), (32, 1024, 32), (32, 256, 32), 
     gamma = torch.ones(c, device=dev)
     sums = torch.empty(2 * c + 1, device=dev)
     ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
-    amax = torch.empty(1, dtype=torch.int32, device=dev)
+    amax = torch.zeros(1, dtype=torch.int32, device=dev)
     gb = m * c * 4 / 1e9
     t = timeit(lambda: check(lib.pylc_bn_apply(ptr(y), c, ptr(scale), ptr(shift), None, 0, ptr(out), c, m, c, 1, ptr(amax), stream())))
     line = '[%d,%d,%d,%d] %.2f GB/tensor | apply %.0f us %.2f TB/s' % (b, c, h, h, gb, t * 1e3, 2 * gb / t)
