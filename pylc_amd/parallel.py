@@ -44,7 +44,13 @@ def init_from_env(backend=None):
     else:
         dist.init_process_group(backend)
     runtime.sync_group = dist.group.WORLD
-    runtime.grad_group = dist.new_group(backend=backend) if backend == 'nccl' else dist.group.WORLD
+    # One communicator for everything by default: torch.distributed documents concurrent use of several NCCL/RCCL process
+    # groups as unsafe (collectives of different communicators may start in different orders on different ranks and wait
+    # for each other).  On a single communicator the bucket all-reduces and the SyncBN messages execute in program order,
+    # identical on every rank; a SyncBN message can queue behind a 64 MB bucket (<= ~0.5 ms each, 4 per step).
+    # PYLC_SEPARATE_GRAD_COMM=1 opts into a dedicated communicator for the buckets.
+    separate = backend == 'nccl' and os.environ.get('PYLC_SEPARATE_GRAD_COMM') == '1'
+    runtime.grad_group = dist.new_group(backend=backend) if separate else dist.group.WORLD
     runtime.manual_seed(runtime.seed, rank)
     return rank, world
 
@@ -55,10 +61,9 @@ class GradBucketer:
     The flat gradient arena is cut into buckets of whole parameters (>= BUCKET_FLOATS each, in arena = module order).
     Backward produces gradients in reverse module order (decoder -> ASPP -> layer4 -> ... -> stem), so buckets complete
     from the END of the arena; the moment the last gradient of a bucket has been written (pylc_amd/ops.py calls
-    `ready(param)` right after launching the kernel that writes it) its SUM all-reduce is enqueued asynchronously on a
-    dedicated RCCL communicator -- a second process group, so the 64 MB transfers never queue in front of the
-    latency-critical SyncBN collectives.  torch's NCCL work objects order each collective after the kernels already
-    enqueued on the compute stream."""
+    `ready(param)` right after launching the kernel that writes it) its SUM all-reduce is enqueued asynchronously (same
+    communicator as the SyncBN messages unless PYLC_SEPARATE_GRAD_COMM=1, see init_from_env).  torch's NCCL work objects
+    order each collective after the kernels already enqueued on the compute stream."""
 
     def __init__(self, arena, group=None, bucket_floats=BUCKET_FLOATS):
         self.arena = arena
