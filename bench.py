@@ -105,6 +105,20 @@ def main():
         parallel.broadcast_parameters(model.arena)
     x, y = synth(rank, args.batch, 3, args.tile, args.classes, dev)
 
+    # Settle (untimed, before the W warm-up steps): a process started right after another GPU job may see that job's
+    # memory teardown for a few seconds (measured: back-to-back launches lose up to 35 % for some runs, 3 s apart none).
+    # Run steps until three consecutive ones agree within 2 % of the fastest seen, at most 40.
+    best, streak = float('inf'), 0
+    for _ in range(40):
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        model.train(x, y)
+        torch.cuda.synchronize()
+        d_s = time.perf_counter() - t_s
+        best = min(best, d_s)
+        streak = streak + 1 if d_s <= 1.02 * best else 0
+        if streak >= 3:
+            break
     for _ in range(args.warmup):
         model.train(x, y)
     ops.amax_passes[:] = [0, 0]
@@ -151,7 +165,9 @@ def main():
         out['roofline']['traffic'] = pmc_traffic(out['roofline']['kernel'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.tile, args.classes)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    del model, x, y
+    torch.cuda.empty_cache()          # hand the 27 GB back before exit: a following launch does not run into the teardown
 
 
 if __name__ == '__main__':

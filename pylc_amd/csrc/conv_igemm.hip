@@ -102,6 +102,7 @@ struct GatherGemmArgs {
     int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
     int accumulate;
     int tiles_n;
+    int n_tiles;            // tiles_m * tiles_n (the persistent ping-pong kernel walks them)
     const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
     const unsigned* amax_w;
     long long x_bytes, w_bytes;   // extents of the x / w buffers (raw buffer loads of the ping-pong kernel)
@@ -498,7 +499,10 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Tile loop: normally one tile per block (grid = n_tiles); with fewer blocks than tiles each block walks a strided
+    // share (persistent mode, see launch_gg_pp).
+    for (int t_ = blockIdx.x; t_ < a.n_tiles; t_ += gridDim.x) {
+    const int tile = xcd_remap(t_, a.n_tiles);
     const int m0 = (tile / a.tiles_n) * BM;
     const int n0 = (tile % a.tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -798,6 +802,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                 dst[a.N_store + n] = sq;
             }
         }
+    }
+    __syncthreads();          // the next tile reuses the LDS stages and the epilogue tables
     }
 }
 
@@ -1252,6 +1258,7 @@ static thread_local int g_last_bm = 128;      // M-tile height of the most recen
 
 template <int BM, int BN, int WM, int WN, bool CIN4, int PREC>
 static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
+    PYLC_REQUIRE(a.w != nullptr, "conv: this geometry reads the fp32 filter, but only prepared planes were given");
     g_last_bm = BM;
     const int tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N_store, BN);
@@ -1272,8 +1279,13 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     g_last_bm = PP_BM;
     const int tiles_m = cdiv(a.M, PP_BM);
     a.tiles_n = cdiv(a.N_store, PP_BN);
-    const long long grid = (long long)tiles_m * a.tiles_n;
-    PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
+    const long long n_tiles = (long long)tiles_m * a.tiles_n;
+    PYLC_REQUIRE(n_tiles > 0 && n_tiles < (1ll << 31), "conv grid out of range");
+    a.n_tiles = (int)n_tiles;
+    // One block per tile.  The kernel can also run as persistent blocks (fewer blocks than tiles: each walks a strided
+    // share), which is +0-6 % on short-K shapes in isolation -- but a static share per block is fragile when the wgrad
+    // stream holds some CUs: late-starting blocks then finish their whole share late (measured: a 317 -> 177 tiles/s outlier).
+    const long long grid = (g_pp_flags & 64) ? (n_tiles < kNumCU ? n_tiles : kNumCU) : n_tiles;
     if (a.dbg != nullptr && a.w_planes != nullptr)
         hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
     else if (a.dbg != nullptr)
