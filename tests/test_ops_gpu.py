@@ -470,3 +470,30 @@ def test_prepared_filter_planes_match_inline_split(dev):
         with torch.no_grad():
             ref.weight.copy_(conv.weight)
         assert torch.equal(y2, ref(x))
+
+
+def test_conv_kernel_variants_are_bit_identical(dev):
+    """The scheduling variants of one arithmetic must not change a single bit: ping-pong vs lock-step 256x128 forward /
+    dgrad kernel, and the uniform-geometry wgrad fast path vs the general path (same tiles, same reduction order)."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib, check
+    if lib.pylc_get_conv_precision() != 2:
+        pytest.skip('variants of the f16x3 kernels')
+    x = to_dev_nhwc(rnd(21, 8, 128, 64, 64), dev).requires_grad_(True)
+    w = to_dev_nhwc(rnd(22, 256, 128, 3, 3, scale=0.05), dev).requires_grad_(True)
+    dy = to_dev_nhwc(rnd(23, 8, 256, 64, 64), dev)
+    res = {}
+    for name, big, flags in (('default', 2, 0), ('lockstep', 1, 0), ('general_wgrad', 2, 8)):
+        lib.pylc_debug_set_big_tile(big)
+        lib.pylc_debug_pp_flags(flags)
+        x.grad = w.grad = None
+        y = ops.conv2d(x, w, None, 1, 1, 1)
+        y.backward(dy)
+        ops.sync_side_streams()
+        torch.cuda.synchronize()
+        res[name] = (y.detach().clone(), x.grad.clone(), w.grad.clone())
+    lib.pylc_debug_set_big_tile(2)
+    lib.pylc_debug_pp_flags(0)
+    for name in ('lockstep', 'general_wgrad'):
+        for a, b in zip(res['default'], res[name]):
+            assert torch.equal(a, b), name
