@@ -31,9 +31,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
         f32x4 k[9];
         load_taps(w, cv, k);
         for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            const int ow = (int)(r % d.OW);
-            const long long t = r / d.OW;
-            const int oh = (int)(t % d.OH), b = (int)(t / d.OH);
+            const unsigned r32 = (unsigned)r;                 // < 2^31 pixels (host check): 32-bit divisions, not 64-bit ones
+            const int ow = (int)(r32 % (unsigned)d.OW);
+            const unsigned t = r32 / (unsigned)d.OW;
+            const int oh = (int)(t % (unsigned)d.OH), b = (int)(t / (unsigned)d.OH);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kr = 0; kr < 3; ++kr) {
@@ -63,9 +64,10 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
         f32x4 k[9];
         load_taps(w, cv, k);
         for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            const int wi = (int)(r % d.W);
-            const long long t = r / d.W;
-            const int hi = (int)(t % d.H), b = (int)(t / d.H);
+            const unsigned r32 = (unsigned)r;
+            const int wi = (int)(r32 % (unsigned)d.W);
+            const unsigned t = r32 / (unsigned)d.W;
+            const int hi = (int)(t % (unsigned)d.H), b = (int)(t / (unsigned)d.H);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kr = 0; kr < 3; ++kr) {
@@ -103,9 +105,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) {
             for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-                const int ow = (int)(r % d.OW);
-                const long long t = r / d.OW;
-                const int oh = (int)(t % d.OH), b = (int)(t / d.OH);
+                const unsigned r32 = (unsigned)r;
+                const int ow = (int)(r32 % (unsigned)d.OW);
+                const unsigned t = r32 / (unsigned)d.OW;
+                const int oh = (int)(t % (unsigned)d.OH), b = (int)(t / (unsigned)d.OH);
                 const f32x4 gy = ld4(dy + r * d.y_pitch + 4 * cv);
 #pragma unroll
                 for (int kr = 0; kr < 3; ++kr) {
@@ -134,14 +137,24 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     }
 }
 
-// dw[c][t] = sum_slab partial[slab][t][c]
-__global__ void dw_wgrad_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ dw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 9*C, i = t*C + c
-    if (i >= 9 * C) return;
+// dw[c][t] = sum_slab partial[slab][t][c], fp64, fixed order: 8 columns x 32 slab lanes per block (a single thread walking
+// all slabs of its column is latency-bound: 250 us for 27 MB).
+__global__ __launch_bounds__(256) void dw_wgrad_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ dw) {
+    __shared__ double red[32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + tx;                        // over 9*C, i = t*C + c
     double acc = 0.0;
-    for (int s = 0; s < nslab; ++s) acc += (double)partial[(size_t)s * 9 * C + i];
-    const int t = i / C, c = i % C;
-    dw[c * 9 + t] = (float)acc;
+    if (i < 9 * C)
+        for (int s = ty; s < nslab; s += 32) acc += (double)partial[(size_t)s * 9 * C + i];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && i < 9 * C) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) sum += red[k][tx];
+        const int t = i / C, c = i % C;
+        dw[c * 9 + t] = (float)sum;
+    }
 }
 
 static int check_dw(const PylcDwDesc* d) {
@@ -150,6 +163,7 @@ static int check_dw(const PylcDwDesc* d) {
     PYLC_REQUIRE((d->stride == 1 || d->stride == 2) && d->dil >= 1, "dwconv: stride 1|2, dil >= 1");
     PYLC_REQUIRE(d->OH == (d->H - 1) / d->stride + 1 && d->OW == (d->W - 1) / d->stride + 1, "dwconv: OH/OW must be (H-1)/stride+1");
     PYLC_REQUIRE(d->x_pitch >= d->C && d->y_pitch >= d->C && d->x_pitch % 4 == 0 && d->y_pitch % 4 == 0, "dwconv: bad pitch");
+    PYLC_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "dwconv: more than 2^31 pixels");
     return PYLC_OK;
 }
 static DwGeom geom(const PylcDwDesc* d) { return DwGeom{d->B, d->H, d->W, d->C, d->stride, d->dil, d->OH, d->OW, d->x_pitch, d->y_pitch}; }
@@ -191,7 +205,7 @@ extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const f
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(dw_wgrad_kernel, dim3(g.nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), g);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_wgrad_combine_kernel, dim3(cdiv(9 * d->C, 256)), dim3(256), 0, st, static_cast<const float*>(workspace), g.nslab, d->C, dw);
+    hipLaunchKernelGGL(dw_wgrad_combine_kernel, dim3(cdiv(9 * d->C, 8)), dim3(256), 0, st, static_cast<const float*>(workspace), g.nslab, d->C, dw);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
