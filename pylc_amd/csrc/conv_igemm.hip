@@ -974,7 +974,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
 // counters) and the per-lane work per row is one add, one compare and one select; operands come through raw buffer loads
 // (out-of-range lanes read zeros, no branches, no 64-bit address arithmetic).  The general path recomputes (b, p, q) per
 // row with integer divisions every step, which cost more vector issue slots than the operand split itself.
-template <int BN, int BC, int WN, int WC, bool CIN4, int PREC, bool FAST>
+// FAST 2 (any OW >= 16): the same buffer-load scheme with per-row pixel coordinates kept as counters in every lane
+// (advance by 32 pixels per step with at most two row wraps) -- no divisions either, a few more vector instructions.
+template <int BN, int BC, int WN, int WC, bool CIN4, int PREC, int FAST>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) {
     constexpr int NPL = PREC == 2 ? 2 : 3;
     constexpr int WAVES_C = BC / WC;
@@ -1040,8 +1042,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) 
     int f_mb = m_begin, f_q0 = 0, f_p = 0, f_b = 0;
     unsigned f_va[FAST ? IA : 1], f_tx[FAST ? IB : 1];
     int f_wc[FAST ? IB : 1];
+    int g_q[FAST == 2 ? IB : 1], g_p[FAST == 2 ? IB : 1], g_b[FAST == 2 ? IB : 1];      // FAST 2: per-row pixel coordinates
     __amdgpu_buffer_rsrc_t rdy, rx;
-    if constexpr (FAST) {
+    if constexpr (FAST == 2) {
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int m = m_begin + prb + RB * i;
+            g_q[i] = m % a.Q;
+            const int t = m / a.Q;
+            g_p[i] = t % a.P;
+            g_b[i] = t / a.P;
+        }
+    }
+    if constexpr (FAST != 0) {
         rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
         rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(unsigned)a.x_bytes, 0x00020000);
         f_q0 = m_begin % a.Q;
@@ -1057,7 +1070,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradArgs a) 
         }
     }
     auto load_tile = [&](int s) {
-        if constexpr (FAST) {
+        if constexpr (FAST == 2) {
+            const unsigned colb = (unsigned)(c0 + 4 * vb);
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int hi = g_p[i] * a.in_sh + dh, wi = g_q[i] * a.in_sw + dw;
+                const bool ok = b_col_ok && f_mb + prb + RB * i < m_end && (unsigned)hi < (unsigned)a.IH && (unsigned)wi < (unsigned)a.IW;
+                const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch + colb) * 4u;
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : OOB, 0, 0));
+                g_q[i] += 32;
+                while (g_q[i] >= a.Q) { g_q[i] -= a.Q; ++g_p[i]; }
+                while (g_p[i] >= a.P) { g_p[i] -= a.P; ++g_b[i]; }
+            }
+            const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 4u;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const bool ok = f_mb + pra + RA * i < m_end;
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? f_va[i] : OOB, soff, 0));
+            }
+            f_mb += 32;
+            return;
+        }
+        if constexpr (FAST == 1) {
             // tile = 32 consecutive output pixels of row (f_b, f_p) starting at column f_q0
             const int hi = f_p * a.in_sh + dh;
             const bool row_ok = b_col_ok && (unsigned)hi < (unsigned)a.IH;
@@ -1346,13 +1380,16 @@ int conv_init() {
     PYLC_HIP(opt_in_lds(wgrad_kernel<32, 128, 32, 32, false>, wg_smem<32, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, true>, wg_smem<64, 64>()));
 #define PYLC_OPT_WG(P)                                                                                                \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, false>, wg16_smem<128, 128, P>()));          \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, false>, wg16_smem<64, 64, P>()));              \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, false>, wg16_smem<32, 128, P>()));            \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, true>, wg16_smem<128, 128, P>()));           \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, true>, wg16_smem<64, 64, P>()));               \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, true>, wg16_smem<32, 128, P>()));             \
-    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, true, P, false>, wg16_smem<64, 64, P>()));
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, 0>, wg16_smem<128, 128, P>()));              \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, 0>, wg16_smem<64, 64, P>()));                  \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, 0>, wg16_smem<32, 128, P>()));                \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, 1>, wg16_smem<128, 128, P>()));              \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, 1>, wg16_smem<64, 64, P>()));                  \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, 1>, wg16_smem<32, 128, P>()));                \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<128, 128, 64, 64, false, P, 2>, wg16_smem<128, 128, P>()));              \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, false, P, 2>, wg16_smem<64, 64, P>()));                  \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<32, 128, 32, 32, false, P, 2>, wg16_smem<32, 128, P>()));                \
+    PYLC_HIP(opt_in_lds(wgrad_split_kernel<64, 64, 32, 32, true, P, 0>, wg16_smem<64, 64, P>()));
     PYLC_OPT_WG(1)
     PYLC_OPT_WG(2)
 #undef PYLC_OPT_WG
@@ -1574,21 +1611,20 @@ extern "C" size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d) {
 template <int BN, int BC, int WN, int WC, bool CIN4>
 static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
-    const bool fast = !CIN4 && g_wgrad_fast && a.Q % 32 == 0 && a.x_bytes < 0xFFFFFFF0ll && a.dy_bytes < 0xFFFFFFF0ll;
-    if (g_conv_precision == 1) {
-        const size_t lds16 = wg16_smem<BN, BC, 1>();
-        if (fast) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1, !CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
-        else hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 1, false>), dim3((unsigned)grid), dim3(256), lds16, st, a);
-        PYLC_LAUNCH_CHECK();
-        return PYLC_OK;
+    const bool buf_ok = !CIN4 && g_wgrad_fast && a.x_bytes < 0xFFFFFFF0ll && a.dy_bytes < 0xFFFFFFF0ll;
+    const int fast = !buf_ok ? 0 : (a.Q % 32 == 0 ? 1 : (a.Q >= 16 ? 2 : 0));
+#define PYLC_LAUNCH_WG(P)                                                                                                             \
+    {                                                                                                                                  \
+        const size_t lds16 = wg16_smem<BN, BC, P>();                                                                                   \
+        if (fast == 1) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, P, CIN4 ? 0 : 1>), dim3((unsigned)grid), dim3(256), lds16, st, a); \
+        else if (fast == 2) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, P, CIN4 ? 0 : 2>), dim3((unsigned)grid), dim3(256), lds16, st, a); \
+        else hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, P, 0>), dim3((unsigned)grid), dim3(256), lds16, st, a);      \
+        PYLC_LAUNCH_CHECK();                                                                                                           \
+        return PYLC_OK;                                                                                                                \
     }
-    if (g_conv_precision == 2) {
-        const size_t lds16 = wg16_smem<BN, BC, 2>();
-        if (fast) hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2, !CIN4>), dim3((unsigned)grid), dim3(256), lds16, st, a);
-        else hipLaunchKernelGGL((wgrad_split_kernel<BN, BC, WN, WC, CIN4, 2, false>), dim3((unsigned)grid), dim3(256), lds16, st, a);
-        PYLC_LAUNCH_CHECK();
-        return PYLC_OK;
-    }
+    if (g_conv_precision == 1) PYLC_LAUNCH_WG(1)
+    if (g_conv_precision == 2) PYLC_LAUNCH_WG(2)
+#undef PYLC_LAUNCH_WG
     const size_t lds = wg_smem<BN, BC>();
     hipLaunchKernelGGL((wgrad_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
     PYLC_LAUNCH_CHECK();

@@ -479,21 +479,22 @@ def test_conv_kernel_variants_are_bit_identical(dev):
     from pylc_amd.lib import lib, check
     if lib.pylc_get_conv_precision() != 2:
         pytest.skip('variants of the f16x3 kernels')
-    x = to_dev_nhwc(rnd(21, 8, 128, 64, 64), dev).requires_grad_(True)
-    w = to_dev_nhwc(rnd(22, 256, 128, 3, 3, scale=0.05), dev).requires_grad_(True)
-    dy = to_dev_nhwc(rnd(23, 8, 256, 64, 64), dev)
-    res = {}
-    for name, big, flags in (('default', 2, 0), ('lockstep', 1, 0), ('general_wgrad', 2, 8)):
-        lib.pylc_debug_set_big_tile(big)
-        lib.pylc_debug_pp_flags(flags)
-        x.grad = w.grad = None
-        y = ops.conv2d(x, w, None, 1, 1, 1)
-        y.backward(dy)
-        ops.sync_side_streams()
-        torch.cuda.synchronize()
-        res[name] = (y.detach().clone(), x.grad.clone(), w.grad.clone())
-    lib.pylc_debug_set_big_tile(2)
-    lib.pylc_debug_pp_flags(0)
-    for name in ('lockstep', 'general_wgrad'):
-        for a, b in zip(res['default'], res[name]):
-            assert torch.equal(a, b), name
+    for hw in (64, 44):            # 64: row-aligned reduction tiles (uniform-geometry wgrad); 44: per-row counters
+        x = to_dev_nhwc(rnd(21, 8, 128, hw, hw), dev).requires_grad_(True)
+        w = to_dev_nhwc(rnd(22, 256, 128, 3, 3, scale=0.05), dev).requires_grad_(True)
+        dy = to_dev_nhwc(rnd(23, 8, 256, hw, hw), dev)
+        res = {}
+        for name, big, flags in (('default', 2, 0), ('lockstep', 1, 0), ('general_wgrad', 2, 8)):
+            lib.pylc_debug_set_big_tile(big)
+            lib.pylc_debug_pp_flags(flags)
+            x.grad = w.grad = None
+            y = ops.conv2d(x, w, None, 1, 1, 1)
+            y.backward(dy)
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            res[name] = (y.detach().clone(), x.grad.clone(), w.grad.clone())
+        lib.pylc_debug_set_big_tile(2)
+        lib.pylc_debug_pp_flags(0)
+        for name in ('lockstep', 'general_wgrad'):
+            for a, b in zip(res['default'], res[name]):
+                assert torch.equal(a, b), (hw, name)
