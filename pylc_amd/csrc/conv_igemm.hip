@@ -393,7 +393,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
     }
 
     // ---- epilogue: per-row output offsets through LDS, then 128-B coalesced row segments per half-wave ----
-    long long* rowoff = reinterpret_cast<long long*>(smem);
+    int* rowoff = reinterpret_cast<int*>(smem);            // element offsets of the tile's output rows (< 2^31: check_desc), -1 = no row
     if (tid < BM) {
         const int m = m0 + tid;
         long long off = -1;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
             const int p = t % a.P, b = t / a.P;
             off = ((long long)(b * a.OH + p * a.out_sh + a.oh0) * a.OW + q * a.out_sw + a.ow0) * a.y_pitch;
         }
-        rowoff[tid] = off;
+        rowoff[tid] = (int)off;
     }
     __syncthreads();
     // BatchNorm statistics ride along: each lane owns one output column of the wave tile, so the column sums of the
@@ -418,17 +418,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            int offs[16];
+            float prev[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = rowoff[row];
-                if (nok && off >= 0) {
+                offs[r] = rowoff[row];
+            }
+            if (a.accumulate) {      // all 16 old values first (independent loads), then add and store
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (nok && offs[r] >= 0) {
                     float val = acc[i][j][r];
                     if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
                     val += bv;
-                    float* dst = a.y + off + n;
-                    if (a.accumulate) val += *dst;
-                    *dst = val;
+                    if (a.accumulate) val += prev[r];
+                    a.y[offs[r] + n] = val;
                     cs += val;
                     css += val * val;
                 }
@@ -742,7 +750,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 #undef PP_STAMP
 
     // ---- epilogue (as gather_gemm_kernel) ----
-    long long* rowoff = reinterpret_cast<long long*>(smem);
+    int* rowoff = reinterpret_cast<int*>(smem);            // element offsets of the tile's output rows (< 2^31: check_desc), -1 = no row
     if (tid < BM) {
         const int m = m0 + tid;
         long long off = -1;
@@ -751,12 +759,20 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             const int p = t % a.P, b = t / a.P;
             off = ((long long)(b * a.OH + p * a.out_sh + a.oh0) * a.OW + q * a.out_sw + a.ow0) * a.y_pitch;
         }
-        rowoff[tid] = off;
+        rowoff[tid] = (int)off;
     }
     __syncthreads();
     float* sred = reinterpret_cast<float*>(smem) + 1024;
     const bool do_stats = a.stats != nullptr;
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+    // fold the cross-term accumulator in first: the store loops below then hold 128, not 256, accumulator registers
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
@@ -765,15 +781,25 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            int offs[16];
+            float prev[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long off = rowoff[row];
-                if (nok && off >= 0) {
-                    float val = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b + bv;
-                    float* dst = a.y + off + n;
-                    if (a.accumulate) val += *dst;
-                    *dst = val;
+                offs[r] = rowoff[row];
+            }
+            // accumulate: fetch all 16 old values first (independent loads in flight), then add and store -- interleaved
+            // load/store pairs serialise because the compiler cannot prove the rows distinct
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (nok && offs[r] >= 0) {
+                    float val = acc[i][j][r] + bv;
+                    if (a.accumulate) val += prev[r];
+                    a.y[offs[r] + n] = val;
                     cs += val;
                     css += val * val;
                 }

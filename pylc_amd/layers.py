@@ -32,8 +32,8 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training)
+    def forward(self, x, res_link=None):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training, res_link)
 
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,
@@ -70,12 +70,12 @@ class BatchNorm2d(nn.Module):
     def evaluate(cls, c):          # the reference's U-Net calls normalizer.evaluate(out_size) (unet.py:113,117)
         return cls(c)
 
-    def forward(self, y, residual=None, relu=False):
+    def forward(self, y, residual=None, relu=False, res_link=None):
         if self.training:
             self._nbt_pending += 1          # no per-layer device add: 113 tiny launches per step otherwise
         return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, residual, relu,
                           self.training, self.eps, self.momentum, runtime.sync_group if self.training else None,
-                          runtime.bn_clamp_eps)
+                          runtime.bn_clamp_eps, res_link)
 
     def flush_counter(self):
         if self._nbt_pending:

@@ -25,13 +25,16 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        # identity blocks: x's gradient = (residual branch of bn3) + (dgrad of conv1); the link makes conv1's dgrad
+        # accumulate into the buffer bn3's backward wrote instead of leaving two tensors for autograd to add
+        link = ops.ResidualLink() if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
+        out = self.bn1(self.conv1(x, res_link=link), relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         out = self.conv3(out)
         res = x
         if self.downsample is not None:
             res = self.downsample.child(1)(self.downsample.child(0)(x))
-        return self.bn3(out, residual=res, relu=True)      # relu(bn3(.) + residual) in one pass
+        return self.bn3(out, residual=res, relu=True, res_link=link)      # relu(bn3(.) + residual) in one pass
 
 
 class ResNet101(nn.Module):

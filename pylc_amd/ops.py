@@ -253,13 +253,29 @@ def weight_amax(w):
     return out
 
 
+class ResidualLink:
+    """Couples the two backward nodes that produce the gradient of an identity-residual block's input x:
+    BatchNorm(+residual x) and the block's first conv (input x).  Instead of two tensors that autograd then adds
+    (a 12 B/element pass), the BatchNorm backward parks its residual gradient here and the conv's dgrad accumulates
+    into that buffer in its epilogue (`accumulate`).  Armed by the conv's forward when x needs a gradient; autograd's
+    dependency order guarantees the BatchNorm backward runs first."""
+    __slots__ = ('armed', 'buf')
+
+    def __init__(self):
+        self.armed = False
+        self.buf = None
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None):
         L.init()
         ctx.set_materialize_grads(False)      # the auxiliary outputs (statistics, ranges) carry no gradient: no zero fills
+        ctx.res_link = res_link
+        if res_link is not None:
+            res_link.armed = bool(ctx.needs_input_grad[0]) and stride == 1
         x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
         cin = x.shape[1]
@@ -313,7 +329,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
@@ -340,7 +356,13 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             kp = _r4(cout)
-            dx = empty_nhwc(*x.shape, device=x.device)
+            link = ctx.res_link
+            sink = link.buf if link is not None else None
+            if sink is not None:            # the residual gradient is already in `sink`: dgrad adds to it (no autograd add pass)
+                link.buf = None
+                dx = sink
+            else:
+                dx = empty_nhwc(*x.shape, device=x.device)
             d.x_pitch = cin
             wt = None
             if lib.pylc_conv2d_dgrad_needs_f32_weights(C.byref(d)):      # else the prepared planes are all the kernel reads
@@ -352,7 +374,7 @@ class Conv2dFn(torch.autograd.Function):
                 ev = _timer.bracket(2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * r * s * cin, n_launch, 'dgrad%dx%d' % (r, s),
                                     4.0 * (dy.numel() + cout * r * s * cin + x.numel()))
                 ev[0].record()
-            check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, st))
+            check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 1 if sink is not None else 0, st))
             if ev is not None:
                 ev[1].record()
             d.x_pitch = pitch_of(x)
@@ -398,10 +420,10 @@ class Conv2dFn(torch.autograd.Function):
                 db = _deliver_grad(bias, tgt)
             else:
                 db = sums[:cout].clone()
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=None):
     """want_stats: also produce the per-channel (sum, sum of squares) of y in the conv epilogue and attach them to the
     returned tensor as `_pylc_sums` for the BatchNorm that consumes it (ops.bn_act picks them up)."""
     xa = wa = None
@@ -409,10 +431,10 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False):
         L.init()
         xa, wa = amax_of(x), weight_amax(w)
     if want_stats:
-        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa)
+        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link)
         y._pylc_sums = sums
         return y
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa)
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -480,9 +502,10 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None,
-                want_amax=False):
+                want_amax=False, res_link=None):
         L.init()
         ctx.set_materialize_grads(False)
+        ctx.res_link = res_link
         y = as_nhwc(y)
         b, c, h, w = y.shape
         m = b * h * w
@@ -541,7 +564,7 @@ class BnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         if dout is None:
-            return (None,) * 14
+            return (None,) * 15
         y, out, coef = ctx.saved_tensors
         relu, training, group, n_global, has_res = ctx.cfg
         gamma, beta = ctx.g_param, ctx.b_param
@@ -594,17 +617,23 @@ class BnActFn(torch.autograd.Function):
                     dbeta = _deliver_grad(beta, tb)
                 else:
                     dbeta = local_sums[c:].clone()
-        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None, None
+        link = ctx.res_link
+        if g_out is not None and link is not None and link.armed and link.buf is None and tuple(g_out.shape) == tuple(y.shape):
+            link.buf = g_out         # the first conv's dgrad accumulates into it and returns it as x's whole gradient
+            g_out = None
+        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
-           group=None, clamp_eps=False):
+           group=None, clamp_eps=False, res_link=None):
     pre = getattr(y, '_pylc_sums', None) if training else None
     if ranges_needed():
-        out, amax = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre, True)
+        out, amax = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
+                                  True, res_link)
         tag_amax(out, amax)
         return out
-    return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre)
+    return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
+                         False, res_link)
 
 
 class ReluFn(torch.autograd.Function):

@@ -58,7 +58,7 @@ for name, cin, cout, k, stride, pad, dil, b, h in SHAPES:
     flops = 2.0 * b * d.OH * d.OW * cout * k * k * cin
     fns = {
         'fwd': lambda: check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w), None, ptr(y), stream())),
-        'dgrad': lambda: check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, stream())),
+        'dgrad': lambda: check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dy), ptr(wt), ptr(dx), int(os.environ.get('PYLC_ACC', '0')), stream())),
         'wgrad': lambda: check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, stream())),
     }
     for kind in which:
