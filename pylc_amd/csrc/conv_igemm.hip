@@ -491,9 +491,13 @@ __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s
     p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
 }
 
-template <bool STAMPS, bool BPL>
+template <bool STAMPS, bool BPL, bool SWZ>
 __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
     constexpr int BM = PP_BM, BN = PP_BN, WM = 64, WN = 64, MT = 2, NT = 2, WAVES_N = 2;
+    // LDS rows: SWZ = unpadded 64-byte rows with the 16-byte chunk index XORed by bits 2-3 of the row (conflict-free
+    // ds_read_b128 fragments AND ds_write_b128 stores under the 16-lane / 8-lane group rules); !SWZ = rows padded to 80 bytes
+    constexpr int LDB = SWZ ? 64 : pylc::LDB;
+    constexpr int PP_STAGE = 2 * (BM + BN) * LDB;
     // STAMPS: waves 0 and 4 of block 0 record s_memtime at every segment boundary into LDS (dumped to a.dbg at the end)
     int n_stamp = 0;
 #define PP_STAMP()                                                                                                     \
@@ -617,8 +621,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         }
     };
     // stage layout: A plane 0 [256][LDB] | A plane 1 | B plane 0 [128][LDB] | B plane 1
-    char* st_a = lds + arow0 * LDB + 16 * v;
-    char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * v;
+    char* st_a = lds + arow0 * LDB + 16 * (SWZ ? (v ^ ((arow0 >> 2) & 3)) : v);
+    char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * (SWZ ? (v ^ ((brow >> 2) & 3)) : v);
     auto store = [&](int stage, const Regs& R) {
         char* base_a = st_a + stage * PP_STAGE;
         if constexpr (STAMPS) {
@@ -645,8 +649,10 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         *reinterpret_cast<uint4*>(base_b) = p0;
         *reinterpret_cast<uint4*>(base_b + BN * LDB) = p1;
     };
-    const char* ra_base = lds + (wave_m * WM + (lane & 31)) * LDB + 16 * (lane >> 5);
-    const char* rb_base = lds + 2 * BM * LDB + (wave_n * WN + (lane & 31)) * LDB + 16 * (lane >> 5);
+    const char* ra_base = lds + (wave_m * WM + (lane & 31)) * LDB;
+    const char* rb_base = lds + 2 * BM * LDB + (wave_n * WN + (lane & 31)) * LDB;
+    const int sw_r = SWZ ? ((lane >> 2) & 3) : 0;           // rows of one lane differ by multiples of 32: same swizzle
+    const int koff[2] = {16 * ((lane >> 5) ^ sw_r), 16 * (((lane >> 5) + 2) ^ sw_r)};
     auto compute = [&](int stage) {
         const char* pa = ra_base + stage * PP_STAGE;
         const char* pb = rb_base + stage * PP_STAGE;
@@ -657,12 +663,12 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 32 * LDB + 32 * ks);
+                    fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 32 * LDB + koff[ks]);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + 32 * ks);
+                    fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + koff[ks]);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1346,14 +1352,19 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     // share), which is +0-6 % on short-K shapes in isolation -- but a static share per block is fragile when the wgrad
     // stream holds some CUs: late-starting blocks then finish their whole share late (measured: a 317 -> 177 tiles/s outlier).
     const long long grid = (g_pp_flags & 64) ? (n_tiles < kNumCU ? n_tiles : kNumCU) : n_tiles;
+    const bool swz = !(g_pp_flags & 128);        // bit 7 (128): padded 80-byte LDS rows instead of the XOR-swizzled 64-byte rows (A/B)
     if (a.dbg != nullptr && a.w_planes != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
     else if (a.dbg != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
+    else if (a.w_planes != nullptr && swz)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     else if (a.w_planes != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+    else if (swz)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     else
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -1396,10 +1407,12 @@ int conv_init() {
     PYLC_OPT_GG(128, 32, 32, 32)
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false>), 2 * PP_STAGE + 4096));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, false>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, false>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false, false>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, false>), 2 * PP_STAGE + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));

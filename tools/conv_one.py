@@ -11,7 +11,7 @@ reps = int(sys.argv[10]) if len(sys.argv) > 10 else 3
 L.init()
 mode = int(os.environ.get('PYLC_MODE', '2'))
 check(lib.pylc_set_conv_precision(mode))
-lib.pylc_debug_set_big_tile(int(os.environ.get('PYLC_BIG', '1')))
+lib.pylc_debug_set_big_tile(int(os.environ.get('PYLC_BIG', '2')))
 dev = torch.device('cuda:0')
 x = torch.randn(b, h, h, cin, device=dev).permute(0, 3, 1, 2)
 w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).permute(0, 3, 1, 2)
@@ -23,6 +23,14 @@ check(lib.pylc_weight_transpose(ptr(w), ptr(wt), cout, k * k, cin, stream()))
 if mode == 2:
     rng = (ops.amax_of(x), ops.weight_amax(w), ops.amax_of(dy))
     d.x_amax, d.w_amax, d.dy_amax = (ptr(t) for t in rng)
+if mode == 2 and os.environ.get('PYLC_PLANES'):
+    kp = (cout + 3) & ~3
+    e = L.WPrepEntry(0, 0, 2 * cout * k * k * cin, 0, cout, k * k, cin, 0)
+    tab = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).clone().to(dev)
+    planes = torch.zeros(2 * cout * k * k * cin + 2 * cin * k * k * kp, dtype=torch.float16, device=dev)
+    check(lib.pylc_weight_prepare(ptr(w), ptr(tab), 1, k * k * ((cout + 31) // 32) * ((cin + 31) // 32), ptr(rng[1]), ptr(planes), stream()))
+    d.w_planes = planes.data_ptr()
+    d.w_planes_t = planes.data_ptr() + 2 * (2 * cout * k * k * cin)
 dx = ops.empty_nhwc(b, cin, h, h, dev)
 dw = torch.empty((cout, k, k, cin), device=dev)
 nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))

@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage: tools/pmc_ab.sh <outdir> <python args...>  -- two bounded rocprofv3 --pmc passes (SQ activity / instruction mix)
+# usage: tools/pmc_ab.sh <outdir> <python args...>  -- bounded rocprofv3 --pmc passes (SQ activity / instruction mix / LDS)
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 150 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $out/a -- python3 "$@" > /dev/null 2>&1
 timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM --output-format csv -d $out/b -- python3 "$@" > /dev/null 2>&1
+timeout 150 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/c -- python3 "$@" > /dev/null 2>&1
 python3 tools/pmc_summary.py $out
