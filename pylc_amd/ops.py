@@ -90,7 +90,7 @@ class KernelTimer:
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
-        self.KERNEL = 'gather_gemm_pp_kernel<false,true>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
+        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
