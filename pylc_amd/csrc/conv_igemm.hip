@@ -481,7 +481,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
 __device__ __attribute__((aligned(16))) float g_zero_page[8];      // zero-initialised: where masked-off lanes load from
 
 constexpr int PP_BM = 256, PP_BN = 128;
-constexpr int PP_STAGE = 2 * (PP_BM + PP_BN) * LDB;      // bytes per LDS stage (two fp16 planes per operand)
+constexpr int PP_STAGE = 2 * (PP_BM + PP_BN) * LDB;      // bytes per LDS stage (two fp16 planes per operand), 80-byte padded rows
+constexpr int PP_STAGE_SWZ = 2 * (PP_BM + PP_BN) * 64;   // ... with the unpadded swizzled rows: three stages fit
 
 __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s, uint4& p0, uint4& p1) {
     uint2 a0, a1, b0, b1;
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 #define PP_STAMP()                                                                                                     \
     if constexpr (STAMPS) {                                                                                            \
         if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && n_stamp < 256) {                                            \
-            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 2 * PP_STAGE)[(threadIdx.x >> 8) * 256 + n_stamp] = \
+            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (SWZ ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + n_stamp] = \
                 __builtin_amdgcn_s_memtime();                                                                          \
             ++n_stamp;                                                                                                 \
         }                                                                                                              \
@@ -683,6 +684,72 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     if (S > 0) {
         // Tiles t >= S are zero tiles (all lanes read the zero page): an odd S runs one harmless extra step and the
         // steady-state loop needs no tail conditions.
+#define PP_SYNC()                                \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __syncthreads();                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+        if constexpr (SWZ) {
+            // THREE LDS stages (48 KB each with the unpadded rows), ONE barrier per K-step.  Step s: every wave computes on
+            // the stage of tile s and stores its share of tile s+2 into the stage that tile s-1 vacated (last read before the
+            // previous barrier); tile s+1 was completed before that barrier too.  The two halves of the block do the two
+            // segments in opposite order, so on every SIMD one wave is in its MFMA segment while its partner splits / stores /
+            // loads -- with no barrier in the middle of the step for either to wait at.
+            load(R0, true);                                   // tile 0
+            load(R1, 1 < S);                                  // tile 1
+            store(0, R0);
+            store(1, R1);
+            load(R0, 2 < S);                                  // tile 2
+            load(R1, 3 < S);                                  // tile 3
+            __syncthreads();
+            int sc = 0;                                       // stage of the tile being computed
+            auto plus1 = [](int x) { return x == 2 ? 0 : x + 1; };
+            auto plus2 = [](int x) { return x == 0 ? 2 : x - 1; };
+            if (grp == 0) {
+                for (int s = 0; s < S; s += 2) {
+                    PP_STAMP();
+                    compute(sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP();
+                    store(plus2(sc), R0);                     // tile s+2
+                    load(R0, s + 4 < S);
+                    PP_STAMP();
+                    PP_SYNC();
+                    sc = plus1(sc);
+                    PP_STAMP();
+                    compute(sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP();
+                    store(plus2(sc), R1);                     // tile s+3
+                    load(R1, s + 5 < S);
+                    PP_STAMP();
+                    PP_SYNC();
+                    sc = plus1(sc);
+                }
+            } else {
+                for (int s = 0; s < S; s += 2) {
+                    PP_STAMP();
+                    store(plus2(sc), R0);
+                    load(R0, s + 4 < S);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP();
+                    compute(sc);
+                    PP_STAMP();
+                    PP_SYNC();
+                    sc = plus1(sc);
+                    PP_STAMP();
+                    store(plus2(sc), R1);
+                    load(R1, s + 5 < S);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PP_STAMP();
+                    compute(sc);
+                    PP_STAMP();
+                    PP_SYNC();
+                    sc = plus1(sc);
+                }
+            }
+        } else {
         load(R0, true);                                   // tile 0
         load(R1, 1 < S);                                  // tile 1
         store(0, R0);
@@ -690,12 +757,6 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         __syncthreads();
         // hipcc is free to sink MFMAs below an s_barrier (nothing orders them against it), which would smear each wave's
         // compute segment into its own store segment and undo the ping-pong: pin every segment boundary
-#define PP_SYNC()                                \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        __syncthreads();                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-    } while (0)
         // Each half alternates a compute segment (fragment reads + 24 MFMAs on the current stage) and a store segment (split +
         // LDS stores of the next tile, then the buffer loads of the tile after next into the register set just freed).
         // Invariant at the top of pair s: tile s complete in stage 0, stage 1 free, tile s+1 in R1, tile s+2 in flight into R0.
@@ -744,12 +805,13 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                 PP_SYNC();
             }
         }
+        }
 #undef PP_SYNC
         if constexpr (STAMPS) {
             if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && a.dbg != nullptr)
                 for (int k = 0; k < 256; ++k)
                     a.dbg[(threadIdx.x >> 8) * 256 + k] = k < n_stamp
-                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 2 * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
+                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (SWZ ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
             __syncthreads();
         }
     }
@@ -1353,16 +1415,18 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     // stream holds some CUs: late-starting blocks then finish their whole share late (measured: a 317 -> 177 tiles/s outlier).
     const long long grid = (g_pp_flags & 64) ? (n_tiles < kNumCU ? n_tiles : kNumCU) : n_tiles;
     const bool swz = !(g_pp_flags & 128);        // bit 7 (128): padded 80-byte LDS rows instead of the XOR-swizzled 64-byte rows (A/B)
-    if (a.dbg != nullptr && a.w_planes != nullptr)
+    if (a.dbg != nullptr && a.w_planes != nullptr && swz)
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ + 4096, st, a);
+    else if (a.dbg != nullptr && a.w_planes != nullptr)
         hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
     else if (a.dbg != nullptr)
         hipLaunchKernelGGL((gather_gemm_pp_kernel<true, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
     else if (a.w_planes != nullptr && swz)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ, st, a);
     else if (a.w_planes != nullptr)
         hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     else if (swz)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ, st, a);
     else
         hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
     PYLC_LAUNCH_CHECK();
@@ -1409,10 +1473,11 @@ int conv_init() {
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, false>), 2 * PP_STAGE));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, false>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true>), 3 * PP_STAGE_SWZ));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false, false>), 2 * PP_STAGE + 4096));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, false>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, true>), 3 * PP_STAGE_SWZ + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));

@@ -32,8 +32,8 @@ check(lib.pylc_conv2d_fwd(C.byref(d), ptr(x), ptr(w), None, ptr(y), stream()))
 torch.cuda.synchronize()
 lib.pylc_debug_pp_stamps(None)
 t = buf.cpu().view(2, 256)
-names = {0: ['compute0', 'bar', 'store1+load', 'bar', 'compute1', 'bar', 'store0+load', 'bar'],
-         1: ['store1+load', 'bar', 'compute0', 'bar', 'store0+load', 'bar', 'compute1', 'bar']}
+names = {0: ['compute', 'store+load', 'bar', 'compute', 'store+load', 'bar'],
+         1: ['store+load', 'compute', 'bar', 'store+load', 'compute', 'bar']}      # three-stage loop: one barrier per step
 if int(os.environ.get('PP_FLAGS', '0')) & 16:
     names = {0: ['compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar'],
              1: ['vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar']}
