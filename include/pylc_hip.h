@@ -307,7 +307,8 @@ int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long lo
 /* 0: 128x128 conv tiles only; 1: lock-step 256x128 8-wave tile; 2 (default): 256x128 ping-pong kernel for f16x3 */
 int pylc_debug_set_big_tile(int mode);
 /* bit 3 (8): wgrad without the uniform-geometry fast path; bit 4 (16): finer stamps (see pylc_debug_pp_stamps);
- * bit 6 (64): ping-pong kernel as persistent blocks (one per CU) instead of one block per tile */
+ * bit 6 (64): ping-pong kernel as persistent blocks (one per CU) instead of one block per tile; bit 7 (128): padded
+ * 80-byte LDS rows and two stages instead of swizzled 64-byte rows and three; bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs */
 int pylc_debug_pp_flags(int flags);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */

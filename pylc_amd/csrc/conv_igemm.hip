@@ -17,6 +17,7 @@
 // models/modules/aspp.py:18,64,67, models/decoder.py:27-38, models/architectures/unet.py:78,112,116,137,
 // models/backbone/xception.py:32,48,122,126 and their autograd backward.
 #include "common.h"
+#include <type_traits>
 
 namespace pylc {
 
@@ -492,8 +493,14 @@ __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s
     p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
 }
 
-template <bool STAMPS, bool BPL, bool SWZ>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// M16 (with SWZ): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- same FLOPs per
+// matrix-pipe cycle, same LDS traffic, but 16 % more sustained throughput at the board's power cap (bare loops on random
+// data: 2005 vs 1690 TFLOP/s, tools/micro/mfma_shapes.hip).  Wave tile 64x64 = 4x4 tiles of 16x16.
+template <bool STAMPS, bool BPL, bool SWZ, bool M16>
 __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
+    static_assert(!M16 || SWZ, "the 16x16x32 variant uses the unpadded swizzled LDS rows");
     constexpr int BM = PP_BM, BN = PP_BN, WM = 64, WN = 64, MT = 2, NT = 2, WAVES_N = 2;
     // LDS rows: SWZ = unpadded 64-byte rows with the 16-byte chunk index XORed by bits 2-3 of the row (conflict-free
     // ds_read_b128 fragments AND ds_write_b128 stores under the 16-lane / 8-lane group rules); !SWZ = rows padded to 80 bytes
@@ -554,13 +561,15 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     const int ntaps = __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
     const int S = ntaps * nchunks;
 
-    f32x16 acc[MT][NT], acc_lo[MT][NT];
+    constexpr int AT = M16 ? 4 : 2, AR = M16 ? 4 : 16;      // accumulator tiles per wave-tile side, registers per tile
+    using acc_t = typename std::conditional<M16, f32x4v, f32x16>::type;
+    acc_t acc[AT][AT], acc_lo[AT][AT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < AT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc_lo[i][j][r] = 0.f; }
+            for (int r = 0; r < AR; ++r) { acc[i][j][r] = 0.f; acc_lo[i][j][r] = 0.f; }
     const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
     const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
 
@@ -622,8 +631,12 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         }
     };
     // stage layout: A plane 0 [256][LDB] | A plane 1 | B plane 0 [128][LDB] | B plane 1
-    char* st_a = lds + arow0 * LDB + 16 * (SWZ ? (v ^ ((arow0 >> 2) & 3)) : v);
-    char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * (SWZ ? (v ^ ((brow >> 2) & 3)) : v);
+    // chunk swizzle of a row: conflict-free for the fragment pattern in use (32-row fragments: bits 2-3 of the row;
+    // 16-row fragments of the 16x16x32 MFMA: bit 2 of the row into bit 1 of the chunk -- found by exhaustive search over
+    // the XOR-linear maps against the ds_read_b128 lane groups)
+    auto swz = [](int row) { return M16 ? (((row >> 2) & 1) << 1) : ((row >> 2) & 3); };
+    char* st_a = lds + arow0 * LDB + 16 * (SWZ ? (v ^ swz(arow0)) : v);
+    char* st_b = lds + 2 * BM * LDB + brow * LDB + 16 * (SWZ ? (v ^ swz(brow)) : v);
     auto store = [&](int stage, const Regs& R) {
         char* base_a = st_a + stage * PP_STAGE;
         if constexpr (STAMPS) {
@@ -650,34 +663,55 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         *reinterpret_cast<uint4*>(base_b) = p0;
         *reinterpret_cast<uint4*>(base_b + BN * LDB) = p1;
     };
-    const char* ra_base = lds + (wave_m * WM + (lane & 31)) * LDB;
-    const char* rb_base = lds + 2 * BM * LDB + (wave_n * WN + (lane & 31)) * LDB;
-    const int sw_r = SWZ ? ((lane >> 2) & 3) : 0;           // rows of one lane differ by multiples of 32: same swizzle
-    const int koff[2] = {16 * ((lane >> 5) ^ sw_r), 16 * (((lane >> 5) + 2) ^ sw_r)};
+    const char* ra_base = lds + (wave_m * WM + (lane & (M16 ? 15 : 31))) * LDB;
+    const char* rb_base = lds + 2 * BM * LDB + (wave_n * WN + (lane & (M16 ? 15 : 31))) * LDB;
+    const int sw_r = SWZ ? swz(lane & 31) : 0;           // rows of one lane differ by multiples of 16 / 32: same swizzle
+    const int koff[2] = {M16 ? 16 * ((lane >> 4) ^ sw_r) : 16 * ((lane >> 5) ^ sw_r), 16 * (((lane >> 5) + 2) ^ sw_r)};
     auto compute = [&](int stage) {
         const char* pa = ra_base + stage * PP_STAGE;
         const char* pb = rb_base + stage * PP_STAGE;
+        if constexpr (M16) {
+            // lane l: row (l & 15) of a 16-row fragment, reduction elements 8 (l >> 4) .. +7 of the 32-deep step
+            f16x8 fb[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 fa[MT][2], fb[NT][2];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int pl = 0; pl < 2; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 16 * LDB + koff[0]);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 32 * LDB + koff[ks]);
+            for (int i = 0; i < 4; ++i) {
+                f16x8 fa[2];
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+                for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 16 * LDB + koff[0]);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + koff[ks]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc_lo[i][j], 0, 0, 0);
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc_lo[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[j][0], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][1], acc_lo[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][0], acc[i][j], 0, 0, 0);
                 }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 fa[MT][2], fb[NT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 32 * LDB + koff[ks]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * LDB + j * 32 * LDB + koff[ks]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc_lo[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     };
 
@@ -835,35 +869,39 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
     // fold the cross-term accumulator in first: the store loops below then hold 128, not 256, accumulator registers
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < AT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+            for (int r = 0; r < AR; ++r) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
     __builtin_amdgcn_sched_barrier(0);
+    // accumulator layout: 32x32 tiles -- lane l holds column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5);
+    //                     16x16 tiles -- lane l holds column l & 15, rows 4 (l >> 4) + r
+    constexpr int TS = M16 ? 16 : 32;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
+    for (int j = 0; j < AT; ++j) {
+        const int n = n0 + wave_n * WN + j * TS + (lane & (TS - 1));
         const bool nok = n < a.N_store;
         const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
         float cs = 0.f, css = 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int offs[16];
-            float prev[16];
+        for (int i = 0; i < AT; ++i) {
+            int offs[AR];
+            float prev[AR];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < AR; ++r) {
+                const int row = M16 ? wave_m * WM + i * 16 + 4 * (lane >> 4) + r
+                                    : wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 offs[r] = rowoff[row];
             }
-            // accumulate: fetch all 16 old values first (independent loads in flight), then add and store -- interleaved
+            // accumulate: fetch all old values first (independent loads in flight), then add and store -- interleaved
             // load/store pairs serialise because the compiler cannot prove the rows distinct
             if (a.accumulate) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
+                for (int r = 0; r < AR; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < AR; ++r) {
                 if (nok && offs[r] >= 0) {
                     float val = acc[i][j][r] + bv;
                     if (a.accumulate) val += prev[r];
@@ -874,10 +912,13 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             }
         }
         if (do_stats) {
-            cs += __shfl_xor(cs, 32, 64);
+            if constexpr (M16) {                                    // lanes l, l+16, l+32, l+48 hold the same column
+                cs += __shfl_xor(cs, 16, 64); css += __shfl_xor(css, 16, 64);
+            }
+            cs += __shfl_xor(cs, 32, 64);                           // lanes l and l+32 hold the same column
             css += __shfl_xor(css, 32, 64);
-            if (lane < 32) {
-                float* d = sred + ((wave_m * BN) + wave_n * WN + j * 32 + lane) * 2;
+            if (lane < TS) {
+                float* d = sred + ((wave_m * BN) + wave_n * WN + j * TS + lane) * 2;
                 d[0] = cs;
                 d[1] = css;
             }
@@ -1414,21 +1455,25 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     // share), which is +0-6 % on short-K shapes in isolation -- but a static share per block is fragile when the wgrad
     // stream holds some CUs: late-starting blocks then finish their whole share late (measured: a 317 -> 177 tiles/s outlier).
     const long long grid = (g_pp_flags & 64) ? (n_tiles < kNumCU ? n_tiles : kNumCU) : n_tiles;
-    const bool swz = !(g_pp_flags & 128);        // bit 7 (128): padded 80-byte LDS rows instead of the XOR-swizzled 64-byte rows (A/B)
-    if (a.dbg != nullptr && a.w_planes != nullptr && swz)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ + 4096, st, a);
-    else if (a.dbg != nullptr && a.w_planes != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
-    else if (a.dbg != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<true, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE + 4096, st, a);
-    else if (a.w_planes != nullptr && swz)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ, st, a);
-    else if (a.w_planes != nullptr)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
-    else if (swz)
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true>), dim3((unsigned)grid), dim3(512), 3 * PP_STAGE_SWZ, st, a);
-    else
-        hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, false>), dim3((unsigned)grid), dim3(512), 2 * PP_STAGE, st, a);
+    const bool swz = !(g_pp_flags & 128);        // bit 7 (128): padded 80-byte LDS rows, two stages (A/B)
+    const bool m16 = swz && !(g_pp_flags & 256); // bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs (A/B)
+    const bool bpl = a.w_planes != nullptr;
+    const dim3 g((unsigned)grid), b(512);
+#define PYLC_PP(ST, BP, SW, M) hipLaunchKernelGGL((gather_gemm_pp_kernel<ST, BP, SW, M>), g, b, ((SW) ? 3 * PP_STAGE_SWZ : 2 * PP_STAGE) + ((ST) ? 4096 : 0), st, a)
+    if (a.dbg != nullptr) {                      // stamped builds (tools/pp_stamps.py): 32x32x16 forms only
+        if (bpl && swz) PYLC_PP(true, true, true, false);
+        else if (bpl) PYLC_PP(true, true, false, false);
+        else PYLC_PP(true, false, false, false);
+    } else if (bpl) {
+        if (m16) PYLC_PP(false, true, true, true);
+        else if (swz) PYLC_PP(false, true, true, false);
+        else PYLC_PP(false, true, false, false);
+    } else {
+        if (m16) PYLC_PP(false, false, true, true);
+        else if (swz) PYLC_PP(false, false, true, false);
+        else PYLC_PP(false, false, false, false);
+    }
+#undef PYLC_PP
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -1471,13 +1516,15 @@ int conv_init() {
     PYLC_OPT_GG(128, 32, 32, 32)
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 1>, gg_smem<256, 128, 1>()));
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<256, 128, 64, 64, false, 2>, gg_smem<256, 128, 2>()));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, false>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, false>), 2 * PP_STAGE));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true>), 3 * PP_STAGE_SWZ));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true>), 3 * PP_STAGE_SWZ));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false, false>), 2 * PP_STAGE + 4096));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, false>), 2 * PP_STAGE + 4096));
-    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, true>), 3 * PP_STAGE_SWZ + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, false, false>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, false, false>), 2 * PP_STAGE));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true, true>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true, true>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true, false>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true, false>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false, false, false>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, false, false>), 2 * PP_STAGE + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, true, false>), 3 * PP_STAGE_SWZ + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));
