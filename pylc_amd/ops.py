@@ -8,6 +8,7 @@ kernels; if libpylc_hip.so is missing, importing ``pylc_amd.lib`` already failed
 import ctypes as C
 
 import os
+import time
 import torch
 import torch.distributed as dist
 
@@ -165,10 +166,34 @@ class _nullcontext:
 _side_streams = {}
 
 
+def _runs_concurrently(cand, device):
+    """True if work on `cand` executes while the current stream is busy, i.e. the two HIP streams sit on different
+    hardware queues.  HIP multiplexes streams onto a few hardware queues in creation order, so a fresh stream can land on
+    the compute stream's queue -- observed once RCCL had created its streams -- and would then serialise behind it."""
+    try:
+        torch.cuda._sleep(30_000_000)                  # ~15 ms busy-wait kernel on the current stream
+    except (AttributeError, RuntimeError):
+        return True                                    # cannot probe: take the stream as it is
+    with torch.cuda.stream(cand):
+        torch.zeros(1, device=device)
+        ev = torch.cuda.Event()
+        ev.record()
+    time.sleep(0.003)
+    ok = ev.query()
+    torch.cuda.synchronize(device)
+    return ok
+
+
 def _side_stream(device):
     key = torch.device(device).index
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)      # (stream priorities made no measurable difference)
+        cands = []
+        for _ in range(8):
+            st = torch.cuda.Stream(device=device)
+            cands.append(st)                          # keep the rejected ones alive so the next candidate is a new stream
+            if _runs_concurrently(st, device):
+                break
+        _side_streams[key] = cands[-1]
     return _side_streams[key]
 
 
