@@ -197,6 +197,13 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+def side_stream_if_any(device):
+    """The wgrad side stream of `device` if one has been created (None on CPU / before the first backward)."""
+    if not torch.device(device).type == 'cuda':
+        return None
+    return _side_streams.get(torch.device(device).index)
+
+
 def sync_side_streams():
     """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
     all-reduce reads the arena)."""

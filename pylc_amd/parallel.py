@@ -95,9 +95,19 @@ class GradBucketer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.pending[b] = -1
-        from .ops import sync_side_streams
-        sync_side_streams()          # this bucket's conv gradients were produced on the wgrad side stream
-        self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        # The bucket holds conv gradients written on the wgrad side stream and BatchNorm gradients written on the compute
+        # stream.  The collective is ordered after BOTH by enqueueing it from the side stream once that stream has been
+        # told to wait for the compute stream's current position -- the compute stream itself never waits here.
+        from . import ops
+        side = ops.side_stream_if_any(self.arena.g.device)
+        if side is None:
+            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Launch whatever did not complete on its own (parameters without a gradient this step) and wait for all."""
