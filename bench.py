@@ -117,7 +117,12 @@ def main():
         d_s = time.perf_counter() - t_s
         best = min(best, d_s)
         streak = streak + 1 if d_s <= 1.02 * best else 0
-        if streak >= 3:
+        done = streak >= 3
+        if world > 1:       # every rank must run the same number of steps (each step contains collectives): stop only when all agree
+            flag = torch.tensor([0.0 if done else 1.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            done = flag.item() == 0.0
+        if done:
             break
     for _ in range(args.warmup):
         model.train(x, y)
