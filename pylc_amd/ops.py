@@ -416,7 +416,8 @@ class Conv2dFn(torch.autograd.Function):
             side = _side_stream(x.device) if _runtime.wgrad_side_stream else None
             if side is not None:
                 ev = torch.cuda.Event()      # recorded AFTER the dgrad launch: wgrad starts when the dgrad is done (letting it
-                ev.record()                  # start next to the dgrad was measured 5 % slower: both are matrix-bound)
+                ev.record()                  # start next to the dgrad was measured 5 % slower, making every dgrad wait for the
+                                             # previous wgrad 2 % slower)
                 side.wait_event(ev)
                 x.record_stream(side)
                 dy.record_stream(side)
