@@ -91,7 +91,7 @@ class KernelTimer:
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
-        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
+        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true,true>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -171,7 +171,7 @@ def _runs_concurrently(cand, device):
     hardware queues.  HIP multiplexes streams onto a few hardware queues in creation order, so a fresh stream can land on
     the compute stream's queue -- observed once RCCL had created its streams -- and would then serialise behind it."""
     try:
-        torch.cuda._sleep(30_000_000)                  # ~15 ms busy-wait kernel on the current stream
+        torch.cuda._sleep(6_000_000)                   # ~14 ms busy-wait kernel on the current stream
     except (AttributeError, RuntimeError):
         return True                                    # cannot probe: take the stream as it is
     with torch.cuda.stream(cand):

@@ -4,6 +4,8 @@ exchange is a handful of large RCCL all-reduces instead of 341 small ones.
 
 Replaces torch.optim.AdamW / SGD + clip_grad_norm_ as used at models/model.py:238-254,322-328 and
 StepLR at models/model.py:256-263 / train.py:91."""
+import weakref
+
 import torch
 
 from . import lib as L
@@ -69,7 +71,8 @@ class FlatArena:
                 k, c, r, s_ = p.shape
                 p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
                                   self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
-        module.register_load_state_dict_post_hook(lambda *_: self.refresh_ranges())
+        me = weakref.ref(self)           # no module -> arena strong reference: a dropped model frees its memory by refcount
+        module.register_load_state_dict_post_hook(lambda *_: me() is not None and me().refresh_ranges())
         self.refresh_ranges()
 
     def refresh_ranges(self):

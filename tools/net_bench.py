@@ -29,4 +29,5 @@ for name in (sys.argv[1:] or list(CFG)):
     print('%-28s train %7.1f ms/step %7.1f tiles/s | inference %7.1f ms/batch %7.1f tiles/s | peak mem %.1f GB' % (
         name, dt * 1e3, b / dt, di * 1e3, b / di, torch.cuda.max_memory_allocated() / 2**30), flush=True)
     del model, x, y
+    import gc; gc.collect()          # the arena <-> module hook cycle needs the collector
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
