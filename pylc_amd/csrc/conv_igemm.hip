@@ -498,8 +498,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // M16 (with SWZ): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- same FLOPs per
 // matrix-pipe cycle, same LDS traffic, but 16 % more sustained throughput at the board's power cap (bare loops on random
 // data: 2005 vs 1690 TFLOP/s, tools/micro/mfma_shapes.hip).  Wave tile 64x64 = 4x4 tiles of 16x16.
-template <bool STAMPS, bool BPL, bool SWZ, bool M16>
+template <bool STAMPS, bool BPL, bool SWZ, bool M16, bool S3 = SWZ>
 __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
+    static_assert(!S3 || SWZ, "three stages need the unpadded rows");
     static_assert(!M16 || SWZ, "the 16x16x32 variant uses the unpadded swizzled LDS rows");
     constexpr int BM = PP_BM, BN = PP_BN, WM = 64, WN = 64, MT = 2, NT = 2, WAVES_N = 2;
     // LDS rows: SWZ = unpadded 64-byte rows with the 16-byte chunk index XORed by bits 2-3 of the row (conflict-free
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 #define PP_STAMP()                                                                                                     \
     if constexpr (STAMPS) {                                                                                            \
         if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && n_stamp < 256) {                                            \
-            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (SWZ ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + n_stamp] = \
+            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (S3 ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + n_stamp] = \
                 __builtin_amdgcn_s_memtime();                                                                          \
             ++n_stamp;                                                                                                 \
         }                                                                                                              \
@@ -724,8 +725,9 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         __syncthreads();                         \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
-        if constexpr (SWZ) {
-            // THREE LDS stages (48 KB each with the unpadded rows), ONE barrier per K-step.  Step s: every wave computes on
+        if constexpr (S3) {
+            // THREE LDS stages (48 KB each with the unpadded rows), ONE barrier per K-step.  (Two swizzled stages = 96 KB would let
+            // a wgrad block share the CU; measured inside the full step: 326 vs 329 tiles/s, so three it is.)  Step s: every wave computes on
             // the stage of tile s and stores its share of tile s+2 into the stage that tile s-1 vacated (last read before the
             // previous barrier); tile s+1 was completed before that barrier too.  The two halves of the block do the two
             // segments in opposite order, so on every SIMD one wave is in its MFMA segment while its partner splits / stores /
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && a.dbg != nullptr)
                 for (int k = 0; k < 256; ++k)
                     a.dbg[(threadIdx.x >> 8) * 256 + k] = k < n_stamp
-                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (SWZ ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
+                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (S3 ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
             __syncthreads();
         }
     }
