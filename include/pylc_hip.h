@@ -106,7 +106,15 @@ int pylc_amax_segments(const float* base, const long long* offsets, int count, u
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */
 int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
                     float* y, void* stream);
-/* Same, and additionally emits per-M-tile partial column sums of y for the BatchNorm that follows (saves a full read
+/* Inference: y = act(conv(x, w) * scale[c] + shift[c] (+ residual)), relu != 0 applies max(., 0) -- eval-mode BatchNorm
+ * (scale / shift from pylc_bn_eval_coeffs), the residual add of a ResNet block and the ReLU, all in the conv epilogue
+ * (models/backbone/resnet.py:36-51 in eval mode).  residual (may be NULL) has y's geometry and pitch.  amax_out (may be
+ * NULL; zero-initialised by the caller) is max-accumulated with the range of y.  Bit-identical to pylc_conv2d_fwd followed
+ * by pylc_bn_apply. */
+int pylc_conv2d_fwd_bnact(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
+                          const float* scale, const float* shift, const float* residual, int relu, float* y,
+                          unsigned int* amax_out, void* stream);
+/* pylc_conv2d_fwd that additionally emits per-M-tile partial column sums of y for the BatchNorm that follows (saves a full read
  * of y): stats_partial has pylc_conv2d_fwd_stats_floats(d) floats, laid out [rows][2][roundup4(Cout)] = (sum | sum of
  * squares); *stats_rows receives the number of rows written.  Combine with pylc_bn_stats_from_partial. */
 size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d);

@@ -102,6 +102,13 @@ struct GatherGemmArgs {
     int N, N_store;         // valid output channels / channels written (N rounded up to 4 inside the pitch)
     int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
     int accumulate;
+    // fused inference epilogue (pylc_conv2d_fwd_bnact): val = relu(val * ep_scale[n] + ep_shift[n] + ep_res[...]); ep_amax
+    // (zero-initialised by the caller) is max-accumulated with the range of what is stored
+    const float* ep_scale;
+    const float* ep_shift;
+    const float* ep_res;    // same geometry and pitch as y
+    unsigned* ep_amax;
+    int ep_relu;
     int tiles_n;
     int n_tiles;            // tiles_m * tiles_n (the persistent ping-pong kernel walks them)
     const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
@@ -409,6 +416,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
     // BatchNorm statistics ride along: each lane owns one output column of the wave tile, so the column sums of the
     // values just computed cost 2 FMAs per element here instead of a separate full read of y
     float* sred = reinterpret_cast<float*>(smem) + 1024;          // [BM/WM][BN][2], past the row table
+    float ep_max = 0.f;
     const bool do_stats = a.stats != nullptr;
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;     // exact (powers of two); applied one after the other
 #pragma unroll
@@ -416,6 +424,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
         const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
         const bool nok = n < a.N_store;
         const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+        const bool ep = a.ep_scale != nullptr;
+        const float esc = (ep && n < a.N) ? a.ep_scale[n] : 0.f, esh = (ep && n < a.N) ? a.ep_shift[n] : 0.f;
         float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -426,9 +436,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                 const int row = wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 offs[r] = rowoff[row];
             }
-            if (a.accumulate) {      // all 16 old values first (independent loads), then add and store
+            const float* extra = a.accumulate ? a.y : a.ep_res;      // old output (accumulate) or the residual (fused epilogue)
+            if (extra != nullptr) {  // all 16 values first (independent loads), then add and store
 #pragma unroll
-                for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
+                for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? extra[offs[r] + n] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -436,10 +447,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                     float val = acc[i][j][r];
                     if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
                     val += bv;
-                    if (a.accumulate) val += prev[r];
+                    if (ep) val = val * esc + esh;                   // BatchNorm-apply's own expression and order
+                    if (extra != nullptr) val += prev[r];
+                    if (a.ep_relu) val = fmaxf(val, 0.f);
                     a.y[offs[r] + n] = val;
                     cs += val;
                     css += val * val;
+                    ep_max = fmaxf(ep_max, fabsf(val));
                 }
             }
         }
@@ -467,6 +481,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
             }
         }
     }
+    if (a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -867,6 +882,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     }
     __syncthreads();
     float* sred = reinterpret_cast<float*>(smem) + 1024;
+    float ep_max = 0.f;
     const bool do_stats = a.stats != nullptr;
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
     // fold the cross-term accumulator in first: the store loops below then hold 128, not 256, accumulator registers
@@ -885,6 +901,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         const int n = n0 + wave_n * WN + j * TS + (lane & (TS - 1));
         const bool nok = n < a.N_store;
         const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+        const bool ep = a.ep_scale != nullptr;
+        const float esc = (ep && n < a.N) ? a.ep_scale[n] : 0.f, esh = (ep && n < a.N) ? a.ep_shift[n] : 0.f;
         float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < AT; ++i) {
@@ -896,20 +914,24 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                                     : wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 offs[r] = rowoff[row];
             }
-            // accumulate: fetch all old values first (independent loads in flight), then add and store -- interleaved
-            // load/store pairs serialise because the compiler cannot prove the rows distinct
-            if (a.accumulate) {
+            // accumulate / fused residual: fetch all values first (independent loads in flight), then add and store --
+            // interleaved load/store pairs serialise because the compiler cannot prove the rows distinct
+            const float* extra = a.accumulate ? a.y : a.ep_res;
+            if (extra != nullptr) {
 #pragma unroll
-                for (int r = 0; r < AR; ++r) prev[r] = (nok && offs[r] >= 0) ? a.y[offs[r] + n] : 0.f;
+                for (int r = 0; r < AR; ++r) prev[r] = (nok && offs[r] >= 0) ? extra[offs[r] + n] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < AR; ++r) {
                 if (nok && offs[r] >= 0) {
                     float val = acc[i][j][r] + bv;
-                    if (a.accumulate) val += prev[r];
+                    if (ep) val = val * esc + esh;                   // BatchNorm-apply's own expression and order
+                    if (extra != nullptr) val += prev[r];
+                    if (a.ep_relu) val = fmaxf(val, 0.f);
                     a.y[offs[r] + n] = val;
                     cs += val;
                     css += val * val;
+                    ep_max = fmaxf(ep_max, fabsf(val));
                 }
             }
         }
@@ -940,6 +962,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             }
         }
     }
+    if (a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
     __syncthreads();          // the next tile reuses the LDS stages and the epilogue tables
     }
 }
@@ -1588,11 +1611,24 @@ extern "C" int pylc_debug_pp_flags(int flags) { g_pp_flags = flags; g_wgrad_fast
 // tuning knob (tools/conv_bench.py): allow / forbid the 256x128 8-wave tile
 extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
 
+namespace {
+struct FwdEpilogue { const float* scale; const float* shift; const float* res; unsigned* amax; int relu; };
+}
 static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
-                           void* stream);
+                           void* stream, const FwdEpilogue* ep = nullptr);
 
 extern "C" int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, void* stream) {
     return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, stream);
+}
+
+// Inference: y = act(conv(x, w) * scale + shift (+ residual)) in the conv epilogue -- eval-mode BatchNorm (scale / shift
+// from pylc_bn_eval_coeffs), the residual add and the ReLU without a separate pass over y.  Same expression and order as
+// pylc_bn_apply, so the result is bit-identical to conv followed by bn_apply.
+extern "C" int pylc_conv2d_fwd_bnact(const PylcConvDesc* d, const float* x, const float* w, const float* bias, const float* scale,
+                                     const float* shift, const float* residual, int relu, float* y, unsigned int* amax_out, void* stream) {
+    PYLC_REQUIRE(scale && shift, "conv2d_fwd_bnact: null scale / shift");
+    const FwdEpilogue ep{scale, shift, residual, amax_out, relu};
+    return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, stream, &ep);
 }
 
 extern "C" size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d) {
@@ -1608,10 +1644,11 @@ extern "C" int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, cons
 }
 
 static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
-                           void* stream) {
+                           void* stream, const FwdEpilogue* ep) {
     if (int rc = check_desc(d)) return rc;
     PYLC_REQUIRE(x && w && y, "null pointer");
     GatherGemmArgs a{};
+    if (ep != nullptr) { a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_res = ep->res; a.ep_amax = ep->amax; a.ep_relu = ep->relu; }
     a.stats = stats;
     a.dbg = g_pp_stamps;
     a.dbg_flags = g_pp_flags;

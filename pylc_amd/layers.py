@@ -94,6 +94,16 @@ class BatchNorm2d(nn.Module):
         return '%d' % self.num_features
 
 
+def conv_bn(conv, bn, x, residual=None, relu=False, conv_link=None):
+    """bn(conv(x), residual, relu).  In inference (eval mode, autograd off) the BatchNorm, the residual add and the ReLU run
+    inside the conv epilogue (ops.conv_bn_act_eval); otherwise the two modules are called as usual."""
+    if (not bn.training and not torch.is_grad_enabled() and runtime.fuse_eval_bn and conv.cin % 4 == 0
+            and (residual is None or ops.pitch_of(ops.as_nhwc(residual)) == ((conv.cout + 3) & ~3))):
+        return ops.conv_bn_act_eval(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn.running_mean,
+                                    bn.running_var, bn.weight, bn.bias, bn.eps, residual, relu)
+    return bn(conv(x, res_link=conv_link), residual=residual, relu=relu)
+
+
 class Dropout(nn.Module):
     def __init__(self, p):
         super().__init__()

@@ -56,6 +56,7 @@ SIGNATURES = {
     'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),
     'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    'pylc_conv2d_fwd_bnact': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     'pylc_conv2d_fwd_stats_floats': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd_stats': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(_I), _P]),
     'pylc_conv2d_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),

@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..layers import Conv2d, BatchNorm2d, Dropout, Named
+from ..layers import Conv2d, BatchNorm2d, Dropout, Named, conv_bn
 from .encoder_resnet import ResNet101
 from .encoder_xception import AlignedXception
 
@@ -19,7 +19,7 @@ class _ASPPBranch(nn.Module):
         self.bn = BatchNorm2d(cout)
 
     def forward(self, x):
-        return self.bn(self.atrous_conv(x), relu=True)
+        return conv_bn(self.atrous_conv, self.bn, x, relu=True)
 
 
 class ASPP(nn.Module):
@@ -38,10 +38,10 @@ class ASPP(nn.Module):
     def forward(self, x):
         h, w = x.shape[2:]
         g = ops.global_avg_pool(x)
-        g = self.global_avg_pool.child(2)(self.global_avg_pool.child(1)(g), relu=True)
+        g = conv_bn(self.global_avg_pool.child(1), self.global_avg_pool.child(2), g, relu=True)
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), ops.bilinear(g, h, w)]
         y = torch.cat(branches, 1)               # channel concat of NHWC tensors (plumbing)
-        return self.dropout(self.bn1(self.conv1(y), relu=True))
+        return self.dropout(conv_bn(self.conv1, self.bn1, y, relu=True))
 
 
 class Decoder(nn.Module):
@@ -55,11 +55,11 @@ class Decoder(nn.Module):
         self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
 
     def forward(self, x, low):
-        low = self.bn1(self.conv1(low), relu=True)
+        low = conv_bn(self.conv1, self.bn1, low, relu=True)
         x = torch.cat((ops.bilinear(x, low.shape[2], low.shape[3]), low), 1)
         lc = self.last_conv
-        x = self.drop3(lc.child(1)(lc.child(0)(x), relu=True))
-        x = self.drop7(lc.child(5)(lc.child(4)(x), relu=True))
+        x = self.drop3(conv_bn(lc.child(0), lc.child(1), x, relu=True))
+        x = self.drop7(conv_bn(lc.child(4), lc.child(5), x, relu=True))
         return lc.child(8)(x)
 
 

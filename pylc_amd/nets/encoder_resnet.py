@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..layers import Conv2d, BatchNorm2d, Named
+from ..layers import Conv2d, BatchNorm2d, Named, conv_bn
 
 
 class Bottleneck(nn.Module):
@@ -28,13 +28,18 @@ class Bottleneck(nn.Module):
         # identity blocks: x's gradient = (residual branch of bn3) + (dgrad of conv1); the link makes conv1's dgrad
         # accumulate into the buffer bn3's backward wrote instead of leaving two tensors for autograd to add
         link = ops.ResidualLink() if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
-        out = self.bn1(self.conv1(x, res_link=link), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        out = self.conv3(out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, conv_link=link)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
         res = x
         if self.downsample is not None:
-            res = self.downsample.child(1)(self.downsample.child(0)(x))
-        return self.bn3(out, residual=res, relu=True, res_link=link)      # relu(bn3(.) + residual) in one pass
+            res = conv_bn(self.downsample.child(0), self.downsample.child(1), x)
+        return self._tail(out, res, link)
+
+    def _tail(self, out, res, link):
+        # relu(bn3(conv3(.)) + residual): one BatchNorm pass in training, the conv epilogue alone in inference
+        if link is None:
+            return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True)
+        return self.bn3(self.conv3(out), residual=res, relu=True, res_link=link)
 
 
 class ResNet101(nn.Module):

@@ -470,6 +470,44 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=N
     return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link)
 
 
+def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False):
+    """Inference only (no autograd): act(BN_eval(conv(x)) (+ residual)) with the BatchNorm coefficients, the residual add and
+    the ReLU applied in the conv epilogue -- bit-identical to conv2d followed by bn_act(training=False), one pass less."""
+    L.init()
+    x = as_nhwc(x)
+    cout, cin_w, r, s = w.shape
+    cin = x.shape[1]
+    if cin != cin_w or cin_w % 4 or not w.permute(0, 2, 3, 1).is_contiguous():
+        raise L.PylcError('conv_bn_act_eval: needs a KRSC filter with Cin % 4 == 0 matching the input')
+    b, _, h, wd = x.shape
+    oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+    yp = _r4(cout)
+    y = empty_nhwc(b, cout, oh, ow, x.device, yp)
+    d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, pitch_of(x), yp)
+    amax = None
+    keep = None
+    if ranges_needed():
+        keep = (amax_of(x), weight_amax(w))
+        d.x_amax, d.w_amax = ptr(keep[0]), ptr(keep[1])
+        planes = getattr(w, '_pylc_planes', None)
+        if planes is not None:
+            d.w_planes = ptr(planes[0])
+        amax = amax_slot(x.device)
+    coef = torch.empty(2 * cout, device=x.device)
+    st = stream()
+    check(lib.pylc_bn_eval_coeffs(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, cout, ptr(coef[:cout]), ptr(coef[cout:]), st))
+    res = None
+    if residual is not None:
+        res = as_nhwc(residual)
+        if tuple(res.shape) != tuple(y.shape) or pitch_of(res) != yp:
+            raise L.PylcError('conv_bn_act_eval: the residual must have the output\'s shape and pitch')
+    check(lib.pylc_conv2d_fwd_bnact(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(coef[:cout]), ptr(coef[cout:]), ptr(res), int(relu), ptr(y),
+                                    ptr(amax), st))
+    if amax is not None:
+        tag_amax(y, amax)
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # depthwise 3x3 (Xception separable convs)
 # ----------------------------------------------------------------------------------------------

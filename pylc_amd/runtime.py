@@ -12,6 +12,7 @@ class _Runtime:
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)
         self.wgrad_side_stream = not os.environ.get('PYLC_NO_SIDE_STREAM')
+        self.fuse_eval_bn = True      # inference: eval-mode BatchNorm (+ residual + ReLU) inside the conv epilogue (layers.conv_bn)
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         self.seed = 0x5EED

@@ -133,3 +133,27 @@ def test_uint8_feed_equals_float_path(dev):
     a = Model(Meta(), dev).pack_input(x)
     b = Model(Meta(), dev).pack_input(x.to(torch.uint8))
     assert torch.equal(a, b)
+
+
+def test_fused_eval_batchnorm_is_bit_identical(dev):
+    """Inference runs eval-mode BatchNorm, the residual add and the ReLU inside the conv epilogue (layers.conv_bn); the logits
+    must equal, bit for bit, the ones from conv -> separate BatchNorm pass."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import runtime
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    x = D.tiles(91, 2, 3, 128, 160)
+    cfg = ostep.StepConfig('deeplab', 'resnet', 9, 3, dropout=False)
+    w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=4), cfg, x.clone())
+    model = Model(Meta(), dev).build()
+    model.net.load_state_dict(w)
+    model.net.eval()
+    out = {}
+    for fuse in (True, False):
+        runtime.fuse_eval_bn = fuse
+        out[fuse] = model.test(x)[0].clone()
+    runtime.fuse_eval_bn = True
+    assert torch.equal(out[True], out[False])
+    want = ostep.test_step({k: v.clone() for k, v in w.items()}, cfg, x.clone())
+    assert (out[True].float().cpu() - want).abs().max().item() < 1e-3
