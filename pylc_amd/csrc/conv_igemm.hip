@@ -513,7 +513,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // M16 (with SWZ): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- same FLOPs per
 // matrix-pipe cycle, same LDS traffic, but 16 % more sustained throughput at the board's power cap (bare loops on random
 // data: 2005 vs 1690 TFLOP/s, tools/micro/mfma_shapes.hip).  Wave tile 64x64 = 4x4 tiles of 16x16.
-template <bool STAMPS, bool BPL, bool SWZ, bool M16, bool S3 = SWZ>
+// EP: the fused inference epilogue (ep_scale / ep_shift / ep_res / ep_relu / ep_amax) is compiled in only for EP = true; the
+// training kernels do not carry it (its mere presence cost 1 % of the training step).
+template <bool STAMPS, bool BPL, bool SWZ, bool M16, bool S3 = SWZ, bool EP = false>
 __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemmArgs a) {
     static_assert(!S3 || SWZ, "three stages need the unpadded rows");
     static_assert(!M16 || SWZ, "the 16x16x32 variant uses the unpadded swizzled LDS rows");
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         const int n = n0 + wave_n * WN + j * TS + (lane & (TS - 1));
         const bool nok = n < a.N_store;
         const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
-        const bool ep = a.ep_scale != nullptr;
+        const bool ep = EP && a.ep_scale != nullptr;
         const float esc = (ep && n < a.N) ? a.ep_scale[n] : 0.f, esh = (ep && n < a.N) ? a.ep_shift[n] : 0.f;
         float cs = 0.f, css = 0.f;
 #pragma unroll
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             }
             // accumulate / fused residual: fetch all values first (independent loads in flight), then add and store --
             // interleaved load/store pairs serialise because the compiler cannot prove the rows distinct
-            const float* extra = a.accumulate ? a.y : a.ep_res;
+            const float* extra = a.accumulate ? a.y : (EP ? a.ep_res : nullptr);
             if (extra != nullptr) {
 #pragma unroll
                 for (int r = 0; r < AR; ++r) prev[r] = (nok && offs[r] >= 0) ? extra[offs[r] + n] : 0.f;
@@ -927,11 +929,11 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                     float val = acc[i][j][r] + bv;
                     if (ep) val = val * esc + esh;                   // BatchNorm-apply's own expression and order
                     if (extra != nullptr) val += prev[r];
-                    if (a.ep_relu) val = fmaxf(val, 0.f);
+                    if (EP && a.ep_relu) val = fmaxf(val, 0.f);
                     a.y[offs[r] + n] = val;
                     cs += val;
                     css += val * val;
-                    ep_max = fmaxf(ep_max, fabsf(val));
+                    if (EP) ep_max = fmaxf(ep_max, fabsf(val));
                 }
             }
         }
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             }
         }
     }
-    if (a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
+    if (EP && a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
     __syncthreads();          // the next tile reuses the LDS stages and the epilogue tables
     }
 }
@@ -1485,7 +1487,10 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     const bool bpl = a.w_planes != nullptr;
     const dim3 g((unsigned)grid), b(512);
 #define PYLC_PP(ST, BP, SW, M) hipLaunchKernelGGL((gather_gemm_pp_kernel<ST, BP, SW, M>), g, b, ((SW) ? 3 * PP_STAGE_SWZ : 2 * PP_STAGE) + ((ST) ? 4096 : 0), st, a)
-    if (a.dbg != nullptr) {                      // stamped builds (tools/pp_stamps.py): 32x32x16 forms only
+    if (a.ep_scale != nullptr) {                 // fused inference epilogue: its own instantiations of the default variant
+        if (bpl) hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true, true, true, true>), g, b, 3 * PP_STAGE_SWZ, st, a);
+        else hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true, true, true, true>), g, b, 3 * PP_STAGE_SWZ, st, a);
+    } else if (a.dbg != nullptr) {               // stamped builds (tools/pp_stamps.py): 32x32x16 forms only
         if (bpl && swz) PYLC_PP(true, true, true, false);
         else if (bpl) PYLC_PP(true, true, false, false);
         else PYLC_PP(true, false, false, false);
@@ -1544,6 +1549,8 @@ int conv_init() {
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, false, false>), 2 * PP_STAGE));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, false, false>), 2 * PP_STAGE));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true, true>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true, true, true, true>), 3 * PP_STAGE_SWZ));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true, true, true, true>), 3 * PP_STAGE_SWZ));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true, true>), 3 * PP_STAGE_SWZ));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, true, true, false>), 3 * PP_STAGE_SWZ));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<false, false, true, false>), 3 * PP_STAGE_SWZ));
