@@ -46,11 +46,13 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if not files:
         return None
-    want = ''.join(kernel.split())
+    want = ''.join(kernel.split()).split('*')[0]          # 'name<a,b,*>' matches every instantiation with that prefix
+    tot_bytes = tot_n = 0.0
     for name, v in json.load(open(files[-1])).items():
         if want in ''.join(name.split()):
-            return v['hbm_bytes_per_launch']
-    return None
+            tot_bytes += v['hbm_bytes_per_launch'] * v['launches']
+            tot_n += v['launches']
+    return tot_bytes / tot_n if tot_n else None
 
 
 def cpu_baseline(hw, n_cls, budget_s=25.0):
