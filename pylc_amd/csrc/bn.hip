@@ -108,11 +108,23 @@ __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* _
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + tx;
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int r = ty; r < nrows; r += 32) {
+    if (c < C) {
+        int r = ty;
+        for (; r + 3 * 32 < nrows; r += 4 * 32) {          // 8 loads in flight; row order of the adds unchanged
+            float v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v0[u] = partial[(size_t)(r + u * 32) * 2 * C + c];
+                v1[u] = partial[(size_t)(r + u * 32) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += (double)v0[u]; a1 += (double)v1[u]; }
+        }
+        for (; r < nrows; r += 32) {
             a0 += (double)partial[(size_t)r * 2 * C + c];
             a1 += (double)partial[(size_t)r * 2 * C + C + c];
         }
+    }
     red[0][ty][tx] = a0;
     red[1][ty][tx] = a1;
     __syncthreads();

@@ -71,8 +71,19 @@ __global__ __launch_bounds__(256) static void column_sum_kernel(const float* __r
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + tx;
     double acc = 0.0;
-    if (c < ncols)
-        for (int r = ty; r < nrows; r += 32) acc += (double)partial[(size_t)r * ncols + c];
+    if (c < ncols) {
+        // eight independent loads in flight per thread (the kernel is pure latency: ~1000 rows, a few dozen blocks); the adds
+        // keep the row order, so the result does not depend on the unrolling
+        int r = ty;
+        for (; r + 7 * 32 < nrows; r += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + u * 32) * ncols + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; r < nrows; r += 32) acc += (double)partial[(size_t)r * ncols + c];
+    }
     red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && c < ncols) {

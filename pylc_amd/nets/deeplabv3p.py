@@ -18,8 +18,8 @@ class _ASPPBranch(nn.Module):
         self.atrous_conv = Conv2d(cin, cout, k, 1, 0 if k == 1 else dilation, dilation, init='kaiming', bn=True)
         self.bn = BatchNorm2d(cout)
 
-    def forward(self, x):
-        return conv_bn(self.atrous_conv, self.bn, x, relu=True)
+    def forward(self, x, link=None):
+        return conv_bn(self.atrous_conv, self.bn, x, relu=True, conv_link=link)
 
 
 class ASPP(nn.Module):
@@ -39,7 +39,8 @@ class ASPP(nn.Module):
         h, w = x.shape[2:]
         g = ops.global_avg_pool(x)
         g = conv_bn(self.global_avg_pool.child(1), self.global_avg_pool.child(2), g, relu=True)
-        branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), ops.bilinear(g, h, w)]
+        link = ops.grad_link(x)                  # the four branch dgrads sum into one buffer (ops.ResidualLink)
+        branches = [self.aspp1(x, link), self.aspp2(x, link), self.aspp3(x, link), self.aspp4(x, link), ops.bilinear(g, h, w)]
         y = torch.cat(branches, 1)               # channel concat of NHWC tensors (plumbing)
         return self.dropout(conv_bn(self.conv1, self.bn1, y, relu=True))
 
@@ -55,7 +56,7 @@ class Decoder(nn.Module):
         self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
 
     def forward(self, x, low):
-        low = conv_bn(self.conv1, self.bn1, low, relu=True)
+        low = conv_bn(self.conv1, self.bn1, low, relu=True, conv_link=ops.grad_link(low))
         x = torch.cat((ops.bilinear(x, low.shape[2], low.shape[3]), low), 1)
         lc = self.last_conv
         x = self.drop3(conv_bn(lc.child(0), lc.child(1), x, relu=True))

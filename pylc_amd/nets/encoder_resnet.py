@@ -25,15 +25,16 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        # identity blocks: x's gradient = (residual branch of bn3) + (dgrad of conv1); the link makes conv1's dgrad
-        # accumulate into the buffer bn3's backward wrote instead of leaving two tensors for autograd to add
-        link = ops.ResidualLink() if (self.downsample is None and torch.is_grad_enabled() and x.requires_grad) else None
+        # x's gradient has two producers: conv1's dgrad and either bn3's residual branch (identity blocks) or the downsample
+        # conv's dgrad (projection blocks; the low-level features add the decoder's conv1).  The link makes them sum into one
+        # buffer in their own epilogues instead of leaving several tensors for autograd to add
+        link = ops.grad_link(x)
         out = conv_bn(self.conv1, self.bn1, x, relu=True, conv_link=link)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
-        res = x
         if self.downsample is not None:
-            res = conv_bn(self.downsample.child(0), self.downsample.child(1), x)
-        return self._tail(out, res, link)
+            res = conv_bn(self.downsample.child(0), self.downsample.child(1), x, conv_link=link)
+            return self._tail(out, res, None)
+        return self._tail(out, x, link)
 
     def _tail(self, out, res, link):
         # relu(bn3(conv3(.)) + residual): one BatchNorm pass in training, the conv epilogue alone in inference

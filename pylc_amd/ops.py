@@ -286,16 +286,35 @@ def weight_amax(w):
 
 
 class ResidualLink:
-    """Couples the two backward nodes that produce the gradient of an identity-residual block's input x:
-    BatchNorm(+residual x) and the block's first conv (input x).  Instead of two tensors that autograd then adds
-    (a 12 B/element pass), the BatchNorm backward parks its residual gradient here and the conv's dgrad accumulates
-    into that buffer in its epilogue (`accumulate`).  Armed by the conv's forward when x needs a gradient; autograd's
-    dependency order guarantees the BatchNorm backward runs first."""
-    __slots__ = ('armed', 'buf')
+    """Couples the backward nodes that each produce a part of ONE tensor's gradient, so that the parts are summed by the
+    kernels that compute them instead of by autograd (an add is a 12 B/element pass):
+      * identity-residual block: BatchNorm(+residual x) parks its residual gradient here, the block's first conv (input x)
+        accumulates its dgrad into that buffer in the epilogue (`accumulate`);
+      * a tensor read by several convs (projection blocks: conv1 + downsample; the low-level features: layer2 + decoder;
+        the ASPP branches): the first dgrad to run writes a fresh buffer, the others accumulate into it.
+    Every conv armed in the forward counts in `pending`; the backward that brings it to zero returns the buffer as the whole
+    gradient of x, the earlier ones return None (autograd adds whatever other consumers of x deliver).  All consumers must
+    take part in the backward pass -- true for the networks of this package, where every branch reaches the loss."""
+    __slots__ = ('pending', 'buf')
 
     def __init__(self):
-        self.armed = False
+        self.pending = 0
         self.buf = None
+
+    @property
+    def armed(self):
+        return self.pending > 0
+
+
+def grad_link(x):
+    """The link shared by all consumers of tensor x (kept on the tensor object); None when x needs no gradient."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    link = getattr(x, '_pylc_link', None)
+    if link is None:
+        link = ResidualLink()
+        x._pylc_link = link
+    return link
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -305,9 +324,9 @@ class Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None):
         L.init()
         ctx.set_materialize_grads(False)      # the auxiliary outputs (statistics, ranges) carry no gradient: no zero fills
-        ctx.res_link = res_link
-        if res_link is not None:
-            res_link.armed = bool(ctx.needs_input_grad[0]) and stride == 1
+        ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
+        if ctx.res_link is not None:
+            res_link.pending += 1
         x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
         cin = x.shape[1]
@@ -390,8 +409,7 @@ class Conv2dFn(torch.autograd.Function):
             kp = _r4(cout)
             link = ctx.res_link
             sink = link.buf if link is not None else None
-            if sink is not None:            # the residual gradient is already in `sink`: dgrad adds to it (no autograd add pass)
-                link.buf = None
+            if sink is not None:            # part of x's gradient is already in `sink`: dgrad adds to it (no autograd add pass)
                 dx = sink
             else:
                 dx = empty_nhwc(*x.shape, device=x.device)
@@ -410,6 +428,12 @@ class Conv2dFn(torch.autograd.Function):
             if ev is not None:
                 ev[1].record()
             d.x_pitch = pitch_of(x)
+            if link is not None:
+                link.pending -= 1
+                if link.pending > 0:        # other consumers of x follow: they accumulate into the same buffer
+                    link.buf, dx = dx, None
+                else:
+                    link.buf = None
         if ctx.needs_input_grad[1]:
             # wgrad is off the critical chain (only the optimiser needs it), so it runs on a side stream: the matrix-bound
             # wgrad kernels then overlap the HBM-bound BatchNorm-backward kernels of the layers that follow on the main stream

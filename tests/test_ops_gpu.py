@@ -505,3 +505,31 @@ def test_conv_kernel_variants_are_bit_identical(dev):
         for a, b in zip(res['default'][:2], res['pp32_swizzled'][:2]):
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), hw
         assert torch.equal(res['default'][2], res['pp32_swizzled'][2])      # dw comes from the wgrad kernel either way
+
+
+def test_gradient_link_equals_autograd_sum(dev):
+    """A tensor read by several convs (projection blocks, low-level features, ASPP): with ops.grad_link the dgrads sum into
+    one buffer in their epilogues; the result is bit-identical to letting autograd add the separate gradients (same
+    arrival order, fp32 adds), including a stride-2 consumer whose dgrad touches only one pixel parity class."""
+    from pylc_amd import ops
+    torch.manual_seed(5)
+    x0 = to_dev_nhwc(rnd(71, 4, 64, 32, 32), dev)
+    ws = [to_dev_nhwc(rnd(72 + i, co, 64, k, k, scale=0.1), dev).requires_grad_(True) for i, (co, k) in enumerate(((32, 1), (128, 1), (64, 3), (48, 1)))]
+    geo = ((1, 0, 1), (2, 0, 1), (1, 2, 2), (1, 0, 1))      # (stride, pad, dilation)
+
+    def run(linked):
+        h = (x0 * 1.0).requires_grad_(True)              # non-leaf consumer input, as inside a network
+        h.retain_grad()
+        link = ops.grad_link(h) if linked else None
+        outs = [ops.conv2d(h, w, None, s, p, d, res_link=link) for w, (s, p, d) in zip(ws, geo)]
+        loss = sum((o * o).sum() for o in outs) + (h * h).sum()      # plus a consumer that is not a conv
+        for w in ws:
+            w.grad = None
+        loss.backward()
+        assert link is None or (link.pending == 0 and link.buf is None)
+        return h.grad.clone(), [w.grad.clone() for w in ws]
+
+    g_ref, gw_ref = run(False)
+    g_lnk, gw_lnk = run(True)
+    assert torch.equal(g_ref, g_lnk)
+    assert all(torch.equal(a, b) for a, b in zip(gw_ref, gw_lnk))

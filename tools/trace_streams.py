@@ -18,7 +18,7 @@ for q, rs in byq.items():
     for r in rs:
         k[r['Kernel_Name'].split('(')[0][-60:]] += r['e'] - r['s']
     print('queue', q, 'kernels', len(rs), 'busy %.2f ms per step' % (busy / 2e6))
-    for name, t in k.most_common(8):
+    for name, t in k.most_common(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
         print('    %-62s %.2f ms/step' % (name, t / 2e6))
 # union busy time
 ev = sorted([(r['s'], 1) for r in sel] + [(r['e'], -1) for r in sel])
