@@ -517,12 +517,14 @@ def test_gradient_link_equals_autograd_sum(dev):
     ws = [to_dev_nhwc(rnd(72 + i, co, 64, k, k, scale=0.1), dev).requires_grad_(True) for i, (co, k) in enumerate(((32, 1), (128, 1), (64, 3), (48, 1)))]
     geo = ((1, 0, 1), (2, 0, 1), (1, 2, 2), (1, 0, 1))      # (stride, pad, dilation)
 
-    def run(linked):
+    def run(linked, extra=False):
         h = (x0 * 1.0).requires_grad_(True)              # non-leaf consumer input, as inside a network
         h.retain_grad()
         link = ops.grad_link(h) if linked else None
         outs = [ops.conv2d(h, w, None, s, p, d, res_link=link) for w, (s, p, d) in zip(ws, geo)]
-        loss = sum((o * o).sum() for o in outs) + (h * h).sum()      # plus a consumer that is not a conv
+        loss = sum((o * o).sum() for o in outs)
+        if extra:
+            loss = loss + (h * h).sum()                  # a consumer that is not a conv: autograd adds its part to the buffer
         for w in ws:
             w.grad = None
         loss.backward()
@@ -533,3 +535,6 @@ def test_gradient_link_equals_autograd_sum(dev):
     g_lnk, gw_lnk = run(True)
     assert torch.equal(g_ref, g_lnk)
     assert all(torch.equal(a, b) for a, b in zip(gw_ref, gw_lnk))
+    g_ref, _ = run(False, True)
+    g_lnk, _ = run(True, True)
+    assert rel_err(g_lnk, g_ref) < 1e-6                  # same terms, different association of the fp32 adds
