@@ -137,6 +137,133 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     }
 }
 
+// ---- stride-1, dilation-1 fast path (all but a handful of the Aligned-Xception depthwise convs) ------------------------
+// The pixel-per-thread kernels above issue 9 (10 for wgrad) 16-byte loads per output vector, nearly all of them L2 hits:
+// they run at the L2 request rate, ~1.6 TB/s of useful traffic.  Here a thread walks a strip of TWO output rows along W
+// with the 4x3 input window in registers: each step loads one new 4-row column (prefetched one step ahead) and produces
+// two outputs -- 2 loads per output (3 for wgrad).  Tap order of the sums is the one of the general kernels, so forward
+// and dgrad results are bit-identical to them.
+struct DwStrip { int nseg, seg, pairs, n_strips, strips_per_block; };
+
+__device__ __forceinline__ void dw_load_col(f32x4 (&c)[4], const float* const (&rowp)[4], const bool (&rv)[4], bool col_ok, int col, int pitch) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (col_ok && rv[j]) ? ld4(rowp[j] + (size_t)col * pitch) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// MODE 0: y = dw(x) (in = x, aux = filter, out = y); MODE 1: dx = dw^T(dy) (in = dy, aux = filter, out = dx);
+// MODE 2: partial[block][9][C] = sum over this block's pixels of dy (x) window(x) (in = x, aux = dy, out = partial)
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 2 : 3, 8))) void dw_strip_kernel(const float* __restrict__ in, const float* __restrict__ aux, float* __restrict__ out,
+                                                       DwGeom d, DwStrip s, int cols, int RL, int CV) {
+    __shared__ f32x4 red[MODE == 2 ? 256 : 1];
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    const int in_pitch = MODE == 1 ? d.y_pitch : d.x_pitch;
+    const int out_pitch = MODE == 1 ? d.x_pitch : d.y_pitch;      // MODE 2: pitch of dy
+    const int s_begin = blockIdx.x * s.strips_per_block;
+    const int s_end = s_begin + s.strips_per_block < s.n_strips ? s_begin + s.strips_per_block : s.n_strips;
+    for (int cb = 0; cb < CV; cb += cols) {
+        const int cv = cb + tx;
+        const bool active = ty < RL && cv < CV;
+        f32x4 k[9];                                                 // filter taps (MODE 0/1) or accumulators (MODE 2)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) k[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            if (MODE != 2) load_taps(aux, cv, k);
+            for (int sid = s_begin + ty; sid < s_end; sid += RL) {
+                const int sgi = sid % s.nseg;
+                const int t_ = sid / s.nseg;
+                const int p = t_ % s.pairs, b = t_ / s.pairs;
+                const int h0 = 2 * p, w0 = sgi * s.seg;
+                const int w1 = w0 + s.seg < d.W ? w0 + s.seg : d.W;
+                const bool two = h0 + 1 < d.H;
+                const float* rowp[4];
+                bool rv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int hh = h0 - 1 + j;
+                    rv[j] = (unsigned)hh < (unsigned)d.H;
+                    rowp[j] = in + ((size_t)(b * d.H + (rv[j] ? hh : 0)) * d.W) * in_pitch + 4 * cv;
+                }
+                const size_t o0 = ((size_t)(b * d.H + h0) * d.W) * out_pitch + 4 * cv;      // output rows h0, h0 + 1 (dy rows in MODE 2)
+                const size_t o1 = o0 + (size_t)d.W * out_pitch;
+                f32x4 ca[4], cb_[4], cc[4], cd[4];
+                dw_load_col(ca, rowp, rv, w0 > 0, w0 - 1, in_pitch);
+                dw_load_col(cb_, rowp, rv, true, w0, in_pitch);
+                dw_load_col(cc, rowp, rv, w0 + 1 < d.W, w0 + 1, in_pitch);
+                int ww = w0;
+                // one step: L/M/R = window columns ww-1, ww, ww+1 (already loaded); N receives column ww+2 for the next step
+#define PYLC_DW_STEP(L, M, R, N)                                                                                          \
+    {                                                                                                                     \
+        dw_load_col(N, rowp, rv, ww + 2 < d.W && ww + 1 < w1, ww + 2, in_pitch);                                          \
+        if (MODE == 2) {                                                                                                  \
+            const f32x4 g0 = ld4(aux + o0 + (size_t)ww * out_pitch);                                                      \
+            const f32x4 g1 = two ? ld4(aux + o1 + (size_t)ww * out_pitch) : f32x4{0.f, 0.f, 0.f, 0.f};                    \
+            _Pragma("unroll") for (int kr = 0; kr < 3; ++kr) {                                                            \
+                k[kr * 3 + 0] += g0 * L[kr]; k[kr * 3 + 1] += g0 * M[kr]; k[kr * 3 + 2] += g0 * R[kr];                    \
+            }                                                                                                             \
+            _Pragma("unroll") for (int kr = 0; kr < 3; ++kr) {                                                            \
+                k[kr * 3 + 0] += g1 * L[kr + 1]; k[kr * 3 + 1] += g1 * M[kr + 1]; k[kr * 3 + 2] += g1 * R[kr + 1];        \
+            }                                                                                                             \
+        } else {                                                                                                          \
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};                                                   \
+            _Pragma("unroll") for (int kr = 0; kr < 3; ++kr) {                                                            \
+                const int j = MODE == 0 ? kr : 2 - kr;      /* dgrad: dy row h + 1 - kr, column w + 1 - ks */             \
+                a0 += k[kr * 3 + 0] * (MODE == 0 ? L[j] : R[j]);                                                          \
+                a0 += k[kr * 3 + 1] * M[j];                                                                               \
+                a0 += k[kr * 3 + 2] * (MODE == 0 ? R[j] : L[j]);                                                          \
+                a1 += k[kr * 3 + 0] * (MODE == 0 ? L[j + 1] : R[j + 1]);                                                  \
+                a1 += k[kr * 3 + 1] * M[j + 1];                                                                           \
+                a1 += k[kr * 3 + 2] * (MODE == 0 ? R[j + 1] : L[j + 1]);                                                  \
+            }                                                                                                             \
+            st4(out + o0 + (size_t)ww * out_pitch, a0);                                                                   \
+            if (two) st4(out + o1 + (size_t)ww * out_pitch, a1);                                                          \
+        }                                                                                                                 \
+        if (++ww >= w1) break;                                                                                            \
+    }
+                for (;;) {
+                    PYLC_DW_STEP(ca, cb_, cc, cd)
+                    PYLC_DW_STEP(cb_, cc, cd, ca)
+                    PYLC_DW_STEP(cc, cd, ca, cb_)
+                    PYLC_DW_STEP(cd, ca, cb_, cc)
+                }
+#undef PYLC_DW_STEP
+            }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                red[threadIdx.x] = k[t];
+                __syncthreads();
+                if (ty == 0 && cv < CV) {
+                    f32x4 sum = k[t];
+                    for (int q = 1; q < RL; ++q) sum += red[q * cols + tx];
+                    st4(out + ((size_t)blockIdx.x * 9 + t) * d.C + 4 * cv, sum);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+static bool dw_fast(const PylcDwDesc* d) { return d->stride == 1 && d->dil == 1 && d->W >= 2; }
+
+static DwStrip make_strips(const PylcDwDesc* d, int cols, int RL) {
+    DwStrip s;
+    s.pairs = (d->H + 1) / 2;
+    int seg = 32;
+    const int waves = (cols * RL + 63) / 64;      // waves per block that carry work
+    for (;;) {
+        s.nseg = cdiv(d->W, seg);
+        s.seg = cdiv(d->W, s.nseg);
+        s.n_strips = d->B * s.pairs * s.nseg;
+        // enough strips to give every SIMD of the chip a few waves; shorter strips pay 2 extra column loads each
+        if (seg <= 8 || (long long)cdiv(s.n_strips, RL) * waves >= 256 * 12) break;
+        seg /= 2;
+    }
+    s.strips_per_block = RL * cdiv(s.n_strips, RL * kMaxSlabs);
+    return s;
+}
+
 // dw[c][t] = sum_slab partial[slab][t][c], fp64, fixed order: 8 columns x 32 slab lanes per block (a single thread walking
 // all slabs of its column is latency-bound: 250 us for 27 MB).
 __global__ __launch_bounds__(256) void dw_wgrad_combine_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ dw) {
@@ -176,6 +303,13 @@ extern "C" int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const flo
     if (int rc = check_dw(d)) return rc;
     PYLC_REQUIRE(x && w && y, "dwconv_fwd: null pointer");
     const Slab g = make_slab((long long)d->B * d->OH * d->OW, d->C);
+    if (dw_fast(d)) {
+        const DwStrip s = make_strips(d, g.cols, g.RL);
+        hipLaunchKernelGGL((dw_strip_kernel<0>), dim3(cdiv(s.n_strips, s.strips_per_block)), dim3(256), 0, as_stream(stream), x, w, y, geom(d), s,
+                           g.cols, g.RL, g.CV);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), x, w, y, geom(d), g);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
@@ -185,6 +319,13 @@ extern "C" int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const 
     if (int rc = check_dw(d)) return rc;
     PYLC_REQUIRE(dy && w && dx, "dwconv_dgrad: null pointer");
     const Slab g = make_slab((long long)d->B * d->H * d->W, d->C);
+    if (dw_fast(d)) {
+        const DwStrip s = make_strips(d, g.cols, g.RL);
+        hipLaunchKernelGGL((dw_strip_kernel<1>), dim3(cdiv(s.n_strips, s.strips_per_block)), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), s,
+                           g.cols, g.RL, g.CV);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     hipLaunchKernelGGL(dw_dgrad_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), g);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
@@ -203,9 +344,17 @@ extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const f
     if ((size_t)g.nslab * 9 * d->C * sizeof(float) > workspace_bytes)
         return fail(PYLC_ERR_WORKSPACE, "dwconv_wgrad workspace too small");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(g.nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), g);
+    int nslab = g.nslab;
+    if (dw_fast(d)) {
+        const DwStrip s = make_strips(d, g.cols, g.RL);
+        nslab = cdiv(s.n_strips, s.strips_per_block);          // <= kMaxSlabs by construction
+        hipLaunchKernelGGL((dw_strip_kernel<2>), dim3(nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), s, g.cols, g.RL,
+                           g.CV);
+    } else {
+        hipLaunchKernelGGL(dw_wgrad_kernel, dim3(g.nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), g);
+    }
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dw_wgrad_combine_kernel, dim3(cdiv(9 * d->C, 8)), dim3(256), 0, st, static_cast<const float*>(workspace), g.nslab, d->C, dw);
+    hipLaunchKernelGGL(dw_wgrad_combine_kernel, dim3(cdiv(9 * d->C, 8)), dim3(256), 0, st, static_cast<const float*>(workspace), nslab, d->C, dw);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

@@ -192,11 +192,16 @@ def test_conv_thin_input(dev, k, stride, pad, hw, conv_mode):
     assert rel_err(wd.grad, wr.grad) < 5e-6
 
 
-@pytest.mark.parametrize('c,stride,dil,hw', [(64, 1, 1, 18), (128, 2, 1, 18), (728, 1, 1, 9), (1024, 1, 2, 10), (128, 2, 1, 17)])
+@pytest.mark.parametrize('c,stride,dil,hw', [(64, 1, 1, 18), (128, 2, 1, 18), (728, 1, 1, 9), (1024, 1, 2, 10), (128, 2, 1, 17),
+                                             (32, 1, 1, (7, 71)), (8, 1, 1, (33, 1)), (1536, 1, 1, (5, 40)), (256, 1, 1, (1, 9)),
+                                             (16, 1, 1, (66, 130))])
 def test_dwconv(dev, c, stride, dil, hw):
+    """Depthwise 3x3 with fixed_padding; the stride-1/dilation-1 cases run the register-window strip kernels (odd heights,
+    rows of several segments, one-pixel rows/columns, more channel vectors than threads), the others the general kernels."""
     from pylc_amd import ops
     b = 2
-    x = rnd(8, b, c, hw, hw)
+    hw = hw if isinstance(hw, tuple) else (hw, hw)
+    x = rnd(8, b, c, *hw)
     wt = rnd(9, c, 1, 3, 3, scale=0.3)
     xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
     total = 2 * dil
