@@ -221,6 +221,16 @@ int pylc_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int H,
                      int pad, int OH, int OW, void* stream);
 int pylc_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int k,
                      int stride, int pad, int OH, int OW, void* stream);
+/* U-Net skip connections (unet.py:95-101,145-152): the encoder feature map x feeds the 2x2 max-pool AND, centre-cropped,
+ * the decoder's channel concat.  pylc_crop_copy writes the crop [h0, h0+TH) x [w0, w0+TW) of src straight into a
+ * channel range of the concat buffer (dst points at that range, dst_pitch = the buffer's channel count);
+ * pylc_maxpool_bwd_add is pylc_maxpool_bwd plus the crop's gradient `add` ([B][add_h][add_w] pixels, add_pitch floats
+ * apart) summed into the window it came from -- instead of a zero-padded full-size tensor and an add pass. */
+int pylc_maxpool_bwd_add(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int k,
+                         int stride, int pad, int OH, int OW, const float* add, int add_pitch, int add_h0,
+                         int add_w0, int add_h, int add_w, void* stream);
+int pylc_crop_copy(const float* src, int src_pitch, int H, int W, int h0, int w0, float* dst, int dst_pitch,
+                   int B, int TH, int TW, int C, void* stream);
 int pylc_bilinear_fwd(const float* x, int x_pitch, float* y, int y_pitch, int B, int H, int W, int C,
                       int OH, int OW, void* stream);
 int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C,

@@ -56,8 +56,12 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
+// `add` (may be NULL): a second gradient of the pooled tensor that covers only the window [h0, h0+AH) x [w0, w0+AW) -- the
+// centre crop a U-Net skip connection reads (unet.py:145-148) -- summed here instead of in a zero-padded full-size pass.
+struct PoolAdd { const float* p; int pitch, h0, w0, AH, AW; };
+
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx, int B, int H,
-                                   int W, int C, int k, int s, int pad, int OH, int OW) {
+                                   int W, int C, int k, int s, int pad, int OH, int OW, PoolAdd add) {
     const int CV = C / 4;
     const long long total = (long long)B * H * W * CV;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -85,7 +89,25 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
                 if (c4.w == code) acc.w += g.w;
             }
         }
+        if (add.p != nullptr && (unsigned)(h - add.h0) < (unsigned)add.AH && (unsigned)(w - add.w0) < (unsigned)add.AW)
+            acc += ld4(add.p + ((size_t)(b * add.AH + (h - add.h0)) * add.AW + (w - add.w0)) * add.pitch + 4 * cv);
         st4(dx + 4 * i, acc);
+    }
+}
+
+// dst[b, y, x, 0:C] = src[b, h0 + y, w0 + x, 0:C] (both NHWC with their own channel pitch)
+__global__ void crop_copy_kernel(const float* __restrict__ src, int src_pitch, int H, int W, int h0, int w0, float* __restrict__ dst,
+                                 int dst_pitch, int B, int TH, int TW, int C) {
+    const int CV = C / 4;
+    const long long total = (long long)B * TH * TW * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int x = (int)(t % TW); t /= TW;
+        const int y = (int)(t % TH);
+        const int b = (int)(t / TH);
+        st4(dst + ((size_t)(b * TH + y) * TW + x) * dst_pitch + 4 * cv,
+            ld4(src + ((size_t)(b * H + h0 + y) * W + w0 + x) * src_pitch + 4 * cv));
     }
 }
 
@@ -272,7 +294,32 @@ extern "C" int pylc_maxpool_bwd(const float* dy, const unsigned char* idx, float
                                 int OH, int OW, void* stream) {
     PYLC_REQUIRE(dy && idx && dx && B > 0 && C > 0 && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "maxpool_bwd: bad arguments");
     const long long total = (long long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, idx, dx, B, H, W, C, k, stride, pad, OH, OW);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, idx, dx, B, H, W, C, k, stride, pad, OH, OW,
+                       PoolAdd{nullptr, 0, 0, 0, 0, 0});
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_maxpool_bwd_add(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int k, int stride, int pad,
+                                    int OH, int OW, const float* add, int add_pitch, int add_h0, int add_w0, int add_h, int add_w, void* stream) {
+    PYLC_REQUIRE(dy && idx && dx && add && B > 0 && C > 0 && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1, "maxpool_bwd_add: bad arguments");
+    PYLC_REQUIRE(add_pitch >= C && add_pitch % 4 == 0 && add_h0 >= 0 && add_w0 >= 0 && add_h > 0 && add_w > 0 && add_h0 + add_h <= H &&
+                     add_w0 + add_w <= W, "maxpool_bwd_add: the added window must lie inside the %dx%d input", H, W);
+    const long long total = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, idx, dx, B, H, W, C, k, stride, pad, OH, OW,
+                       PoolAdd{add, add_pitch, add_h0, add_w0, add_h, add_w});
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_crop_copy(const float* src, int src_pitch, int H, int W, int h0, int w0, float* dst, int dst_pitch, int B, int TH, int TW,
+                              int C, void* stream) {
+    PYLC_REQUIRE(src && dst && B > 0 && C > 0 && C % 4 == 0 && TH > 0 && TW > 0, "crop_copy: bad arguments");
+    PYLC_REQUIRE(src_pitch >= C && dst_pitch >= C && src_pitch % 4 == 0 && dst_pitch % 4 == 0, "crop_copy: bad pitch");
+    PYLC_REQUIRE(h0 >= 0 && w0 >= 0 && h0 + TH <= H && w0 + TW <= W, "crop_copy: window outside the %dx%d source", H, W);
+    const long long total = (long long)B * TH * TW * (C / 4);
+    hipLaunchKernelGGL(crop_copy_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_pitch, H, W, h0, w0, dst, dst_pitch, B, TH,
+                       TW, C);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

@@ -32,8 +32,8 @@ class Conv2d(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def forward(self, x, res_link=None):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training, res_link)
+    def forward(self, x, res_link=None, out=None):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training, res_link, out)
 
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,

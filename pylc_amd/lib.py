@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PylcError(RuntimeError):
@@ -80,6 +80,8 @@ SIGNATURES = {
     'pylc_relu_bwd': (_I, [_P, _I, _P, _I, _P, _I, _LL, _I, _P]),
     'pylc_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pylc_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_maxpool_bwd_add': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'pylc_crop_copy': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     'pylc_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pylc_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pylc_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),

@@ -31,12 +31,13 @@ class UNetUpBlock(nn.Module):
         self.conv_block = UNetConvBlock(cin, cout, padding, dropout)
 
     def forward(self, x, bridge):
-        h, w = x.shape[2:]
-        up = self.up.child(1)(ops.bilinear(x, 2 * h, 2 * w))
-        th, tw = up.shape[2:]
-        dy, dx = (bridge.shape[2] - th) // 2, (bridge.shape[3] - tw) // 2
-        x = torch.cat([up, bridge[:, :, dy:dy + th, dx:dx + tw]], 1)     # centre-crop + concat (plumbing)
-        return self.conv_block(x)
+        # unet.py:145-152: cat([up, center_crop(bridge)], 1).  The 1x1 conv writes `up` straight into the concat buffer, the
+        # crop is copied behind it, and the crop's gradient is summed by the max-pool backward of the same skip tensor
+        b, _, h, w = x.shape
+        conv = self.up.child(1)
+        holder = [ops.empty_nhwc(b, conv.cout + bridge.shape[1], 2 * h, 2 * w, x.device)]
+        up = conv(ops.bilinear(x, 2 * h, 2 * w), out=holder)
+        return self.conv_block(ops.crop_concat(up, bridge, holder, ops.grad_link(bridge)))
 
 
 class UNet(nn.Module):
@@ -67,7 +68,7 @@ class UNet(nn.Module):
             x = down(x)
             if i != self.depth - 1:
                 skips.append(x)
-                x = ops.maxpool(x, 2, 2, 0)
+                x = ops.maxpool(x, 2, 2, 0, link=ops.grad_link(x))
         for i, up in enumerate(self.decoder):
             x = up(x, skips[-i - 1])
         return self.last(x)

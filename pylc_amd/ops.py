@@ -295,11 +295,13 @@ class ResidualLink:
     Every conv armed in the forward counts in `pending`; the backward that brings it to zero returns the buffer as the whole
     gradient of x, the earlier ones return None (autograd adds whatever other consumers of x deliver).  All consumers must
     take part in the backward pass -- true for the networks of this package, where every branch reaches the loss."""
-    __slots__ = ('pending', 'buf')
+    __slots__ = ('pending', 'buf', 'pool_armed', 'crop')
 
     def __init__(self):
         self.pending = 0
         self.buf = None
+        self.pool_armed = False     # U-Net skips: a max-pool reads x and will add the parked crop gradient in its backward
+        self.crop = None            # (dy of the concat buffer, channel offset, h0, w0) parked by CropConcatFn.backward
 
     @property
     def armed(self):
@@ -321,7 +323,7 @@ class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None, out=None):
         L.init()
         ctx.set_materialize_grads(False)      # the auxiliary outputs (statistics, ranges) carry no gradient: no zero fills
         ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
@@ -344,8 +346,16 @@ class Conv2dFn(torch.autograd.Function):
             raise L.PylcError('conv weight must have KRSC (channels_last) memory')
         b, _, h, wd = x.shape
         oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
-        yp = _r4(cout)
-        y = empty_nhwc(b, cout, oh, ow, x.device, yp)
+        if out is not None:
+            # write into channels [0, cout) of a caller-owned NHWC buffer (a concat target): out = [buffer]
+            buf = out[0]
+            yp = pitch_of(buf)
+            if tuple(buf.shape[2:]) != (oh, ow) or buf.shape[0] != b or buf.shape[1] < cout or cout % 4:
+                raise L.PylcError('conv out= buffer %s does not fit a [%d,%d,%d,%d] result' % (tuple(buf.shape), b, cout, oh, ow))
+            y = buf[:, :cout]
+        else:
+            yp = _r4(cout)
+            y = empty_nhwc(b, cout, oh, ow, x.device, yp)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
         d.x_amax, d.w_amax = ptr(x_amax), ptr(w_amax)
         ctx.ranges = (x_amax, w_amax)
@@ -380,7 +390,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return (None,) * 10
+            return (None,) * 11
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
@@ -477,21 +487,22 @@ class Conv2dFn(torch.autograd.Function):
                 db = _deliver_grad(bias, tgt)
             else:
                 db = sums[:cout].clone()
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=None):
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=None, out=None):
     """want_stats: also produce the per-channel (sum, sum of squares) of y in the conv epilogue and attach them to the
-    returned tensor as `_pylc_sums` for the BatchNorm that consumes it (ops.bn_act picks them up)."""
+    returned tensor as `_pylc_sums` for the BatchNorm that consumes it (ops.bn_act picks them up).
+    out: [buffer] -- write the result into the leading channels of that NHWC buffer (see crop_concat)."""
     xa = wa = None
     if ranges_needed():
         L.init()
         xa, wa = amax_of(x), weight_amax(w)
     if want_stats:
-        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link)
+        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link, out)
         y._pylc_sums = sums
         return y
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link)
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out)
 
 
 def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False):
@@ -786,7 +797,7 @@ def dropout(x, p, seed):
 # ----------------------------------------------------------------------------------------------
 class MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, stride, pad):
+    def forward(ctx, x, k, stride, pad, link=None):
         L.init()
         x = as_nhwc(x)
         if pitch_of(x) != x.shape[1]:
@@ -799,6 +810,9 @@ class MaxPoolFn(torch.autograd.Function):
         check(lib.pylc_maxpool_fwd(ptr(x), ptr(y), ptr(idx), b, h, w, c, k, stride, pad, oh, ow, stream()))
         ctx.save_for_backward(idx)
         ctx.cfg = (b, c, h, w, k, stride, pad, oh, ow)
+        ctx.link = link if need_idx else None
+        if ctx.link is not None:
+            link.pool_armed = True
         return y
 
     @staticmethod
@@ -809,12 +823,65 @@ class MaxPoolFn(torch.autograd.Function):
         if pitch_of(dy) != c:
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = empty_nhwc(b, c, h, w, dy.device)
-        check(lib.pylc_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), b, h, w, c, k, stride, pad, oh, ow, stream()))
-        return dx, None, None, None
+        link = ctx.link
+        crop = None
+        if link is not None:
+            link.pool_armed = False
+            crop, link.crop = link.crop, None
+        if crop is not None:        # the skip connection's gradient (centre crop) is summed in the same pass
+            g, c0, h0, w0 = crop
+            check(lib.pylc_maxpool_bwd_add(ptr(dy), ptr(idx), ptr(dx), b, h, w, c, k, stride, pad, oh, ow, g.data_ptr() + 4 * c0, pitch_of(g),
+                                           h0, w0, g.shape[2], g.shape[3], stream()))
+        else:
+            check(lib.pylc_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), b, h, w, c, k, stride, pad, oh, ow, stream()))
+        return dx, None, None, None, None
 
 
-def maxpool(x, k, stride, pad=0):
-    return MaxPoolFn.apply(x, k, stride, pad)
+def maxpool(x, k, stride, pad=0, link=None):
+    return MaxPoolFn.apply(x, k, stride, pad, link)
+
+
+class CropConcatFn(torch.autograd.Function):
+    """U-Net's `torch.cat([up, center_crop(bridge)], 1)` (unet.py:145-152) without the copies that can be avoided: `up` was
+    written into the leading channels of the concat buffer by its conv (conv2d(out=[buffer])); the crop of `bridge` is copied
+    behind it.  Backward: up's gradient is a channel slice (a view) of the buffer's gradient; the bridge's gradient is
+    non-zero only inside the crop window, so when a max-pool also reads `bridge` (always, in the U-Net) it is parked on the
+    shared link and summed by the pool's backward kernel -- no zero-padded tensor, no autograd add."""
+
+    @staticmethod
+    def forward(ctx, up, bridge, holder, link):
+        L.init()
+        buf = holder[0]
+        bridge = as_nhwc(bridge)
+        b, cu, th, tw = up.shape
+        cb, hh, ww = bridge.shape[1:]
+        if (tuple(buf.shape) != (b, cu + cb, th, tw) or pitch_of(buf) != cu + cb or up.data_ptr() != buf.data_ptr() or cu % 4 or cb % 4
+                or th > hh or tw > ww):
+            raise L.PylcError('crop_concat: `up` must be the leading channels of the [B, C_up + C_bridge, h, w] buffer')
+        h0, w0 = (hh - th) // 2, (ww - tw) // 2
+        check(lib.pylc_crop_copy(ptr(bridge), pitch_of(bridge), hh, ww, h0, w0, buf.data_ptr() + 4 * cu, cu + cb, b, th, tw, cb, stream()))
+        ctx.geom = (cu, cb, hh, ww, h0, w0)
+        ctx.link = link if ctx.needs_input_grad[1] else None
+        return buf
+
+    @staticmethod
+    def backward(ctx, dy):
+        cu, cb, hh, ww, h0, w0 = ctx.geom
+        dy = as_nhwc(dy)
+        d_up = dy[:, :cu] if ctx.needs_input_grad[0] else None
+        d_bridge = None
+        if ctx.needs_input_grad[1]:
+            link = ctx.link
+            if link is not None and link.pool_armed and link.crop is None:
+                link.crop = (dy, cu, h0, w0)
+            else:
+                d_bridge = zeros_nhwc(dy.shape[0], cb, hh, ww, dy.device)
+                d_bridge[:, :, h0:h0 + dy.shape[2], w0:w0 + dy.shape[3]] = dy[:, cu:]
+        return d_up, d_bridge, None, None
+
+
+def crop_concat(up, bridge, holder, link=None):
+    return CropConcatFn.apply(up, bridge, holder, link)
 
 
 class BilinearFn(torch.autograd.Function):

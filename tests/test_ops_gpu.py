@@ -543,3 +543,45 @@ def test_gradient_link_equals_autograd_sum(dev):
     g_ref, _ = run(False, True)
     g_lnk, _ = run(True, True)
     assert rel_err(g_lnk, g_ref) < 1e-6                  # same terms, different association of the fp32 adds
+
+
+def test_unet_skip_connection_fusion(dev):
+    """unet.py:95-101,145-152: the skip tensor feeds the 2x2 max-pool and, centre-cropped, the decoder concat.  The 1x1 `up`
+    conv writes into the concat buffer (conv2d(out=)), ops.crop_concat copies the crop behind it, and the crop's gradient is
+    summed by the max-pool backward (pylc_maxpool_bwd_add) -- against torch's cat / slicing / max_pool2d on the CPU."""
+    from pylc_amd import ops
+    b, c, hh, th = 2, 8, 22, 12
+    skip = rnd(81, b, c, hh, hh)
+    z = rnd(82, b, 16, th, th)
+    wt = rnd(83, c, 16, 1, 1, scale=0.3)
+    bias = rnd(84, c)
+    g_cat, g_pool = rnd(85, b, 2 * c, th, th), rnd(86, b, c, hh // 2, hh // 2)
+    # reference
+    sr, zr, wr, br = (t.double().requires_grad_(True) for t in (skip, z, wt, bias))
+    o = (hh - th) // 2
+    cat_r = torch.cat([F.conv2d(zr, wr, br), sr[:, :, o:o + th, o:o + th]], 1)
+    pool_r = F.max_pool2d(sr, 2)
+    ((cat_r * g_cat.double()).sum() + (pool_r * g_pool.double()).sum()).backward()
+    # HIP path
+    leaf = to_dev_nhwc(skip, dev).requires_grad_(True)
+    sd = leaf * 1.0                                      # a non-leaf skip tensor, as in the network
+    zd = to_dev_nhwc(z, dev).requires_grad_(True)
+    wd = to_dev_nhwc(wt, dev).requires_grad_(True)
+    bd = bias.to(dev).requires_grad_(True)
+    pooled = ops.maxpool(sd, 2, 2, 0, link=ops.grad_link(sd))
+    holder = [ops.empty_nhwc(b, 2 * c, th, th, dev)]
+    up = ops.conv2d(zd, wd, bd, 1, 0, 1, out=holder)
+    cat = ops.crop_concat(up, sd, holder, ops.grad_link(sd))
+    assert cat.data_ptr() == holder[0].data_ptr() and rel_err(cat, cat_r) < 2e-6 and rel_err(pooled, pool_r) < 1e-7
+    ((cat * to_dev_nhwc(g_cat, dev)).sum() + (pooled * to_dev_nhwc(g_pool, dev)).sum()).backward()
+    assert rel_err(leaf.grad, sr.grad) < 1e-6
+    assert rel_err(zd.grad, zr.grad) < 4e-6 and rel_err(wd.grad, wr.grad) < 5e-6 and rel_err(bd.grad, br.grad) < 2e-6
+    # without a pool on the same tensor the crop gradient is materialised (zero-padded)
+    leaf2 = to_dev_nhwc(skip, dev).requires_grad_(True)
+    holder = [ops.empty_nhwc(b, 2 * c, th, th, dev)]
+    up = ops.conv2d(zd, wd, bd, 1, 0, 1, out=holder)
+    cat = ops.crop_concat(up, leaf2 * 1.0, holder, None)
+    (cat * to_dev_nhwc(g_cat, dev)).sum().backward()
+    ref = torch.zeros_like(skip)
+    ref[:, :, o:o + th, o:o + th] = g_cat[:, c:]
+    assert rel_err(leaf2.grad, ref) < 1e-7
