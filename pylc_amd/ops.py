@@ -91,7 +91,7 @@ class KernelTimer:
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
-        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true,true>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
+        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -170,17 +170,25 @@ def _runs_concurrently(cand, device):
     """True if work on `cand` executes while the current stream is busy, i.e. the two HIP streams sit on different
     hardware queues.  HIP multiplexes streams onto a few hardware queues in creation order, so a fresh stream can land on
     the compute stream's queue -- observed once RCCL had created its streams -- and would then serialise behind it."""
+    with torch.cuda.stream(cand):                      # first use of a stream can take milliseconds (queue creation):
+        torch.zeros(1, device=device)                  # keep that out of the timed part
+    cand.synchronize()
     try:
-        torch.cuda._sleep(6_000_000)                   # ~14 ms busy-wait kernel on the current stream
+        torch.cuda._sleep(40_000_000)                  # tens of ms of busy-wait on the current stream
     except (AttributeError, RuntimeError):
         return True                                    # cannot probe: take the stream as it is
     with torch.cuda.stream(cand):
         torch.zeros(1, device=device)
         ev = torch.cuda.Event()
         ev.record()
-    time.sleep(0.003)
-    ok = ev.query()
+    ok = False
+    t0 = time.perf_counter()
+    while not ok and time.perf_counter() - t0 < 0.010:
+        time.sleep(0.001)
+        ok = ev.query()
     torch.cuda.synchronize(device)
+    if os.environ.get('PYLC_DEBUG_STREAMS'):
+        print('[pylc] side-stream candidate %s: %s' % (cand, 'concurrent' if ok else 'serialised behind the compute stream'), flush=True)
     return ok
 
 

@@ -79,6 +79,8 @@ class GradBucketer:
         self.buckets.append([lo, arena.numel, n])
         self.pending = [b[2] for b in self.buckets]
         self.works = []
+        # PYLC_GRAD_OVERLAP=0: exchange all buckets after the backward pass instead of as they complete (A/B knob)
+        self.overlap = os.environ.get('PYLC_GRAD_OVERLAP', '1') != '0'
 
     def reset(self):
         self.pending = [b[2] for b in self.buckets]
@@ -89,7 +91,7 @@ class GradBucketer:
         if b is None:
             return
         self.pending[b] -= 1
-        if self.pending[b] == 0:
+        if self.pending[b] == 0 and self.overlap:
             self._launch(b)
 
     def _launch(self, b):
