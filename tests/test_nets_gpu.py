@@ -178,6 +178,68 @@ print('RESULT', runtime.sync_group is not None, float(m.crit.ce), float(m.crit.d
     assert res[''][1] == res['1'][1], res
 
 
+def test_two_ranks_equal_one_process_at_global_batch(dev):
+    """SURVEY.md section 8e oracle for N > 1: two ranks with half the tiles each (SyncBN statistics, loss-head partial sums and
+    the bucketed gradient SUM exchanged between them) must reproduce one process at the global batch.  Both ranks share
+    the box's one GPU and talk over gloo (RCCL refuses two ranks on one device); everything above the transport -- the
+    HIP kernels, the wire formats, the bucket firing order under the real backward -- is the multi-GPU code path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys; sys.path.insert(0, %r)
+import torch, pylc_amd
+from pylc_amd import parallel, runtime
+from pylc_amd.model import Model, Meta
+from tests import _data as D
+import oracle
+world = int(os.environ.get('WORLD_SIZE', '1'))
+rank = 0
+if world > 1:
+    rank, world = parallel.init_from_env('gloo')
+    assert runtime.sync_group is not None
+runtime.dropout_enabled = False
+x = D.tiles(1, 4, 3, 64, 64); y = D.blob_masks(2, 4, 64, 64, 9, cell=8)
+per = 4 // world
+x, y = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+w = oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=5)
+m = Model(Meta(), torch.device('cuda:0')).build()
+m.net.load_state_dict(w)
+if world > 1:
+    parallel.broadcast_parameters(m.arena)
+out = []
+for _ in range(2):
+    m.train(x, y)
+    out += [float(m.crit.ce), float(m.crit.dsc), float(m.crit.fl), float(m.optim.norm[0])]
+rm = float(m.net.state_dict()['backbone.layer3.22.bn3.running_var'].double().sum())
+if world > 1:
+    assert m._bucketer is not None and len(m._bucketer.buckets) >= 3
+    parallel.barrier()
+if rank == 0:
+    print('RESULT', *out, rm)
+''' % root
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PYLC_FORCE_PG', None)
+
+    def result(cmd):
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
+        assert out.returncode == 0 and line, out.stdout[-3000:] + out.stderr[-3000:]
+        return [float(v) for v in line[0].split()[1:]]
+
+    one = result([sys.executable, '-c', code])
+    two = result([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                  '--master-port', '29537', '--no-python', sys.executable, '-c', code])
+    print('two ranks vs one process: step-1 (ce, dice, focal, |g|)', one[:4], two[:4], 'step-2', one[4:8], two[4:8])
+    # step 1: same weights on both sides, only fp32 summation order differs (per-rank partial sums, per-rank f16x3 operand scales)
+    for a, b in zip(one[:4], two[:4]):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (one, two)
+    # step 2 goes through AdamW's first step (a sign-like update that amplifies rounding noise in near-zero gradients)
+    for a, b in zip(one[4:7], two[4:7]):
+        assert abs(a - b) <= 5e-3, (one, two)
+    assert abs(one[8] - two[8]) <= 1e-3 * abs(one[8]), (one[8], two[8])       # running variance saw the global batch
+
+
 def test_epoch_driver_matches_reference(dev, tmp_path):
     """pylc_amd.train.trainer vs the reference's train.py loop (fixture tests/golden/driver.json): same logging cadence,
     interval averages, best-Dice events, learning-rate schedule, checkpoint files."""
