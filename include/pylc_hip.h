@@ -326,7 +326,9 @@ int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long lo
 int pylc_debug_set_big_tile(int mode);
 /* bit 3 (8): wgrad without the uniform-geometry fast path; bit 4 (16): finer stamps (see pylc_debug_pp_stamps);
  * bit 6 (64): ping-pong kernel as persistent blocks (one per CU) instead of one block per tile; bit 7 (128): padded
- * 80-byte LDS rows and two stages instead of swizzled 64-byte rows and three; bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs */
+ * 80-byte LDS rows and two stages instead of swizzled 64-byte rows and three; bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs;
+ * bit 10 (1024): take the 256x128 tile even for launches of fewer than 192 tiles (tools/pp_stamps.py: a tile's phases with few
+ * CUs active) */
 int pylc_debug_pp_flags(int flags);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */

@@ -510,6 +510,17 @@ __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Sum over the 16 lanes of a DPP row (same fixed order in every lane): quad butterflies, then the two mirrors.
+__device__ __forceinline__ float row_sum16(float v) {
+#define PYLC_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    PYLC_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+    PYLC_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+    PYLC_DPP_ADD(0x141);     // row_half_mirror: lane i <-> 7 - i of each half row
+    PYLC_DPP_ADD(0x140);     // row_mirror: lane i <-> 15 - i
+#undef PYLC_DPP_ADD
+    return v;
+}
+
 // M16 (with SWZ): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- same FLOPs per
 // matrix-pipe cycle, same LDS traffic, but 16 % more sustained throughput at the board's power cap (bare loops on random
 // data: 2005 vs 1690 TFLOP/s, tools/micro/mfma_shapes.hip).  Wave tile 64x64 = 4x4 tiles of 16x16.
@@ -536,6 +547,14 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
+    // whole-tile phases (slots 248..252 of each group's stamp row): block start, main loop start, main loop end, fold done, stores issued
+#define PP_STAMP_AT(slot)                                                                                              \
+    if constexpr (STAMPS) {                                                                                            \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)                                                               \
+            reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (S3 ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + (slot)] = \
+                __builtin_amdgcn_s_memtime();                                                                          \
+    }
+    PP_STAMP_AT(248);
 
     // Tile loop: normally one tile per block (grid = n_tiles); with fewer blocks than tiles each block walks a strided
     // share (persistent mode, see launch_gg_pp).
@@ -564,17 +583,28 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     }
     const int T = a.TR * a.TS;
     const int nchunks = (a.Cin + BK - 1) / BK;
+    // Taps that reach at least one valid input pixel of this tile (the others are skipped): a ballot per tap gives the wave's
+    // mask, the 8 wave masks meet in LDS behind ONE barrier.  (A __syncthreads_or per tap -- two barriers and an LDS reduction
+    // each -- made the prologue of every 3x3 tile 10 k cycles longer than a 1x1 tile's: tools/pp_stamps.py.)
     unsigned long long tapmask = ~0ull;
     if (T > 1) {
-        tapmask = 0;
+        __shared__ unsigned long long s_wave_taps[8];
+        unsigned long long mine = 0;
         for (int t = 0; t < T; ++t) {
             const int dh = a.dh0 + (t / a.TS) * a.dh_step, dw = a.dw0 + (t % a.TS) * a.dw_step;
             int any = 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 any |= ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);
-            if (__syncthreads_or(any)) tapmask |= 1ull << t;
+            if (__builtin_amdgcn_ballot_w64(any != 0) != 0) mine |= 1ull << t;
         }
+        if (lane == 0) s_wave_taps[wave] = mine;
+        __syncthreads();
+        unsigned long long all = 0;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) all |= s_wave_taps[wv];
+        tapmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(all >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)all);
     }
     const int ntaps = __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
     const int S = ntaps * nchunks;
@@ -702,9 +732,11 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                 for (int pl = 0; pl < 2; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * LDB + i * 16 * LDB + koff[0]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[j][0], acc_lo[i][j], 0, 0, 0);
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][1], acc_lo[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][0], acc[i][j], 0, 0, 0);
+                    // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels
+                    // 4 (l >> 4) .. +3), which is what lets the epilogue store 16 bytes per lane
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
                 }
             }
         } else {
@@ -756,6 +788,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             load(R0, 2 < S);                                  // tile 2
             load(R1, 3 < S);                                  // tile 3
             __syncthreads();
+            PP_STAMP_AT(249);
             int sc = 0;                                       // stage of the tile being computed
             auto plus1 = [](int x) { return x == 2 ? 0 : x + 1; };
             auto plus2 = [](int x) { return x == 0 ? 2 : x - 1; };
@@ -860,15 +893,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         }
         }
 #undef PP_SYNC
-        if constexpr (STAMPS) {
-            if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && a.dbg != nullptr)
-                for (int k = 0; k < 256; ++k)
-                    a.dbg[(threadIdx.x >> 8) * 256 + k] = k < n_stamp
-                        ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (S3 ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
-            __syncthreads();
-        }
+        PP_STAMP_AT(250);
     }
-#undef PP_STAMP
 
     // ---- epilogue (as gather_gemm_kernel) ----
     int* rowoff = reinterpret_cast<int*>(smem);            // element offsets of the tile's output rows (< 2^31: check_desc), -1 = no row
@@ -895,9 +921,115 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 #pragma unroll
             for (int r = 0; r < AR; ++r) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
     __builtin_amdgcn_sched_barrier(0);
-    // accumulator layout: 32x32 tiles -- lane l holds column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5);
-    //                     16x16 tiles -- lane l holds column l & 15, rows 4 (l >> 4) + r
-    constexpr int TS = M16 ? 16 : 32;
+    PP_STAMP_AT(251);
+    if constexpr (M16) {
+    // 16x16 tiles, transposed (see compute()): lane l holds pixel row l & 15 of every 16-row tile and the four CONSECUTIVE
+    // channels 4 (l >> 4) .. +3 of every 16-channel tile -> one 16-byte store per tile and lane.
+    // The epilogue runs in two phases because gfx9 counts loads AND stores in one in-order counter (vmcnt): any load issued after
+    // a store -- an old value to accumulate into, a bias, even the reload of a spilled register -- can only be waited for by
+    // waiting for that store to reach memory first.  Interleaved with the stores (as they were: per 16 x 16 tile), such waits cost
+    // 14-16 k cycles per output tile, as much as the 8 K-steps of a short-K 1x1 conv (tools/pp_stamps.py; the stores alone take
+    // 2-4 k: tools/micro/store_patterns.hip).  Phase 1: every row lookup, element offset, bias / scale vector and old value;
+    // phase 2: arithmetic and stores only.
+    const float* extra = a.accumulate ? a.y : (EP ? a.ep_res : nullptr);
+    const bool ep = EP && a.ep_scale != nullptr;
+    int eoff[AT][AT];                                            // element offset of (pixel row of tile i, channel quad of tile j), -1: not stored
+    float bv[AT][4], esc[EP ? AT : 1][4], esh[EP ? AT : 1][4];
+    {
+        int offs[AT];
+#pragma unroll
+        for (int i = 0; i < AT; ++i) offs[i] = rowoff[wave_m * WM + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < AT; ++j) {
+            const int n4 = n0 + wave_n * WN + j * 16 + 4 * (lane >> 4);
+            const bool nok = n4 < a.N_store;                    // N_store % 4 == 0: all four channels or none
+#pragma unroll
+            for (int i = 0; i < AT; ++i) eoff[i][j] = (nok && offs[i] >= 0) ? offs[i] + n4 : -1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bv[j][r] = (a.bias != nullptr && n4 + r < a.N) ? a.bias[n4 + r] : 0.f;
+                if constexpr (EP) {
+                    esc[j][r] = (ep && n4 + r < a.N) ? a.ep_scale[n4 + r] : 0.f;
+                    esh[j][r] = (ep && n4 + r < a.N) ? a.ep_shift[n4 + r] : 0.f;
+                }
+            }
+        }
+    }
+    float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+    // phase 2 for the channel tiles [j0, j0 + NJ): (a) ALL the arithmetic, unconditionally and in place -- this is where every
+    // loaded value (bias, scale, old value) is waited for; (b) the stores, which then depend on ALU results only.  (With the
+    // arithmetic inside the per-tile `if (stored)` blocks the compiler has to re-wait for the conditionally loaded registers in
+    // every block, and once a store is in flight such a wait can only be vmcnt(0): each store waited for the previous one to
+    // reach memory -- 16 x 800 cycles per output tile.)
+    auto finish = [&](auto has_prev, auto j0c, const f32x4v (&prev)[AT][2]) {
+        constexpr int j0 = decltype(j0c)::value;
+        constexpr int NJ = decltype(has_prev)::value ? 2 : AT;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = j0 + jj;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < AT; ++i) {
+                const bool stored = eoff[i][j] >= 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = acc[i][j][r] + bv[j][r];
+                    if constexpr (EP) {
+                        if (ep) val = val * esc[j][r] + esh[j][r];       // BatchNorm-apply's own expression and order
+                    }
+                    if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
+                    if (EP && a.ep_relu) val = fmaxf(val, 0.f);
+                    acc[i][j][r] = val;
+                    const float cv = stored ? val : 0.f;                 // rows / channels outside the tensor do not count
+                    cs[r] += cv;
+                    css[r] += cv * cv;
+                    if (EP) ep_max = fmaxf(ep_max, fabsf(cv));
+                }
+            }
+            if (do_stats) {                                         // the 16 lanes of a DPP row hold the 16 pixel rows of one channel quad
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r]; sdst[(j * 16 + r) * 2 + 1] = css[r]; }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+                if (eoff[i][j0 + jj] >= 0) *reinterpret_cast<f32x4v*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
+    };
+    __builtin_amdgcn_sched_barrier(0);                          // nothing of phase 1 may sink below a store
+    if (extra == nullptr) {
+        const f32x4v none[AT][2] = {};
+        finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
+    } else {
+        // accumulate / fused residual: the old values of half the tile at a time (32 registers) -- one wait behind stores per
+        // tile instead of one per 16 x 16 tile
+        f32x4v prev[AT][2];
+        auto fetch = [&](int j0) {
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+                    prev[i][jj] = eoff[i][j0 + jj] >= 0 ? *reinterpret_cast<const f32x4v*>(extra + eoff[i][j0 + jj]) : zero;
+                }
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
+    }
+    } else {
+    // accumulator layout: 32x32 tiles -- lane l holds column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    constexpr int TS = 32;
 #pragma unroll
     for (int j = 0; j < AT; ++j) {
         const int n = n0 + wave_n * WN + j * TS + (lane & (TS - 1));
@@ -911,11 +1043,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             int offs[AR];
             float prev[AR];
 #pragma unroll
-            for (int r = 0; r < AR; ++r) {
-                const int row = M16 ? wave_m * WM + i * 16 + 4 * (lane >> 4) + r
-                                    : wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                offs[r] = rowoff[row];
-            }
+            for (int r = 0; r < AR; ++r) offs[r] = rowoff[wave_m * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
             // accumulate / fused residual: fetch all values first (independent loads in flight), then add and store --
             // interleaved load/store pairs serialise because the compiler cannot prove the rows distinct
             const float* extra = a.accumulate ? a.y : (EP ? a.ep_res : nullptr);
@@ -938,9 +1066,6 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             }
         }
         if (do_stats) {
-            if constexpr (M16) {                                    // lanes l, l+16, l+32, l+48 hold the same column
-                cs += __shfl_xor(cs, 16, 64); css += __shfl_xor(css, 16, 64);
-            }
             cs += __shfl_xor(cs, 32, 64);                           // lanes l and l+32 hold the same column
             css += __shfl_xor(css, 32, 64);
             if (lane < TS) {
@@ -949,6 +1074,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                 d[1] = css;
             }
         }
+    }
     }
     if (do_stats) {
         __syncthreads();
@@ -965,8 +1091,18 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         }
     }
     if (EP && a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
+    if constexpr (STAMPS) __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP_AT(252);
+    if constexpr (STAMPS) {
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && a.dbg != nullptr)
+            for (int k = 0; k < 256; ++k)
+                a.dbg[(threadIdx.x >> 8) * 256 + k] = (k < n_stamp || k >= 248)
+                    ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + (S3 ? 3 : 2) * PP_STAGE)[(threadIdx.x >> 8) * 256 + k] : 0ull;
+    }
     __syncthreads();          // the next tile reuses the LDS stages and the epilogue tables
     }
+#undef PP_STAMP
+#undef PP_STAMP_AT
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1468,7 +1604,10 @@ static int launch_gg(GatherGemmArgs& a, hipStream_t st) {
 
 // geometry / size conditions of the ping-pong kernel (on top of: f16x3 mode, stored N > 64, >= 192 tiles of 256x128)
 static bool takes_pp(const GatherGemmArgs& a) {
-    return g_big_tile == 2 && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) && a.w_bytes > 0 && a.w_bytes < (1ll << 31);
+    // (16-byte epilogue stores: pitches and stored widths are multiples of 4 floats by check_desc; the bases must be aligned too)
+    const bool aligned = a.y_pitch % 4 == 0 && a.N_store % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.ep_res) & 15) == 0;
+    return g_big_tile == 2 && aligned && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) && a.w_bytes > 0 && a.w_bytes < (1ll << 31);
 }
 
 static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
@@ -1490,8 +1629,9 @@ static int launch_gg_pp(GatherGemmArgs& a, hipStream_t st) {
     if (a.ep_scale != nullptr) {                 // fused inference epilogue: its own instantiations of the default variant
         if (bpl) hipLaunchKernelGGL((gather_gemm_pp_kernel<false, true, true, true, true, true>), g, b, 3 * PP_STAGE_SWZ, st, a);
         else hipLaunchKernelGGL((gather_gemm_pp_kernel<false, false, true, true, true, true>), g, b, 3 * PP_STAGE_SWZ, st, a);
-    } else if (a.dbg != nullptr) {               // stamped builds (tools/pp_stamps.py): 32x32x16 forms only
-        if (bpl && swz) PYLC_PP(true, true, true, false);
+    } else if (a.dbg != nullptr) {               // stamped builds (tools/pp_stamps.py)
+        if (bpl && m16) PYLC_PP(true, true, true, true);
+        else if (bpl && swz) PYLC_PP(true, true, true, false);
         else if (bpl) PYLC_PP(true, true, false, false);
         else PYLC_PP(true, false, false, false);
     } else if (bpl) {
@@ -1517,7 +1657,7 @@ static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
     }
     if (a.N_store <= 32) return launch_gg<128, 32, 32, 32, false, PREC>(a, st);
     if (a.N_store <= 64) return launch_gg<256, 64, 64, 64, false, PREC>(a, st);
-    if (PREC != 0 && g_big_tile && (long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192) {
+    if (PREC != 0 && g_big_tile && ((long long)cdiv(a.M, 256) * cdiv(a.N_store, 128) >= 192 || (g_pp_flags & 1024))) {
         if (PREC == 2 && takes_pp(a)) return launch_gg_pp(a, st);
         return launch_gg<256, 128, 64, 64, false, PREC>(a, st);      // 8 waves: halves LDS-write bytes per MFMA
     }
@@ -1557,6 +1697,7 @@ int conv_init() {
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, false, false, false>), 2 * PP_STAGE + 4096));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, false, false>), 2 * PP_STAGE + 4096));
     PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, true, false>), 3 * PP_STAGE_SWZ + 4096));
+    PYLC_HIP(opt_in_lds((gather_gemm_pp_kernel<true, true, true, true>), 3 * PP_STAGE_SWZ + 4096));
 #undef PYLC_OPT_GG
     PYLC_HIP(opt_in_lds(wgrad_kernel<128, 128, 64, 64, false>, wg_smem<128, 128>()));
     PYLC_HIP(opt_in_lds(wgrad_kernel<64, 64, 32, 32, false>, wg_smem<64, 64>()));

@@ -112,7 +112,7 @@ class KernelTimer:
         terms = self.TERMS.get(self.mode, 6)
         peak = peak_16bit_tflops / terms
         arith = ('3-term scaled fp16 split ("f16x3": a0b0 + 2^-11 (a1b0 + a0b1), cross terms in their own fp32 accumulator) '
-                 'on v_mfma_f32_32x32x16_f16' if self.mode == 2 else
+                 'on v_mfma_f32_16x16x32_f16' if self.mode == 2 else
                  '6-term bf16 split ("bf16x6") on v_mfma_f32_32x32x16_bf16')
         return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                 'kernel': self.KERNEL, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1),

@@ -477,6 +477,47 @@ def test_prepared_filter_planes_match_inline_split(dev):
         assert torch.equal(y2, ref(x))
 
 
+def test_conv_multi_round_launches_are_bit_identical(dev):
+    """Launches with more than one 256x128 tile per CU: one block per tile (default) against persistent blocks walking a
+    strided share of the tiles (debug flag 64) -- not a bit may change in the forward with fused BatchNorm statistics, the
+    dgrad, or a dgrad accumulating into another conv's gradient, on row-aligned, ragged (M and N not multiples of the tile)
+    and tap-skipping atrous geometries; every configuration runs twice (repeat launches are deterministic)."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib
+    if lib.pylc_get_conv_precision() != 2:
+        pytest.skip('variants of the f16x3 ping-pong kernel')
+    cases = [(8, 128, 256, 3, 1, 1, 96),        # 576 tiles, 36 K-steps
+             (16, 256, 1024, 1, 0, 1, 48),      # 1152 tiles of a short-K 1x1
+             (5, 64, 200, 3, 1, 1, 90),         # ragged: M = 40500, N = 200
+             (32, 64, 384, 3, 12, 12, 32)]      # atrous taps that fall into the padding are skipped per tile
+    for b, cin, cout, k, pad, dil, hw in cases:
+        x = to_dev_nhwc(rnd(31, b, cin, hw, hw), dev).requires_grad_(True)
+        w1 = to_dev_nhwc(rnd(32, cout, cin, k, k, scale=0.05), dev).requires_grad_(True)
+        w2 = to_dev_nhwc(rnd(33, cout, cin, k, k, scale=0.05), dev).requires_grad_(True)
+        dy1 = to_dev_nhwc(rnd(34, b, cout, hw, hw), dev)
+        dy2 = to_dev_nhwc(rnd(35, b, cout, hw, hw), dev)
+        res = {}
+        try:
+            for flags in (0, 0, 64, 64):
+                lib.pylc_debug_pp_flags(flags)
+                x.grad = w1.grad = w2.grad = None
+                link = ops.ResidualLink()
+                y1 = ops.conv2d(x, w1, None, 1, pad, dil, want_stats=True, res_link=link)
+                y2 = ops.conv2d(x, w2, None, 1, pad, dil, res_link=link)
+                torch.autograd.backward([y1, y2], [dy1, dy2])       # the second dgrad to run accumulates into the first one's buffer
+                ops.sync_side_streams()
+                torch.cuda.synchronize()
+                got = (y1.detach().clone(), y1._pylc_sums.clone(), y2.detach().clone(), x.grad.clone())
+                if flags in res:
+                    assert all(torch.equal(p, q) for p, q in zip(res[flags], got)), ('repeat launch differs', flags, hw)
+                res[flags] = got
+        finally:
+            lib.pylc_debug_pp_flags(0)
+        for p, q in zip(res[0], res[64]):
+            assert torch.equal(p, q), (b, cin, cout, k, dil, hw)
+        assert torch.isfinite(res[0][3]).all() and res[0][3].abs().max().item() > 0
+
+
 def test_conv_kernel_variants_are_bit_identical(dev):
     """The scheduling variants of one arithmetic must not change a single bit: the 32x32x16-MFMA forward / dgrad kernels
     (ping-pong with swizzled or padded LDS rows, lock-step) among themselves, and the wgrad fast paths vs the general path

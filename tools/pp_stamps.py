@@ -38,12 +38,18 @@ if int(os.environ.get('PP_FLAGS', '0')) & 16:
     names = {0: ['compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar'],
              1: ['vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar']}
 for g in (0, 1):
-    ts = [int(v) for v in t[g] if v != 0]
+    ph = [int(v) for v in t[g][248:253]]
+    if all(ph):        # whole-tile phases of block 0 (ticks of s_memtime: 10 ns)
+        print('group', g, 'tile phases [ticks]: prologue (geometry, first loads, first LDS stores)', ph[1] - ph[0], '| main loop', ph[2] - ph[1],
+              '| fold', ph[3] - ph[2], '| epilogue stores + statistics', ph[4] - ph[3], '| total', ph[4] - ph[0])
+    ts = [int(v) for v in t[g][:248] if v != 0]
     base = ts[0]
     print('group', g, 'stamps', len(ts), 'clock units: s_memtime ticks')
     # average segment durations over pairs 2.. (skip warm-up)
     k = len(names[g])
     n = (len(ts) - 1) // k
+    if n < 3:
+        continue
     acc = [0] * k
     for p in range(1, n):
         for j in range(k):
