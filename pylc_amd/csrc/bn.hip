@@ -43,21 +43,26 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             const bool remask = MODE == 1 && relu && out == nullptr;      // ReLU mask recomputed from y: out = max(y*scale + shift, 0)
             if (MODE == 1) { mu = ld4(mean + 4 * cv); is = ld4(invstd + 4 * cv); }
             if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
-            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-                if (MODE == 0) {
-                    const f32x4 v = ld4(a + r * a_pitch + 4 * cv);
-                    s0 += v;
-                    s1 += v * v;
-                } else {
-                    f32x4 gg = ld4(a + r * a_pitch + 4 * cv);
-                    const f32x4 yv = ld4(y + r * y_pitch + 4 * cv);
-                    if (remask) gg = relu_mask(gg, yv * sc + sh);          // the forward's own expression: identical bits
-                    else if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
-                    const f32x4 xh = (yv - mu) * is;
-                    s0 += gg;
-                    s1 += gg * xh;
-                }
-            }
+            const bool use_out = MODE == 1 && relu && !remask;
+            f32x4 va[kRowBatch], vy[kRowBatch], vo[kRowBatch];
+            walk_rows(r_begin + ty, r_end, g.RL,
+                [&](int u, long long r) {
+                    va[u] = ld4(a + r * a_pitch + 4 * cv);
+                    if (MODE == 1) vy[u] = ld4(y + r * y_pitch + 4 * cv);
+                    if (use_out) vo[u] = ld4(out + r * out_pitch + 4 * cv);
+                },
+                [&](int u, long long, bool valid) {
+                    if (MODE == 0) {
+                        if (valid) { s0 += va[u]; s1 += va[u] * va[u]; }
+                    } else {
+                        f32x4 gg = va[u];
+                        if (remask) gg = relu_mask(gg, vy[u] * sc + sh);   // the forward's own expression: identical bits
+                        else if (relu) gg = relu_mask(gg, vo[u]);
+                        const f32x4 xh = (vy[u] - mu) * is;
+                        if (valid) { s0 += gg; s1 += gg * xh; }
+                    }
+                },
+                [](int, long long) {});
         }
         red[0][threadIdx.x] = s0;
         red[1][threadIdx.x] = s1;
@@ -172,19 +177,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (ty < g.RL) {
         for (int cv = tx; cv < g.CV; cv += g.cols) {
             const f32x4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
-            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-                f32x4 v = ld4(y + r * y_pitch + 4 * cv) * sc + sh;
-                if (res != nullptr) v += ld4(res + r * res_pitch + 4 * cv);
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                st4(out + r * out_pitch + 4 * cv, v);
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            }
+            f32x4 vy[kRowBatch], vr[kRowBatch];
+            walk_rows(r_begin + ty, r_end, g.RL,
+                [&](int u, long long r) {
+                    vy[u] = ld4(y + r * y_pitch + 4 * cv);
+                    if (res != nullptr) vr[u] = ld4(res + r * res_pitch + 4 * cv);
+                },
+                [&](int u, long long, bool valid) {
+                    f32x4 v = vy[u] * sc + sh;
+                    if (res != nullptr) v += vr[u];
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    vy[u] = v;
+                    if (valid) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                },
+                [&](int u, long long r) { st4(out + r * out_pitch + 4 * cv, vy[u]); });
         }
     }
     if (amax_out != nullptr) amax_commit(amax, amax_out);      // range of the output for the f16x3 conv that consumes it
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
+__global__ __launch_bounds__(256, 4) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
                                                            const float* __restrict__ out, int out_pitch,
                                                            const float* __restrict__ y, int y_pitch,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -206,17 +218,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const bool remask = relu && out == nullptr;
             f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
             if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
-            for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-                f32x4 gg = ld4(dout + r * dout_pitch + 4 * cv);
-                const f32x4 yv = ld4(y + r * y_pitch + 4 * cv);
-                if (remask) gg = relu_mask(gg, yv * sc + sh);
-                else if (relu) gg = relu_mask(gg, ld4(out + r * out_pitch + 4 * cv));
-                const f32x4 xh = (yv - mu) * is;
-                if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, gg);
-                const f32x4 v = k * (gg - sg - xh * sgx);
-                st4(dy + r * dy_pitch + 4 * cv, v);
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            }
+            const bool use_out = relu && !remask;
+            constexpr int NB = 3;            // 3 rows x 3 tensors in flight per wave and still 4 waves per SIMD (128 registers)
+            f32x4 vg[NB], vy[NB], vo[NB];
+            walk_rows<NB>(r_begin + ty, r_end, g.RL,
+                [&](int u, long long r) {
+                    vg[u] = ld4(dout + r * dout_pitch + 4 * cv);
+                    vy[u] = ld4(y + r * y_pitch + 4 * cv);
+                    if (use_out) vo[u] = ld4(out + r * out_pitch + 4 * cv);
+                },
+                [&](int u, long long, bool valid) {
+                    f32x4 gg = vg[u];
+                    if (remask) gg = relu_mask(gg, vy[u] * sc + sh);
+                    else if (relu) gg = relu_mask(gg, vo[u]);
+                    const f32x4 xh = (vy[u] - mu) * is;
+                    const f32x4 v = k * (gg - sg - xh * sgx);
+                    vg[u] = gg;                                      // the masked gradient (residual branch) and dy, kept for the store pass
+                    vy[u] = v;
+                    if (valid) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                },
+                [&](int u, long long r) {
+                    if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, vg[u]);
+                    st4(dy + r * dy_pitch + 4 * cv, vy[u]);
+                });
         }
     }
     if (amax_dy != nullptr) amax_commit(amax, amax_dy);

@@ -419,13 +419,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
     float ep_max = 0.f;
     const bool do_stats = a.stats != nullptr;
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;     // exact (powers of two); applied one after the other
+    // Per-column vectors of ALL column tiles are fetched and waited for here, before the first store: gfx9 counts loads and
+    // stores in one in-order counter, so a wait for them inside the conditional store blocks below would be repeated in every
+    // block and, behind a store in flight, could only be vmcnt(0) -- every store would wait for the previous one to reach memory.
+    const bool ep = a.ep_scale != nullptr;
+    float bvs[NT], escs[NT], eshs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
+        bvs[j] = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+        escs[j] = (ep && n < a.N) ? a.ep_scale[n] : 0.f;
+        eshs[j] = (ep && n < a.N) ? a.ep_shift[n] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bvs[j]), "v"(escs[j]), "v"(eshs[j]));
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wave_n * WN + j * 32 + (lane & 31);
         const bool nok = n < a.N_store;
-        const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
-        const bool ep = a.ep_scale != nullptr;
-        const float esc = (ep && n < a.N) ? a.ep_scale[n] : 0.f, esh = (ep && n < a.N) ? a.ep_shift[n] : 0.f;
+        const float bv = bvs[j], esc = escs[j], esh = eshs[j];
         float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -441,21 +453,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) prev[r] = (nok && offs[r] >= 0) ? extra[offs[r] + n] : 0.f;
             }
+            // arithmetic for all 16 values first, unconditionally (this is where the old values are waited for), then stores that
+            // depend on ALU results only -- see the note on vmcnt above
+            float vals[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (nok && offs[r] >= 0) {
-                    float val = acc[i][j][r];
-                    if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
-                    val += bv;
-                    if (ep) val = val * esc + esh;                   // BatchNorm-apply's own expression and order
-                    if (extra != nullptr) val += prev[r];
-                    if (a.ep_relu) val = fmaxf(val, 0.f);
-                    a.y[offs[r] + n] = val;
-                    cs += val;
-                    css += val * val;
-                    ep_max = fmaxf(ep_max, fabsf(val));
-                }
+                float val = acc[i][j][r];
+                if constexpr (PREC == 2) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                val += bv;
+                if (ep) val = val * esc + esh;                       // BatchNorm-apply's own expression and order
+                if (extra != nullptr) val += prev[r];
+                if (a.ep_relu) val = fmaxf(val, 0.f);
+                vals[r] = val;
+                const float cv = (nok && offs[r] >= 0) ? val : 0.f;  // rows / channels outside the tensor do not count
+                cs += cv;
+                css += cv * cv;
+                ep_max = fmaxf(ep_max, fabsf(cv));
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nok && offs[r] >= 0) a.y[offs[r] + n] = vals[r];
         }
         if (do_stats) {
             cs += __shfl_xor(cs, 32, 64);                           // lanes l and l+32 hold the same column

@@ -32,6 +32,36 @@ inline Slab make_slab(long long M, int C) {
     return g;
 }
 
+// A thread's rows r0, r0 + RL, ... are walked kRowBatch at a time: `load(u, row)` for every row of the batch first, then
+// `math(u, row, valid)` for every row (unconditional arithmetic on the loaded values), then `store(u, row)` for the valid ones.
+// Why three passes: gfx9 counts vector loads and stores in one in-order counter (vmcnt), and once a store is in flight a wait
+// for an older load can only be vmcnt(0).  A row-at-a-time loop (load, wait, store, next load, wait ...) therefore has ONE
+// 16-byte load in flight per wave and waits for its own previous store every iteration; here a wave has kRowBatch x (loads per
+// row) in flight and meets its stores once per batch.  The tail batch clamps its row indices, so the loads stay unconditional
+// (straight-line code); rows are used in ascending order, so per-thread sums are bit-identical to the row-at-a-time order.
+constexpr int kRowBatch = 4;
+template <int NB = kRowBatch, class L, class M, class S>
+__device__ __forceinline__ void walk_rows(long long r0, long long r_end, int RL, L load, M math, S store) {
+    for (long long r = r0; r < r_end; r += (long long)NB * RL) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const long long rr = r + (long long)u * RL;
+            load(u, rr < r_end ? rr : r_end - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const long long rr = r + (long long)u * RL;
+            math(u, rr, rr < r_end);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const long long rr = r + (long long)u * RL;
+            if (rr < r_end) store(u, rr);
+        }
+    }
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
