@@ -327,6 +327,7 @@ int pylc_debug_set_big_tile(int mode);
 /* bit 3 (8): wgrad without the uniform-geometry fast path; bit 4 (16): finer stamps (see pylc_debug_pp_stamps);
  * bit 6 (64): ping-pong kernel as persistent blocks (one per CU) instead of one block per tile; bit 7 (128): padded
  * 80-byte LDS rows and two stages instead of swizzled 64-byte rows and three; bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs;
+ * bit 12 (4096): ping-pong kernel walks the reduction with channel chunks innermost (the old order) instead of taps innermost;
  * bit 10 (1024): take the 256x128 tile even for launches of fewer than 192 tiles (tools/pp_stamps.py: a tile's phases with few
  * CUs active) */
 int pylc_debug_pp_flags(int flags);

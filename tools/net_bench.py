@@ -15,7 +15,17 @@ for name in (sys.argv[1:] or list(CFG)):
     model = Model(meta, dev).build()
     x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (b, ch, hw, hw)).astype(np.float32)).to(dev)
     y = torch.from_numpy(np.random.RandomState(2).randint(0, ncls, (b, hw, hw)).astype(np.int64)).to(dev)
-    for _ in range(2): model.train(x, y)
+    # settle like bench.py: a process started right after another GPU job sees that job's memory teardown for a while
+    # (measured: R101 at 85 instead of 340 tiles/s for the first seconds after a 100 GB pytest process had exited)
+    best, streak = float('inf'), 0
+    for _ in range(40):
+        torch.cuda.synchronize(); t_s = time.perf_counter()
+        model.train(x, y)
+        torch.cuda.synchronize(); d_s = time.perf_counter() - t_s
+        best = min(best, d_s)
+        streak = streak + 1 if d_s <= 1.02 * best else 0
+        if streak >= 3:
+            break
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 5
     for _ in range(n): model.train(x, y)
