@@ -520,7 +520,7 @@ def test_conv_multi_round_launches_are_bit_identical(dev):
 
 def test_conv_kernel_variants_are_bit_identical(dev):
     """The scheduling variants of one arithmetic must not change a single bit: the 32x32x16-MFMA forward / dgrad kernels
-    (ping-pong with swizzled or padded LDS rows, lock-step) among themselves, and the wgrad fast paths vs the general path
+    (ping-pong with swizzled or padded LDS rows, lock-step -- in the same reduction order) among themselves, and the wgrad fast paths vs the general path
     (same tiles, same reduction order).  The default 16x16x32-MFMA kernel sums each 32-deep step in one instruction instead
     of two, so it agrees with them to fp32 rounding only."""
     from pylc_amd import ops
@@ -533,7 +533,7 @@ def test_conv_kernel_variants_are_bit_identical(dev):
         dy = to_dev_nhwc(rnd(23, 8, 256, hw, hw), dev)
         res = {}
         for name, big, flags in (('default', 2, 0), ('pp32_swizzled', 2, 256), ('pp32_padded', 2, 128), ('lockstep', 1, 0),
-                                 ('general_wgrad', 2, 8)):
+                                 ('pp32_chunk_inner', 2, 256 | 4096), ('general_wgrad', 2, 8)):
             lib.pylc_debug_set_big_tile(big)
             lib.pylc_debug_pp_flags(flags)
             x.grad = w.grad = None
@@ -544,9 +544,14 @@ def test_conv_kernel_variants_are_bit_identical(dev):
             res[name] = (y.detach().clone(), x.grad.clone(), w.grad.clone())
         lib.pylc_debug_set_big_tile(2)
         lib.pylc_debug_pp_flags(0)
-        for name in ('pp32_padded', 'lockstep'):
-            for a, b in zip(res['pp32_swizzled'], res[name]):
-                assert torch.equal(a, b), (hw, name)
+        for a, b in zip(res['pp32_swizzled'], res['pp32_padded']):
+            assert torch.equal(a, b), (hw, 'pp32_padded')
+        # the ping-pong kernel walks a 3x3 reduction taps-innermost, the lock-step kernel channel-chunks-innermost: same bits
+        # once the ping-pong kernel is told to use that order too (flag 4096), fp32 rounding apart otherwise
+        for a, b in zip(res['pp32_chunk_inner'], res['lockstep']):
+            assert torch.equal(a, b), (hw, 'lockstep')
+        for a, b in zip(res['pp32_swizzled'][:2], res['pp32_chunk_inner'][:2]):
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), hw
         assert all(torch.equal(a, b) for a, b in zip(res['default'], res['general_wgrad'])), hw
         for a, b in zip(res['default'][:2], res['pp32_swizzled'][:2]):
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), hw
