@@ -565,7 +565,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
-    // whole-tile phases (slots 248..252 of each group's stamp row): block start, main loop start, main loop end, fold done, stores issued
+    // whole-tile phases (slots 248..255 of each group's stamp row): block start, main loop start, main loop end, fold done, stores
+    // issued; 253..255 split the prologue: geometry done, first operands landed, first LDS stores done
 #define PP_STAMP_AT(slot)                                                                                              \
     if constexpr (STAMPS) {                                                                                            \
         if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)                                                               \
@@ -810,10 +811,15 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             // previous barrier); tile s+1 was completed before that barrier too.  The two halves of the block do the two
             // segments in opposite order, so on every SIMD one wave is in its MFMA segment while its partner splits / stores /
             // loads -- with no barrier in the middle of the step for either to wait at.
+            PP_STAMP_AT(253);                                 // geometry and tap mask done
             load(R0, true);                                   // tile 0
             load(R1, 1 < S);                                  // tile 1
+            if constexpr (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            PP_STAMP_AT(254);                                 // first operand round trip
             store(0, R0);
             store(1, R1);
+            if constexpr (STAMPS) __builtin_amdgcn_sched_barrier(0);
+            PP_STAMP_AT(255);                                 // split + LDS stores of two operand tiles
             load(R0, 2 < S);                                  // tile 2
             load(R1, 3 < S);                                  // tile 3
             __syncthreads();

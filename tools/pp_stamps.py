@@ -39,7 +39,11 @@ if int(os.environ.get('PP_FLAGS', '0')) & 16:
              1: ['vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute0', 'bar', 'vmwait', 'itemA0', 'itemA1', 'itemB+load', 'bar', 'compute1', 'bar']}
 for g in (0, 1):
     ph = [int(v) for v in t[g][248:253]]
-    if all(ph):        # whole-tile phases of block 0 (ticks of s_memtime: 10 ns)
+    pro = [int(v) for v in t[g][253:256]]
+    if all(ph) and all(pro):
+        print('group', g, 'prologue [ticks]: launch -> geometry / tap mask done', pro[0] - ph[0], '| first operand round trip', pro[1] - pro[0],
+              '| split + LDS stores', pro[2] - pro[1], '| next loads issued + barrier', ph[1] - pro[2])
+    if all(ph):        # whole-tile phases of block 0 (ticks = shader cycles)
         print('group', g, 'tile phases [ticks]: prologue (geometry, first loads, first LDS stores)', ph[1] - ph[0], '| main loop', ph[2] - ph[1],
               '| fold', ph[3] - ph[2], '| epilogue stores + statistics', ph[4] - ph[3], '| total', ph[4] - ph[0])
     ts = [int(v) for v in t[g][:248] if v != 0]
