@@ -19,25 +19,30 @@ for name in (sys.argv[1:] or list(CFG)):
     # (measured: R101 at 85 instead of 340 tiles/s for the first seconds after a 100 GB pytest process had exited)
     best, streak = float('inf'), 0
     for _ in range(40):
+        n_malloc = torch.cuda.memory_stats().get('num_device_alloc', 0)
         torch.cuda.synchronize(); t_s = time.perf_counter()
         model.train(x, y)
         torch.cuda.synchronize(); d_s = time.perf_counter() - t_s
         best = min(best, d_s)
-        streak = streak + 1 if d_s <= 1.02 * best else 0
+        steady = torch.cuda.memory_stats().get('num_device_alloc', 0) == n_malloc      # no hipMalloc inside the step
+        streak = streak + 1 if (d_s <= 1.02 * best and steady) else 0
         if streak >= 3:
             break
+    mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 5
     for _ in range(n): model.train(x, y)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0) - mallocs      # > 0: the caching allocator is not in steady state
     model.net.eval()
     with torch.no_grad():
         for _ in range(2): model.test(x)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n): model.test(x)
         torch.cuda.synchronize(); di = (time.perf_counter() - t0) / n
-    print('%-28s train %7.1f ms/step %7.1f tiles/s | inference %7.1f ms/batch %7.1f tiles/s | peak mem %.1f GB' % (
-        name, dt * 1e3, b / dt, di * 1e3, b / di, torch.cuda.max_memory_allocated() / 2**30), flush=True)
+    print('%-28s train %7.1f ms/step %7.1f tiles/s | inference %7.1f ms/batch %7.1f tiles/s | peak mem %.1f GB (reserved %.1f GB, %d '
+          'hipMalloc calls inside the timed steps)' % (name, dt * 1e3, b / dt, di * 1e3, b / di, torch.cuda.max_memory_allocated() / 2**30,
+                                                     torch.cuda.memory_reserved() / 2**30, mallocs), flush=True)
     del model, x, y
     import gc; gc.collect()          # the arena <-> module hook cycle needs the collector
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
