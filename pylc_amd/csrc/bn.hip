@@ -255,12 +255,19 @@ __global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ a, 
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
     for (int cv = tx; cv < g.CV; cv += g.cols) {
-        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            f32x4 v = ld4(a + r * a_pitch + 4 * cv);
-            if (MODE == 0) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else v = relu_mask(v, ld4(o + r * o_pitch + 4 * cv));
-            st4(dst + r * dst_pitch + 4 * cv, v);
-        }
+        f32x4 va[kRowBatch], vo[kRowBatch];
+        walk_rows(r_begin + ty, r_end, g.RL,
+            [&](int u, long long r) {
+                va[u] = ld4(a + r * a_pitch + 4 * cv);
+                if (MODE != 0) vo[u] = ld4(o + r * o_pitch + 4 * cv);
+            },
+            [&](int u, long long, bool) {
+                f32x4 v = va[u];
+                if (MODE == 0) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else v = relu_mask(v, vo[u]);
+                va[u] = v;
+            },
+            [&](int u, long long r) { st4(dst + r * dst_pitch + 4 * cv, va[u]); });
     }
 }
 
@@ -278,15 +285,19 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
     for (int cv = tx; cv < g.CV; cv += g.cols) {
-        for (long long r = r_begin + ty; r < r_end; r += g.RL) {
-            const unsigned long long h = mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r * g.CV + cv + 1));
-            f32x4 v = ld4(x + r * x_pitch + 4 * cv);
-            v.x = ((h & 0xFFFF) >= thresh16) ? v.x * keep_scale : 0.f;
-            v.y = (((h >> 16) & 0xFFFF) >= thresh16) ? v.y * keep_scale : 0.f;
-            v.z = (((h >> 32) & 0xFFFF) >= thresh16) ? v.z * keep_scale : 0.f;
-            v.w = (((h >> 48) & 0xFFFF) >= thresh16) ? v.w * keep_scale : 0.f;
-            st4(out + r * out_pitch + 4 * cv, v);
-        }
+        f32x4 vx[kRowBatch];
+        walk_rows(r_begin + ty, r_end, g.RL,
+            [&](int u, long long r) { vx[u] = ld4(x + r * x_pitch + 4 * cv); },
+            [&](int u, long long r, bool) {
+                const unsigned long long h = mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r * g.CV + cv + 1));
+                f32x4 v = vx[u];
+                v.x = ((h & 0xFFFF) >= thresh16) ? v.x * keep_scale : 0.f;
+                v.y = (((h >> 16) & 0xFFFF) >= thresh16) ? v.y * keep_scale : 0.f;
+                v.z = (((h >> 32) & 0xFFFF) >= thresh16) ? v.z * keep_scale : 0.f;
+                v.w = (((h >> 48) & 0xFFFF) >= thresh16) ? v.w * keep_scale : 0.f;
+                vx[u] = v;
+            },
+            [&](int u, long long r) { st4(out + r * out_pitch + 4 * cv, vx[u]); });
     }
 }
 
