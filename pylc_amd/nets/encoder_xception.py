@@ -58,6 +58,10 @@ class Block(nn.Module):
     def forward(self, inp):
         if self.start_with_relu:
             inp = ops.relu(inp)                   # aliasing quirk: both branches see relu(inp)
+        if self.skip is not None:
+            skip = self.skipbn(self.skip(inp))
+        else:
+            skip = inp
         x = inp
         n = len(self.plan)
         i = 1 if self.start_with_relu else 0
@@ -66,17 +70,15 @@ class Block(nn.Module):
             if kind == 'sep':
                 x = getattr(self.rep, name)(x)
             elif kind == 'bn':
-                fuse = i + 1 < n and self.plan[i + 1][0] == 'relu'     # BN followed by the shared ReLU -> one pass
+                if i == n - 1:          # the branch ends in a BatchNorm: `rep(inp) + skip` (xception.py:97) is its apply pass
+                    return getattr(self.rep, name)(x, residual=skip, relu=False)      # (y*scale + shift) + skip: the same two fp32 operations
+                fuse = self.plan[i + 1][0] == 'relu'                   # BN followed by the shared ReLU -> one pass
                 x = getattr(self.rep, name)(x, relu=fuse)
                 if fuse:
                     i += 1
             else:
                 x = ops.relu(x)
             i += 1
-        if self.skip is not None:
-            skip = self.skipbn(self.skip(inp))
-        else:
-            skip = inp
         return x + skip
 
 

@@ -720,7 +720,11 @@ class BnActFn(torch.autograd.Function):
         else:
             sums_apply = sums
         dy = empty_nhwc(b, c, h, w, dev)
-        g_out = empty_nhwc(b, c, h, w, dev) if (has_res and ctx.needs_input_grad[5]) else None
+        want_res = has_res and ctx.needs_input_grad[5]
+        # without a ReLU the residual's gradient IS dout: hand the tensor on instead of having the kernel write a copy (unless a
+        # conv is going to accumulate its dgrad into the buffer, which must then be ours)
+        res_is_dout = want_res and not relu and not (ctx.res_link is not None and ctx.res_link.armed)
+        g_out = empty_nhwc(b, c, h, w, dev) if (want_res and not res_is_dout) else None
         amax_dy = amax_slot(dev) if ctx.want_amax else None
         check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
                                     ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
@@ -744,6 +748,8 @@ class BnActFn(torch.autograd.Function):
                     dbeta = _deliver_grad(beta, tb)
                 else:
                     dbeta = local_sums[c:].clone()
+        if res_is_dout:
+            g_out = dout
         link = ctx.res_link
         if g_out is not None and link is not None and link.armed and link.buf is None and tuple(g_out.shape) == tuple(y.shape):
             link.buf = g_out         # the first conv's dgrad accumulates into it and returns it as x's whole gradient
