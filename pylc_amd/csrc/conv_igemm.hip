@@ -996,9 +996,10 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     // arithmetic inside the per-tile `if (stored)` blocks the compiler has to re-wait for the conditionally loaded registers in
     // every block, and once a store is in flight such a wait can only be vmcnt(0): each store waited for the previous one to
     // reach memory -- 16 x 800 cycles per output tile.)
-    auto finish = [&](auto has_prev, auto j0c, const f32x4v (&prev)[AT][2]) {
+    constexpr int PJ = EP ? 1 : 2;          // channel tiles per batch of old values (the fused inference epilogue carries 32 more registers)
+    auto finish = [&](auto has_prev, auto j0c, const f32x4v (&prev)[AT][PJ]) {
         constexpr int j0 = decltype(j0c)::value;
-        constexpr int NJ = decltype(has_prev)::value ? 2 : AT;
+        constexpr int NJ = decltype(has_prev)::value ? PJ : AT;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             const int j = j0 + jj;
@@ -1039,17 +1040,17 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     };
     __builtin_amdgcn_sched_barrier(0);                          // nothing of phase 1 may sink below a store
     if (extra == nullptr) {
-        const f32x4v none[AT][2] = {};
+        const f32x4v none[AT][PJ] = {};
         finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
     } else {
-        // accumulate / fused residual: the old values of half the tile at a time (32 registers) -- one wait behind stores per
-        // tile instead of one per 16 x 16 tile
-        f32x4v prev[AT][2];
+        // accumulate / fused residual: the old values of PJ channel tiles at a time (16 registers each) -- one wait behind
+        // stores per batch instead of one per 16 x 16 tile
+        f32x4v prev[AT][PJ];
         auto fetch = [&](int j0) {
 #pragma unroll
             for (int i = 0; i < AT; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
+                for (int jj = 0; jj < PJ; ++jj) {
                     const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
                     prev[i][jj] = eoff[i][j0 + jj] >= 0 ? *reinterpret_cast<const f32x4v*>(extra + eoff[i][j0 + jj]) : zero;
                 }
@@ -1057,10 +1058,22 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
         finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        if constexpr (PJ == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(std::true_type{}, std::integral_constant<int, 1>{}, prev);
+        }
         __builtin_amdgcn_sched_barrier(0);
         fetch(2);
         __builtin_amdgcn_sched_barrier(0);
         finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
+        if constexpr (PJ == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(3);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(std::true_type{}, std::integral_constant<int, 3>{}, prev);
+        }
     }
     } else {
     // accumulator layout: 32x32 tiles -- lane l holds column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
