@@ -37,11 +37,14 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # PYLC_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks sharing ONE GPU (RCCL refuses two ranks on a device)
+        backend = os.environ.get('PYLC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     else:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend)
     runtime.sync_group = dist.group.WORLD
     # One communicator for everything by default: torch.distributed documents concurrent use of several NCCL/RCCL process
