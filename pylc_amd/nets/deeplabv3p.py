@@ -41,7 +41,7 @@ class ASPP(nn.Module):
         g = conv_bn(self.global_avg_pool.child(1), self.global_avg_pool.child(2), g, relu=True)
         link = ops.grad_link(x)                  # the four branch dgrads sum into one buffer (ops.ResidualLink)
         branches = [self.aspp1(x, link), self.aspp2(x, link), self.aspp3(x, link), self.aspp4(x, link), ops.bilinear(g, h, w)]
-        y = torch.cat(branches, 1)               # channel concat of NHWC tensors (plumbing)
+        y = ops.cat_channels(branches)           # channel concat of NHWC tensors (plumbing; the branches' ranges travel along)
         return self.dropout(conv_bn(self.conv1, self.bn1, y, relu=True))
 
 
@@ -57,7 +57,7 @@ class Decoder(nn.Module):
 
     def forward(self, x, low):
         low = conv_bn(self.conv1, self.bn1, low, relu=True, conv_link=ops.grad_link(low))
-        x = torch.cat((ops.bilinear(x, low.shape[2], low.shape[3]), low), 1)
+        x = ops.cat_channels((ops.bilinear(x, low.shape[2], low.shape[3]), low))
         lc = self.last_conv
         x = self.drop3(conv_bn(lc.child(0), lc.child(1), x, relu=True))
         x = self.drop7(conv_bn(lc.child(4), lc.child(5), x, relu=True))

@@ -284,6 +284,34 @@ def tag_amax(t, amax):
     t._pylc_amax = (amax, t._version)
 
 
+def inherit_amax(out, src, binades=0):
+    """Tag `out` with an upper bound of its range derived from the tag of the tensor it was computed from, instead of a read
+    pass over `out`: max-pooling and (align_corners) bilinear interpolation never exceed max|src|; dropout scales by
+    1 / (1 - p) <= 2^binades.  The conv kernels only need an upper bound within a few binades."""
+    tag = getattr(src, '_pylc_amax', None)
+    if tag is None or tag[1] != src._version:
+        return out
+    a = tag[0]
+    if binades:
+        a = a + (binades << 23)            # float bits of 2^binades * amax (one-element int32 tensor)
+    tag_amax(out, a)
+    return out
+
+
+def cat_channels(parts):
+    """torch.cat along the channels (plumbing) that carries the parts' ranges along: max|cat| = max of the parts' maxima
+    (non-negative float bit patterns order like integers)."""
+    out = torch.cat(parts, 1)
+    if ranges_needed():
+        tags = [getattr(t, '_pylc_amax', None) for t in parts]
+        if all(tg is not None and tg[1] == t._version for tg, t in zip(tags, parts)):
+            a = tags[0][0]
+            for tg in tags[1:]:
+                a = torch.maximum(a, tg[0])
+            tag_amax(out, a)
+    return out
+
+
 def amax_of(t):
     """Device int32[1] with the float bits of max|t| for an NHWC activation / gradient: the producer's tag when one is
     attached and still valid, else one read pass over the tensor."""
@@ -816,7 +844,13 @@ class DropoutFn(torch.autograd.Function):
 
 
 def dropout(x, p, seed):
-    return DropoutFn.apply(x, p, seed)
+    out = DropoutFn.apply(x, p, seed)
+    if ranges_needed() and 0.0 <= p < 1.0:
+        binades = 0
+        while (1 << binades) * (1.0 - p) < 1.0:      # 1 / (1 - p) <= 2^binades
+            binades += 1
+        inherit_amax(out, x, binades)
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -865,7 +899,8 @@ class MaxPoolFn(torch.autograd.Function):
 
 
 def maxpool(x, k, stride, pad=0, link=None):
-    return MaxPoolFn.apply(x, k, stride, pad, link)
+    y = MaxPoolFn.apply(x, k, stride, pad, link)
+    return inherit_amax(y, x) if ranges_needed() else y
 
 
 class CropConcatFn(torch.autograd.Function):
@@ -943,7 +978,8 @@ class BilinearFn(torch.autograd.Function):
 
 
 def bilinear(x, oh, ow):
-    return BilinearFn.apply(x, oh, ow)
+    y = BilinearFn.apply(x, oh, ow)
+    return inherit_amax(y, x) if ranges_needed() else y       # interpolation weights are a convex combination
 
 
 class GapFn(torch.autograd.Function):
