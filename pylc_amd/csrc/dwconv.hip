@@ -260,7 +260,7 @@ static DwStrip make_strips(const PylcDwDesc* d, int cols, int RL) {
         if (seg <= 8 || (long long)cdiv(s.n_strips, RL) * waves >= 256 * 12) break;
         seg /= 2;
     }
-    s.strips_per_block = RL * cdiv(s.n_strips, RL * kMaxSlabs);
+    s.strips_per_block = RL * cdiv(s.n_strips, RL * kDefaultSlabs);
     return s;
 }
 
@@ -333,7 +333,7 @@ extern "C" int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const 
 
 extern "C" size_t pylc_dwconv3x3_wgrad_workspace(const PylcDwDesc* d) {
     if (check_dw(d)) return 0;
-    return (size_t)kMaxSlabs * 9 * (size_t)d->C * sizeof(float);
+    return (size_t)kDefaultSlabs * 9 * (size_t)d->C * sizeof(float);
 }
 
 extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -347,7 +347,7 @@ extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const f
     int nslab = g.nslab;
     if (dw_fast(d)) {
         const DwStrip s = make_strips(d, g.cols, g.RL);
-        nslab = cdiv(s.n_strips, s.strips_per_block);          // <= kMaxSlabs by construction
+        nslab = cdiv(s.n_strips, s.strips_per_block);          // <= kDefaultSlabs by construction
         hipLaunchKernelGGL((dw_strip_kernel<2>), dim3(nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), s, g.cols, g.RL,
                            g.CV);
     } else {

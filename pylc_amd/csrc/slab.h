@@ -1,12 +1,27 @@
 // Row-slab walk shared by the HBM-bound [M rows][C channels] kernels (bn.hip, dwconv.hip).
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 namespace pylc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMaxSlabs = 1024;    // measured: 512 slabs (2 blocks/CU) costs the HBM-bound BN kernels 10-25 %
+constexpr int kMaxSlabs = 2048;    // workspace bound; the launch limit is slab_limit()
+constexpr int kDefaultSlabs = 1024;   // dwconv.hip's strip kernels
+// Blocks per launch of the row-slab kernels (BatchNorm, ReLU, dropout).  With one row per iteration 1024 (4 blocks per CU) was
+// best (512 cost 10-25 %); with the batched row walks (walk_rows) a wave keeps 8-12 loads in flight and 768 = three blocks per CU
+// wins inside the training step: 344-345 vs 336-337 tiles/s on one box (640: 342, 896: 340, 1536 / 2048: 335).
+// PYLC_MAX_SLABS overrides for A/B runs.
+constexpr int kRowSlabs = 768;
+inline int slab_limit() {
+    static const int v = [] {
+        const char* e = getenv("PYLC_MAX_SLABS");
+        const int n = e ? atoi(e) : kRowSlabs;
+        return n < 64 ? 64 : (n > kMaxSlabs ? kMaxSlabs : n);
+    }();
+    return v;
+}
 
 struct Slab {
     int CV;             // float4 vectors per row
@@ -23,7 +38,7 @@ inline Slab make_slab(long long M, int C) {
     g.CV = C / 4;
     g.cols = g.CV < 256 ? g.CV : 256;
     g.RL = 256 / g.cols;
-    long long rps = cdiv<long long>(M, kMaxSlabs);
+    long long rps = cdiv<long long>(M, slab_limit());
     const long long min_rows = (long long)g.RL * 8;
     if (rps < min_rows) rps = min_rows;
     rps = cdiv<long long>(rps, g.RL) * g.RL;
