@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (amax_out != nullptr) amax_commit(amax, amax_out);      // range of the output for the f16x3 conv that consumes it
 }
 
-__global__ __launch_bounds__(256, 4) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
+__global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
                                                            const float* __restrict__ out, int out_pitch,
                                                            const float* __restrict__ y, int y_pitch,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_apply_kernel(const float* __res
             f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
             if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
             const bool use_out = relu && !remask;
-            constexpr int NB = 3;            // 3 rows x 3 tensors in flight per wave and still 4 waves per SIMD (128 registers)
+            constexpr int NB = 4;            // 4 rows x 3 tensors in flight per wave; 136 registers = 3 waves per SIMD = the 3 blocks per CU of a 768-slab launch
             f32x4 vg[NB], vy[NB], vo[NB];
             walk_rows<NB>(r_begin + ty, r_end, g.RL,
                 [&](int u, long long r) {

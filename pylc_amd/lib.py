@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpylc_hip.so')
+# PYLC_LIB: load another build of the library (same-box A/B of two builds: tools/ab_builds.sh)
+LIB_PATH = os.environ.get('PYLC_LIB') or os.path.join(_HERE, 'libpylc_hip.so')
 
 ABI_VERSION = 4
 
