@@ -27,14 +27,30 @@ class _Bag:
         self.__dict__.update(state if isinstance(state, dict) else {})
 
 
+# Globals a PyLC model file may legitimately reference.  Model files are downloaded / published artefacts (README.md:90-103),
+# so the unpickler resolves ONLY these; anything else raises instead of importing (and executing) an arbitrary callable.
+_ALLOWED_GLOBALS = {
+    ('collections', 'OrderedDict'),
+    ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_parameter'),
+    ('torch._utils', '_rebuild_parameter_with_state'), ('torch._tensor', '_rebuild_from_type_v2'),
+    ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'), ('torch', 'Tensor'), ('torch.nn.parameter', 'Parameter'),
+    ('torch.serialization', '_get_layout'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype'),
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
+    ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'), ('builtins', 'bytearray'),
+}
+_ALLOWED_TORCH_STORAGE = ('FloatStorage', 'DoubleStorage', 'HalfStorage', 'BFloat16Storage', 'LongStorage', 'IntStorage',
+                          'ShortStorage', 'CharStorage', 'ByteStorage', 'BoolStorage', 'UntypedStorage')
+_BAGGED_PACKAGES = ('config', 'utils', 'models', 'db')      # the reference's own modules: mapped onto attribute bags, never imported
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
+        if module.split('.')[0] in _BAGGED_PACKAGES:
+            return type(name, (_Bag,), {'__module__': module})
+        if (module, name) in _ALLOWED_GLOBALS or (module in ('torch', 'torch.storage') and name in _ALLOWED_TORCH_STORAGE):
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            if module.split('.')[0] in ('config', 'utils', 'models', 'db'):
-                return type(name, (_Bag,), {'__module__': module})
-            raise
+        raise pickle.UnpicklingError('model file references %s.%s, which is not on the allowlist of a PyLC model file' % (module, name))
 
 
 _tolerant_pickle = types.ModuleType('pylc_tolerant_pickle')

@@ -15,6 +15,7 @@ class TileFeeder:
         self.stream = torch.cuda.Stream(device=self.device)
         self.depth = depth
         self._staging = []           # per slot: (pinned img, pinned mask)
+        self._slot_events = {}       # per slot: event of the last H2D copy that READ the pinned buffers
         self._queue = []             # in flight: (dev img, dev mask, event)
         self._slot = 0
 
@@ -25,6 +26,12 @@ class TileFeeder:
         if cur is None or cur[0].shape != img.shape or cur[0].dtype != img.dtype or cur[1].shape != mask.shape or cur[1].dtype != mask.dtype:
             cur = (torch.empty(img.shape, dtype=img.dtype).pin_memory(), torch.empty(mask.shape, dtype=mask.dtype).pin_memory())
             self._staging[slot] = cur
+        # The slot rotation only guarantees that the slot's previous batch was handed to the consumer on the HOST; the
+        # non_blocking copy out of these pinned buffers may still be queued (the host can run steps ahead of the GPU, and a
+        # copy stream can share a hardware queue with the compute stream).  Wait for that copy before overwriting its source.
+        ev = self._slot_events.get(slot)
+        if ev is not None:
+            ev.synchronize()
         cur[0].copy_(img)
         cur[1].copy_(mask)
         return cur
@@ -45,6 +52,7 @@ class TileFeeder:
             d_mask = pmask.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._slot_events[slot] = ev
         self._queue.append((d_img, d_mask, ev))
         return True
 

@@ -192,6 +192,7 @@ class Model:
             runtime.grad_ready = self._bucketer.ready
         loss.backward()
         ops.sync_side_streams()                   # wgrad kernels run on a side stream
+        self.arena.clear_undelivered()            # a parameter without a gradient this step must not keep last step's (before the exchange)
         if runtime.sync_group is not None:
             runtime.grad_ready = None
             self._bucketer.finish()               # gradient SUM all-reduce, overlapped with the backward above
@@ -233,9 +234,20 @@ class Model:
     def save(self, save_dir):
         """Model.save (model.py:389-392 -> checkpoint.py:51-67): checkpoint.pth always, <id>.pth on a new best validation Dice."""
         import os
-        from . import checkpoint
-        d = os.path.join(save_dir, self.model_id())
-        os.makedirs(d, exist_ok=True)
-        checkpoint.save(self, os.path.join(d, 'checkpoint.pth'))
-        if self.loss.is_best:
-            checkpoint.save(self, os.path.join(d, self.model_id() + '.pth'), best=True)
+        from . import checkpoint, parallel
+        # data parallel: replicas are identical, rank 0 writes (the reference is single-process); every file is written to a
+        # temporary name and renamed into place, so a reader or a crash never sees a torn zip; the barrier keeps the other
+        # ranks from racing ahead into a resume / read of the file
+        rank0 = runtime.sync_group is None or parallel.rank() == 0
+        if rank0:
+            d = os.path.join(save_dir, self.model_id())
+            os.makedirs(d, exist_ok=True)
+            targets = [(os.path.join(d, 'checkpoint.pth'), False)]
+            if self.loss.is_best:
+                targets.append((os.path.join(d, self.model_id() + '.pth'), True))
+            for path, best in targets:
+                tmp = path + '.tmp.%d' % os.getpid()
+                checkpoint.save(self, tmp, best=best)
+                os.replace(tmp, path)
+        if runtime.sync_group is not None:
+            parallel.barrier()

@@ -248,6 +248,11 @@ def _deliver_grad(param, g):
     if _grad_target(param) is not None:
         if param.grad is None or param.grad.data_ptr() != g.data_ptr():
             param.grad = g
+        arena = getattr(param, '_pylc_arena', None)
+        if arena is not None:
+            a = arena()
+            if a is not None:
+                a.mark_delivered(param)
         if _runtime.grad_ready is not None:
             _runtime.grad_ready(param)        # data-parallel: may trigger this bucket's asynchronous all-reduce
         return None

@@ -43,6 +43,7 @@ class FlatArena:
             p.data = dst
             p._pylc_grad = torch.as_strided(self.g, p.shape, p.stride(), o)
             p.grad = p._pylc_grad
+            p._pylc_arena = weakref.ref(self)
         # per-parameter max magnitude (float bits), the filter range of the f16x3 conv arithmetic: one launch refreshes all
         self.amax = torch.zeros(len(params), dtype=torch.int32, device=dev)
         self._segments = torch.tensor(offs + [total], dtype=torch.int64, device=dev)
@@ -71,6 +72,8 @@ class FlatArena:
                 k, c, r, s_ = p.shape
                 p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
                                   self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
+        self._index = {id(p): i for i, p in enumerate(params)}
+        self._delivered = set()          # parameters whose gradient a backward kernel wrote since the last zero_grad()
         me = weakref.ref(self)           # no module -> arena strong reference: a dropped model frees its memory by refcount
         module.register_load_state_dict_post_hook(lambda *_: me() is not None and me().refresh_ranges())
         self.refresh_ranges()
@@ -88,6 +91,29 @@ class FlatArena:
     def zero_grad(self):
         self.g.zero_()
 
+    def mark_delivered(self, p):
+        self._delivered.add(id(p))
+
+    def begin_step(self):
+        """Forget which gradients were delivered (called by the optimiser's zero_grad(), i.e. before each backward)."""
+        self._delivered.clear()
+
+    def clear_undelivered(self):
+        """Backward kernels OVERWRITE arena gradients, so a parameter that received no gradient this step (an unused branch, an
+        early-returning backward) would otherwise be stepped with last step's values.  Zero those slices (torch.optim would
+        skip such a parameter entirely; with a zero gradient it still sees weight decay and moment decay -- reported once)."""
+        if not self._delivered or len(self._delivered) == len(self.params):
+            return 0          # all delivered, or delivery not tracked (gradients written by something else than pylc_amd.ops)
+        missing = [i for i, p in enumerate(self.params) if id(p) not in self._delivered]
+        for i in missing:
+            p, o = self.params[i], self.offsets[i]
+            self.g[o:o + p.numel()].zero_()
+        if not getattr(self, '_warned_undelivered', False):
+            import warnings
+            warnings.warn('%d parameter tensor(s) received no gradient this step; their arena gradients were zeroed' % len(missing))
+            self._warned_undelivered = True
+        return len(missing)
+
 
 class _FlatOptimizer:
     def __init__(self, arena, lr, clip):
@@ -101,10 +127,13 @@ class _FlatOptimizer:
         self.param_groups = [{'lr': self.lr}]             # models/model.py:394-397 get_lr() reads this
 
     def zero_grad(self, set_to_none=False):
-        """Gradients are overwritten by the backward kernels every step; nothing to clear."""
+        """Gradients are overwritten by the backward kernels every step; nothing to clear -- only the record of which
+        parameters have been delivered (step() zeroes the slices of those that were not, see FlatArena.clear_undelivered)."""
+        self.arena.begin_step()
 
     def _clip(self):
         a = self.arena
+        a.clear_undelivered()
         if self.clip is None:
             return None
         check(lib.pylc_grad_norm_clip(ptr(a.g), a.numel, float(self.clip), ptr(self.norm), ptr(self._ws), stream()))

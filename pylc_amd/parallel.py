@@ -145,6 +145,10 @@ def broadcast_parameters(arena, group=None, src=0):
     arena.refresh_ranges()          # parameter ranges and prepared conv filters follow the new values
 
 
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
