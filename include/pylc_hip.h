@@ -65,6 +65,12 @@ typedef struct PylcConvDesc {
      * with the scale that w_amax implies.  NULL = the kernels split the fp32 filter themselves. */
     const void* w_planes;
     const void* w_planes_t;
+    /* Operand formats (0 = fp32, the default).  1 = "planes": the tensor was written by its producer (pylc_bn_apply /
+     * pylc_bn_bwd_apply with planes output, pylc_to_planes) already scaled and split into two fp16 planes -- see "fp16 planes"
+     * below; the `x` (fwd, wgrad) / `dy` (dgrad, wgrad) argument then points at plane 0 and the matching *_amax must be the
+     * bound the producer scaled with.  Needs precision mode >= 2, Cin resp. Cout % 8 == 0 and pitches % 8 == 0. */
+    int x_fmt;
+    int dy_fmt;
 } PylcConvDesc;
 
 /* Arithmetic of the dense conv kernels (process-wide):
@@ -101,6 +107,17 @@ typedef struct PylcWPrepEntry {
 int pylc_weight_prepare(const float* base, const PylcWPrepEntry* table, int count, long long total_tiles,
                         const unsigned int* amax, void* planes, void* stream);
 int pylc_amax_segments(const float* base, const long long* offsets, int count, unsigned int* out_bits, void* stream);
+
+/* fp16 planes (operand format 1 of PylcConvDesc): M pixels x C channels (C % 8 == 0, pitch P % 8 == 0 halves) stored as two
+ * fp16 planes of M x P halves, `plane_stride` halves apart: plane 0 = rn16(s x), plane 1 = rn16(2^11 (s x - plane 0)), with
+ * s the power of two that maps the bound behind `amax` into [2^14, 2^15) -- the two pieces the f16x3 arithmetic forms from an
+ * fp32 operand, written ONCE by the tensor's producer (4 bytes per element, like fp32) so that the conv kernels copy operand
+ * tiles to LDS by LDS-DMA with no arithmetic.  nplanes = 1 writes / reads plane 0 only (precision mode 3).
+ * Replaces nothing in the reference: it is the HBM layout of the activations between the BatchNorm and conv kernels. */
+int pylc_to_planes(const float* x, int x_pitch, void* planes, int p_pitch, long long plane_stride, long long M, int C,
+                   const unsigned int* amax, int nplanes, void* stream);
+int pylc_from_planes(const void* planes, int p_pitch, long long plane_stride, float* x, int x_pitch, long long M, int C,
+                     const unsigned int* amax, int nplanes, void* stream);
 
 /* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */

@@ -16,111 +16,9 @@
 // Reference call sites replaced: nn.Conv2d in models/backbone/resnet.py:21-26,72,92,
 // models/modules/aspp.py:18,64,67, models/decoder.py:27-38, models/architectures/unet.py:78,112,116,137,
 // models/backbone/xception.py:32,48,122,126 and their autograd backward.
-#include "common.h"
-#include <type_traits>
+#include "conv_common.h"
 
 namespace pylc {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int LDB = 80;   // bf16x6 mode: bytes per LDS row per plane (32 bf16 = 64 B + 16 B pad)
-
-// Exact 3-way split of four fp32 values into bf16 planes by truncation: x = x0 + x1 + x2, each piece the top 16 bits of
-// the running remainder (8 significant bits), packed two per dword in k order.
-__device__ __forceinline__ void split3(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
-    unsigned u0[4], u1[4], u2[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        u0[e] = __float_as_uint(x[e]);
-        const float r1 = x[e] - __uint_as_float(u0[e] & 0xFFFF0000u);
-        u1[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(u1[e] & 0xFFFF0000u);
-        u2[e] = __float_as_uint(r2);
-    }
-    p0.x = (u0[0] >> 16) | (u0[1] & 0xFFFF0000u); p0.y = (u0[2] >> 16) | (u0[3] & 0xFFFF0000u);
-    p1.x = (u1[0] >> 16) | (u1[1] & 0xFFFF0000u); p1.y = (u1[2] >> 16) | (u1[3] & 0xFFFF0000u);
-    p2.x = (u2[0] >> 16) | (u2[1] & 0xFFFF0000u); p2.y = (u2[2] >> 16) | (u2[3] & 0xFFFF0000u);
-}
-__device__ __forceinline__ void split3(const float __attribute__((ext_vector_type(4))) v, uint2& p0, uint2& p1, uint2& p2) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    split3(x, p0, p1, p2);
-}
-
-// 2-way fp16 split of four scaled fp32 values: h0 = rn16(s*x), h1 = rn16(2048 (s*x - h0)); s*x = h0 + h1/2048 up to
-// 2^-23 |s*x|.  s is a power of two chosen from the tensor's max magnitude, so s*x is exact.
-// Scalar f32 ops on purpose: packed f32 VALU (v_pk_mul_f32 / v_pk_add_f32) issues at a third of the rate beside MFMAs
-// (MI355X_MICROARCH.md, constants table); the residual is one mixed-precision FMA per element (v_fma_mix_f32).  Measured
-// alternatives: v_fma_mixlo/hi_f16 (multiply + convert in one, 3 instead of 4 instructions per element) is slower.
-__device__ __forceinline__ void split2(const f32x4 v, float s, uint2& p0, uint2& p1) {
-    const float s2 = s * 2048.f;
-    const f32x2 lo = {v.x * s, v.y * s}, hi = {v.z * s, v.w * s};
-    const f16x2 l0 = __builtin_convertvector(lo, f16x2), h0 = __builtin_convertvector(hi, f16x2);
-    const f32x2 rl = {__builtin_fmaf((float)l0.x, -2048.f, v.x * s2), __builtin_fmaf((float)l0.y, -2048.f, v.y * s2)};
-    const f32x2 rh = {__builtin_fmaf((float)h0.x, -2048.f, v.z * s2), __builtin_fmaf((float)h0.y, -2048.f, v.w * s2)};
-    const f16x2 l1 = __builtin_convertvector(rl, f16x2), h1 = __builtin_convertvector(rh, f16x2);
-    p0.x = __builtin_bit_cast(unsigned, l0); p0.y = __builtin_bit_cast(unsigned, h0);
-    p1.x = __builtin_bit_cast(unsigned, l1); p1.y = __builtin_bit_cast(unsigned, h1);
-}
-
-// power-of-two scale that maps a tensor with max magnitude `amax` (given as float bits) into [2^14, 2^15): exact to apply
-// and to undo, keeps the fp16 pieces clear of overflow with the low piece inside the (sub)normal range for 40 binades.
-__device__ __forceinline__ float pow2_scale_for(unsigned amax_bits) {
-    int e = (int)((amax_bits >> 23) & 0xFFu);                  // biased exponent of amax (0: zero / denormal)
-    int se = 127 + 14 - (e - 127);
-    se = se < 1 ? 1 : (se > 254 ? 254 : se);
-    return __uint_as_float((unsigned)se << 23);
-}
-
-constexpr int BK = 32;    // reduction depth per LDS stage
-constexpr int LDT = 36;   // padded LDS row (floats): 144 B rows -> conflict-free ds_read_b128 of k-slices
-
-// Bijective XCD-aware remap: blocks b and b+8 share an XCD (observed round-robin dispatch), so give every
-// XCD a contiguous range of logical tiles -> neighbouring tiles (which share halos / weight panels) share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-struct GatherGemmArgs {
-    const float* x;
-    const float* w;
-    const float* bias;
-    float* y;
-    int M, P, Q;            // M = B*P*Q logical output pixels
-    int IH, IW, Cin, x_pitch;
-    int in_sh, in_sw;       // input coordinate of pixel (p,q), tap (r,s): (p*in_sh + dh0 + r*dh_step, ...)
-    int TR, TS;
-    int dh0, dh_step, dw0, dw_step;
-    int w_off0, w_step_r, w_step_s, w_row_stride;
-    int N, N_store;         // valid output channels / channels written (N rounded up to 4 inside the pitch)
-    int OH, OW, out_sh, out_sw, oh0, ow0, y_pitch;
-    int accumulate;
-    // fused inference epilogue (pylc_conv2d_fwd_bnact): val = relu(val * ep_scale[n] + ep_shift[n] + ep_res[...]); ep_amax
-    // (zero-initialised by the caller) is max-accumulated with the range of what is stored
-    const float* ep_scale;
-    const float* ep_shift;
-    const float* ep_res;    // same geometry and pitch as y
-    unsigned* ep_amax;
-    int ep_relu;
-    int tiles_n;
-    int n_tiles;            // tiles_m * tiles_n (the persistent ping-pong kernel walks them)
-    const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)
-    const unsigned* amax_w;
-    long long x_bytes, w_bytes;   // extents of the x / w buffers (raw buffer loads of the ping-pong kernel)
-    const void* w_planes;         // optional: the filter already split into two fp16 planes (pylc_weight_prepare), same
-                                  // indexing as w, plane 1 at + w_plane_stride halves; scaled with the amax behind amax_w
-    long long w_plane_stride;
-    int dbg_flags;           // tools/pp_stamps.py: 16 = finer stamps inside the store segment (STAMPS build only)
-    unsigned long long* dbg; // debug builds of the ping-pong kernel: per-segment clock stamps of block 0 (else null)
-    float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)
-};
 
 // PREC 0: v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chain, 157 TFLOP/s peak).
 // PREC 1: "bf16x6" -- every fp32 operand is split EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 mantissa bits
@@ -524,19 +422,6 @@ __device__ __forceinline__ void split2x8(const f32x4 lo, const f32x4 hi, float s
     split2(hi, s, b0, b1);
     p0 = make_uint4(a0.x, a0.y, b0.x, b0.y);
     p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
-}
-
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-// Sum over the 16 lanes of a DPP row (same fixed order in every lane): quad butterflies, then the two mirrors.
-__device__ __forceinline__ float row_sum16(float v) {
-#define PYLC_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-    PYLC_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
-    PYLC_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
-    PYLC_DPP_ADD(0x141);     // row_half_mirror: lane i <-> 7 - i of each half row
-    PYLC_DPP_ADD(0x140);     // row_mirror: lane i <-> 15 - i
-#undef PYLC_DPP_ADD
-    return v;
 }
 
 // M16 (with SWZ): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- same FLOPs per
@@ -1717,7 +1602,13 @@ static int dispatch_gg_p(GatherGemmArgs& a, bool cin4, hipStream_t st) {
 }
 
 static int dispatch_gg(GatherGemmArgs& a, bool cin4, hipStream_t st) {
-    return g_conv_precision == 0 ? dispatch_gg_p<0>(a, cin4, st) : g_conv_precision == 2 ? dispatch_gg_p<2>(a, cin4, st) : dispatch_gg_p<1>(a, cin4, st);
+    if (a.x_planes != nullptr) {       // A operand pre-split by its producer: conv_pl.hip (no fp32 view of x exists)
+        PYLC_REQUIRE(g_conv_precision >= 2 && !cin4, "conv: fp16-plane operands need precision mode 2 or 3 and a dense (not thin-input) geometry");
+        a.nterms = g_conv_precision == 3 ? 1 : 3;
+        return launch_gg_pl(a, st);
+    }
+    // mode 3 (plain fp16 operands) exists only for plane operands; fp32 operands (stem, ranges unknown to the producer) run f16x3
+    return g_conv_precision == 0 ? dispatch_gg_p<0>(a, cin4, st) : g_conv_precision >= 2 ? dispatch_gg_p<2>(a, cin4, st) : dispatch_gg_p<1>(a, cin4, st);
 }
 
 template <typename K>
@@ -1726,6 +1617,7 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 }
 
 int conv_init() {
+    if (int rc = conv_pl_init()) return rc;
 #define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 0>, gg_smem<BM, BN, 0>()));                  \
@@ -1796,7 +1688,7 @@ static inline int roundup4(int v) { return (v + 3) & ~3; }
 using namespace pylc;
 
 extern "C" int pylc_set_conv_precision(int mode) {
-    PYLC_REQUIRE(mode >= 0 && mode <= 2, "conv precision mode must be 0 (fp32 MFMA), 1 (bf16x6) or 2 (f16x3)");
+    PYLC_REQUIRE(mode >= 0 && mode <= 3, "conv precision mode must be 0 (fp32 MFMA), 1 (bf16x6), 2 (f16x3) or 3 (fp16 operands, fp32 accumulation)");
     g_conv_precision = mode;
     return PYLC_OK;
 }
@@ -1846,18 +1738,23 @@ extern "C" int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, cons
 static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
                            void* stream, const FwdEpilogue* ep) {
     if (int rc = check_desc(d)) return rc;
-    PYLC_REQUIRE(x && w && y, "null pointer");
+    PYLC_REQUIRE(x && y && (w || (d->x_fmt == 1 && d->w_planes)), "null pointer");
     GatherGemmArgs a{};
     if (ep != nullptr) { a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_res = ep->res; a.ep_amax = ep->amax; a.ep_relu = ep->relu; }
     a.stats = stats;
     a.dbg = g_pp_stamps;
     a.dbg_flags = g_pp_flags;
-    PYLC_REQUIRE(g_conv_precision != 2 || (d->x_amax && d->w_amax), "f16x3 mode: conv2d_fwd needs x_amax and w_amax in the descriptor");
+    PYLC_REQUIRE(g_conv_precision < 2 || (d->x_amax && d->w_amax), "f16x3 / fp16 mode: conv2d_fwd needs x_amax and w_amax in the descriptor");
     a.amax_x = d->x_amax; a.amax_w = d->w_amax;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
     a.w_bytes = (long long)d->Cout * d->R * d->S * d->Cin * 4;
     a.w_planes = d->w_planes; a.w_plane_stride = (long long)d->Cout * d->R * d->S * d->Cin;
+    if (d->x_fmt == 1) {                     // x points at plane 0 of an fp16-plane tensor
+        a.x_planes = x; a.x = nullptr;
+        a.x_plane_stride = (long long)d->B * d->H * d->W * d->x_pitch;
+        a.x_bytes /= 2;                      // bytes of ONE plane
+    }
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
     a.IH = d->H; a.IW = d->W; a.Cin = d->Cin; a.x_pitch = d->x_pitch;
     a.in_sh = a.in_sw = d->stride;
@@ -1869,7 +1766,7 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     a.accumulate = 0;
     const bool cin4 = d->Cin == 4 && d->R * d->S > 1;
     if (int rc = dispatch_gg(a, cin4, as_stream(stream))) return rc;
-    if (stats_rows) *stats_rows = cdiv(a.M, a.tiles_n > 0 ? g_last_bm : 128);
+    if (stats_rows) *stats_rows = cdiv(a.M, a.x_planes != nullptr ? a.tile_bm : (a.tiles_n > 0 ? g_last_bm : 128));
     return PYLC_OK;
 }
 
@@ -1877,7 +1774,9 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
 // d->w_planes_t are all it touches (f16x3 mode, stride 1, a geometry that dispatches to the ping-pong kernel)
 extern "C" int pylc_conv2d_dgrad_needs_f32_weights(const PylcConvDesc* d) {
     if (check_desc(d)) return 1;
-    if (g_conv_precision != 2 || d->stride != 1 || d->w_planes_t == nullptr) return 1;
+    if (g_conv_precision < 2 || d->w_planes_t == nullptr) return 1;
+    if (d->dy_fmt == 1) return 0;            // plane operands: conv_pl.hip reads prepared planes only (any stride)
+    if (d->stride != 1) return 1;
     const int Kp = roundup4(d->Cout);
     GatherGemmArgs a{};
     a.Cin = Kp;
@@ -1898,12 +1797,17 @@ extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const f
     PYLC_REQUIRE(Kp <= d->y_pitch, "dy pitch %d must cover roundup4(Cout)=%d", d->y_pitch, Kp);
     GatherGemmArgs a{};
     a.dbg_flags = g_pp_flags;
-    PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->w_amax), "f16x3 mode: conv2d_dgrad needs dy_amax and w_amax in the descriptor");
+    PYLC_REQUIRE(g_conv_precision < 2 || (d->dy_amax && d->w_amax), "f16x3 / fp16 mode: conv2d_dgrad needs dy_amax and w_amax in the descriptor");
     a.amax_x = d->dy_amax; a.amax_w = d->w_amax;
     a.x = dy; a.w = w_crsk; a.bias = nullptr; a.y = dx;
     a.x_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + Kp) * 4;
     a.w_bytes = (long long)d->Cin * d->R * d->S * Kp * 4;
     a.w_planes = d->w_planes_t; a.w_plane_stride = (long long)d->Cin * d->R * d->S * Kp;
+    if (d->dy_fmt == 1) {
+        a.x_planes = dy; a.x = nullptr;
+        a.x_plane_stride = (long long)d->B * d->OH * d->OW * d->y_pitch;
+        a.x_bytes /= 2;
+    }
     a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
     a.N = d->Cin; a.N_store = d->Cin;
     a.OH = d->H; a.OW = d->W; a.y_pitch = d->x_pitch;
@@ -2014,7 +1918,7 @@ static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
         return PYLC_OK;                                                                                                                \
     }
     if (g_conv_precision == 1) PYLC_LAUNCH_WG(1)
-    if (g_conv_precision == 2) PYLC_LAUNCH_WG(2)
+    if (g_conv_precision >= 2) PYLC_LAUNCH_WG(2)
 #undef PYLC_LAUNCH_WG
     const size_t lds = wg_smem<BN, BC>();
     hipLaunchKernelGGL((wgrad_kernel<BN, BC, WN, WC, CIN4>), dim3((unsigned)grid), dim3(256), lds, st, a);
@@ -2044,7 +1948,7 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     a.out_row_stride = T * d->Cin;
     a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c; a.splits = p.splits; a.m_per_split = p.m_per_split;
     a.slab_stride = p.slab;
-    PYLC_REQUIRE(g_conv_precision != 2 || (d->dy_amax && d->x_amax), "f16x3 mode: conv2d_wgrad needs dy_amax and x_amax in the descriptor");
+    PYLC_REQUIRE(g_conv_precision < 2 || (d->dy_amax && d->x_amax), "f16x3 / fp16 mode: conv2d_wgrad needs dy_amax and x_amax in the descriptor");
     a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
     a.dy_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + a.N_ld) * 4;
     a.amax_dy = d->dy_amax; a.amax_x = d->x_amax;

@@ -1,0 +1,498 @@
+// Implicit-GEMM convolution (forward and dgrad "gather GEMM") whose operands arrive PRE-SPLIT as fp16 planes.
+//
+// conv_igemm.hip's f16x3 kernels read fp32 activations and split every element into two scaled fp16 pieces inside the main
+// loop (64 vector instructions per wave and K-step next to 48 MFMAs: the matrix pipe was busy half the time).  Here the
+// producer of a tensor (BatchNorm-apply, BatchNorm-backward, pylc_to_planes) has already written
+//      plane 0: h0 = rn16(s x)            plane 1: h1 = rn16(2^11 (s x - h0))           s = 2^k from the tensor's range bound
+// (4 bytes per element, as fp32) and the filter planes come from pylc_weight_prepare, so BOTH operand tiles are plain copies:
+// they go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), no staging registers, no ds_write, no vector ALU work.
+// The wave's main loop is: 8 DMA issues, 16 ds_read_b128 fragment reads, 48 MFMAs (NTERMS = 3) or 16 (NTERMS = 1).
+//
+// Two tile shapes, one body (BM = 128 / 256 pixel rows x 128 channels x 32 deep; every wave owns 64 x 64 outputs on 4 x 4
+// v_mfma_f32_16x16x32_f16 tiles):
+//   * 128 x 128, 4 waves, two LDS stages of 32 KB, TWO blocks per CU.  The blocks are independent, so one block's prologue
+//     (geometry, first operand round trip) and epilogue (stores) overlap the other's main loop -- what a one-block-per-CU kernel
+//     cannot hide on the short-K 1x1 convs.  DMA runs one K-step ahead.
+//   * 256 x 128, 8 waves, three LDS stages of 48 KB, one block per CU.  DMA runs TWO K-steps ahead behind a counted vmcnt and one
+//     raw s_barrier per step.  25 % fewer operand bytes per MFMA: what counts on the long reductions, because the L2 -> LDS path
+//     (~70 GB/s per CU in practice, MI355X_MICROARCH.md "Indexed rows: gather into LDS") is what bounds the 128 x 128 tile
+//     (32 KB per 192 MFMAs = 80-100 GB/s per CU at the full matrix rate).
+//
+// What bounds it (tools/pl_ablate.py, pl_stamps.py on 3x3 256->256 @128^2, bs 32): the MFMA phase alone runs at 520 TFLOP/s
+// (algorithmic; the chip holds ~1.5-1.9 GHz under it), the operand DMA alone takes as long (19-20 TB/s L2 -> LDS chip-wide is
+// all the CUs take: 32 KB per block and K-step), and the two overlap only partly -- a wave whose DMA issue blocks on the full
+// queue issues no MFMAs.  Measured and dropped: handing a stage back in the middle of a step (second barrier, DMA 1.7 steps
+// ahead with two stages); spreading the DMA pieces over the MFMA phase (one or two per 12 MFMAs).  Both neutral: the limit is
+// bytes per MFMA, not latency or burstiness.
+//
+// LDS image: unpadded 64-byte rows (32 halves), 16-byte chunk index XORed with ((row >> 2) & 1) << 1: conflict-free for the
+// 16-row ds_read_b128 fragments.  LDS-DMA writes lane-linearly (wave base + lane * 16), so the swizzle is applied on the SOURCE
+// address (each lane fetches the chunk that belongs at its position) and again on the read.
+//
+// NTERMS = 3: a0 b0 + 2^-11 (a1 b0 + a0 b1), identical instruction order to conv_igemm.hip's kernels -> bit-identical results.
+// NTERMS = 1: plain fp16 operands (plane 0 only), fp32 accumulation: precision mode 3 (BASELINE configs[4] "bf16 MFMA" class).
+//
+// Reference call sites replaced: as conv_igemm.hip (nn.Conv2d forward/backward in models/backbone/resnet.py:21-26,72,92,
+// models/modules/aspp.py:18,64,67, models/decoder.py:27-38, models/backbone/xception.py:32,48,122,126).
+#include "conv_common.h"
+
+namespace pylc {
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+constexpr int PL_BN = 128;
+constexpr int PL_ROW = 64;                                  // bytes per LDS row per plane
+template <int NTERMS, int BM>
+constexpr int pl_stage_bytes() { return (NTERMS == 3 ? 2 : 1) * (BM + PL_BN) * PL_ROW; }
+template <int BM>
+constexpr int pl_stages() { return BM == 256 ? 3 : 2; }
+template <int NTERMS, int BM>
+constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, BM>() + BM * 4 + 64; }
+
+// STAMPS (tools/pl_stamps.py): lane 0 of the first and the last wave of block `dbg_flags >> 16` records s_memtime at the phase
+// boundaries of every K-step into LDS (dumped to a.dbg at the end); production launches use STAMPS = false.
+template <int NTERMS, int BM, bool STAMPS = false>
+__global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a) {
+    constexpr int BN = PL_BN, WM = 64, WN = 64, AT = 4, ROW = PL_ROW;
+    constexpr int NW = BM / 32;                             // waves: 4 (2 M x 2 N) or 8 (4 M x 2 N)
+    constexpr int NST = pl_stages<BM>();
+    constexpr int BI = BN / (16 * NW);                      // filter rows per thread (16-row DMA pieces per wave): 2 or 1
+    constexpr int NPL = NTERMS == 3 ? 2 : 1;
+    constexpr int NDMA = (2 + BI) * NPL;                    // DMA instructions per wave and K-step
+    constexpr int STAGE = pl_stage_bytes<NTERMS, BM>();
+    constexpr int OFF_B = NPL * BM * ROW;
+    constexpr unsigned OOB = 0x80000000u;                   // >= num_records of every descriptor (takes_pl: buffers below 2 GiB)
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // ONE LDS object (a second one makes hipcc drain the DMA early)
+    char* lds = reinterpret_cast<char*>(smem);
+    int* rowoff = reinterpret_cast<int*>(lds + NST * STAGE);                                     // [BM] output element offsets, -1: no row
+    unsigned long long* s_wave_taps = reinterpret_cast<unsigned long long*>(lds + NST * STAGE + BM * 4);    // [NW]
+    unsigned long long* stamp_base = reinterpret_cast<unsigned long long*>(lds + NST * STAGE + BM * 4 + 64);  // STAMPS: [2][256]
+    int n_stamp = 0;
+#define PL_STAMP()                                                                                                    \
+    if constexpr (STAMPS) {                                                                                           \
+        if (stamper && n_stamp < 250) stamp_base[(wave != 0) * 256 + n_stamp++] = __builtin_amdgcn_s_memtime();       \
+    }
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA destinations live in M0
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int lrow = lane >> 2;                                         // loader: 4 lanes per 64-byte row, 16 rows per DMA instruction
+    const int lc = (lane & 3) ^ (((lane >> 4) & 1) << 1);               // logical chunk this lane fetches for its LDS position
+    const bool ident = a.ident != 0;
+    const bool stamper = STAMPS && (int)blockIdx.x == (a.dbg_flags >> 16) && lane == 0 && (wave == 0 || wave == NW - 1);
+    PL_STAMP();
+
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+
+    // ---- filter rows of this thread: no geometry needed, so their first DMA goes out before anything else ----
+    unsigned woff_row[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int n = n0 + 16 * BI * wave + 16 * i + lrow;
+        woff_row[i] = n < a.N ? ((unsigned)n * (unsigned)a.w_row_stride + 8u * lc) * 2u : OOB;
+    }
+    const unsigned plane1_w = (unsigned)(a.w_plane_stride * 2);
+
+    // ---- pixel rows of this thread ----
+    int rowh[2], roww[2];
+    unsigned xoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 32 * wave + 16 * i + lrow;
+        const bool ok = m < a.M;
+        if (ident) {                       // 1x1, stride 1, no padding: input pixel == output pixel, no decode
+            rowh[i] = ok ? 0 : -(1 << 28);
+            roww[i] = 0;
+            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch + 8u * lc) * 2u;
+        } else {
+            const int mm = ok ? m : 0;
+            const int q = mm % a.Q, t = mm / a.Q;
+            const int p = t % a.P, b = t / a.P;
+            rowh[i] = ok ? p * a.in_sh : -(1 << 28);          // invalid rows fail every bounds check
+            roww[i] = q * a.in_sw;
+            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * lc) * 2u;      // garbage for invalid rows (masked)
+        }
+    }
+    // output row table (read by the epilogue; the first barrier of the main loop orders it)
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < a.M) {
+            if (ident) {
+                off = (long long)m * a.y_pitch;
+            } else {
+                const int q = m % a.Q, t = m / a.Q;
+                const int p = t % a.P, b = t / a.P;
+                off = ((long long)(b * a.OH + p * a.out_sh + a.oh0) * a.OW + q * a.out_sw + a.ow0) * a.y_pitch;
+            }
+        }
+        rowoff[tid] = (int)off;
+    }
+
+    const int T = a.TR * a.TS;
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    // taps that reach at least one valid input pixel of this tile (the others are skipped): one ballot per tap, one barrier
+    unsigned long long tapmask = ~0ull;
+    if (T > 1) {
+        unsigned long long mine = 0;
+        for (int t = 0; t < T; ++t) {
+            const int dh = a.dh0 + (t / a.TS) * a.dh_step, dw = a.dw0 + (t % a.TS) * a.dw_step;
+            int any = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                any |= ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);
+            if (__builtin_amdgcn_ballot_w64(any != 0) != 0) mine |= 1ull << t;
+        }
+        if (lane == 0) s_wave_taps[wave] = mine;
+        __syncthreads();
+        unsigned long long all = 0;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) all |= s_wave_taps[wv];
+        tapmask = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(all >> 32)) << 32) |
+                  (unsigned)__builtin_amdgcn_readfirstlane((int)all);
+    }
+    const int ntaps = __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
+    const int S = ntaps * nchunks;
+
+    typedef float f32x4v_ __attribute__((ext_vector_type(4)));
+    f32x4v_ acc[AT][AT];
+    f32x4v_ acc_lo[NTERMS == 3 ? AT : 1][NTERMS == 3 ? AT : 1];
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+            }
+
+    // reduction cursor (as conv_igemm.hip: taps innermost unless the taps are widely dilated -- dbg_flags bit 12)
+    const bool tap_inner = !(a.dbg_flags & 4096);
+    int ld_tap = -1, ld_tr = 0, ld_ts = -1, ld_chunk = tap_inner ? 0 : nchunks - 1;
+    auto advance = [&]() {
+        if (tap_inner) {
+            do {
+                ++ld_tap;
+                if (++ld_ts == a.TS) { ld_ts = 0; ++ld_tr; }
+                if (ld_tap == T) { ld_tap = 0; ld_tr = 0; ld_ts = 0; ++ld_chunk; }
+            } while (!((tapmask >> ld_tap) & 1ull));
+        } else if (++ld_chunk == nchunks) {
+            ld_chunk = 0;
+            do {
+                ++ld_tap;
+                if (++ld_ts == a.TS) { ld_ts = 0; ++ld_tr; }
+            } while (!((tapmask >> ld_tap) & 1ull));
+        }
+    };
+    // LDS-DMA of the next reduction tile into `stage`: per thread 2 pixel rows + 2 filter rows, NPL planes each.
+    // Masked lanes (padding tap, row past M, channels past Cin, filter row past N) get an out-of-range offset: the hardware
+    // writes zeros for them.
+    char* const dstA = lds + (32 * wave) * ROW;              // + stage * STAGE + plane * BM * ROW + 16 i * ROW
+    char* const dstB = lds + OFF_B + (16 * BI * wave) * ROW;
+    auto issue = [&](int stage) {
+        advance();
+        const int dh = a.dh0 + ld_tr * a.dh_step, dw = a.dw0 + ld_ts * a.dw_step;
+        const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
+        const bool cok = ld_chunk * BK + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * BK) * 2);      // wave-uniform, may be "negative"
+        const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2);
+        char* const sa = dstA + stage * STAGE;
+        char* const sb = dstB + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = cok & ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);      // no short-circuit: branch-free
+            const unsigned vo = ok ? xoff[i] + tapdelta : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)(sa + 16 * i * ROW), 16, vo, 0, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(sa + BM * ROW + 16 * i * ROW), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const unsigned vo = cok ? woff_row[i] : OOB;
+            const unsigned vo1 = cok ? woff_row[i] + plane1_w : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + 16 * i * ROW), 16, vo, so, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + BN * ROW + 16 * i * ROW), 16, vo1, so, 0, 0);
+        }
+    };
+    // fragment reads: lane l = row (l & 15) of a 16-row fragment, reduction elements 8 (l >> 4) .. +7 of the 32-deep step
+    const int koff = 16 * ((lane >> 4) ^ (((lane >> 2) & 1) << 1));
+    const char* const ra_base = lds + (wave_m * WM + (lane & 15)) * ROW + koff;
+    const char* const rb_base = lds + OFF_B + (wave_n * WN + (lane & 15)) * ROW + koff;
+    auto compute = [&](int stage) {
+        const char* pa = ra_base + stage * STAGE;
+        const char* pb = rb_base + stage * STAGE;
+        f16x8 fb[AT][NPL];
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
+            f16x8 fa[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+                // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels
+                // 4 (l >> 4) .. +3) -> 16-byte epilogue stores.  Same term order as conv_igemm.hip (bit-identical sums).
+                if constexpr (NTERMS == 3) {
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop, ONE barrier per K-step.  LDS-DMA data is ordered for a ds_read only by the ISSUING wave's vmcnt followed by a
+    // barrier the reader has passed; hipcc does not wait for a DMA before an LDS read, so the waits are written out.
+    if constexpr (NST == 2) {
+        // two stages: __syncthreads() = s_waitcnt vmcnt(0) (this wave's share of tile s has landed) + s_barrier (every wave's has, and
+        // every wave has finished reading the stage that tile s+1 is about to overwrite)
+        if (S > 0) {
+            PL_STAMP();
+            issue(0);
+            for (int s = 0; s < S; ++s) {
+                PL_STAMP();
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                PL_STAMP();
+                // STAMPS builds only -- timing ablations (results are garbage): debug flag 64 = no DMA in the loop, 128 = no MFMA phase
+                if (s + 1 < S && !(STAMPS && (a.dbg_flags & 64))) issue((s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                PL_STAMP();
+                if (!(STAMPS && (a.dbg_flags & 128))) compute(s & 1);
+                if constexpr (STAMPS) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // three stages: tiles s+1 and s+2 are in flight while tile s is computed.  At the top of step s this wave's DMA of tile s
+        // must have landed, that of tile s+1 (NDMA instructions, issued later, in order) may still be on its way: vmcnt(NDMA).
+        // Behind the barrier every wave has finished computing tile s-1, so its stage takes tile s+2.
+        if (S > 0) {
+            PL_STAMP();
+            issue(0);
+            if (S > 1) issue(1);
+            int sc = 0, sn = 2;                                  // stage of the tile being computed / of the tile being requested
+            for (int s = 0; s < S; ++s) {
+                PL_STAMP();
+                if (s + 1 < S) {
+                    if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                PL_STAMP();
+                if (s + 2 < S && !(STAMPS && (a.dbg_flags & 64))) issue(sn);
+                __builtin_amdgcn_sched_barrier(0);
+                PL_STAMP();
+                if (!(STAMPS && (a.dbg_flags & 128))) compute(sc);
+                __builtin_amdgcn_sched_barrier(0);
+                sc = sc == 2 ? 0 : sc + 1;
+                sn = sn == 2 ? 0 : sn + 1;
+            }
+        }
+    }
+    PL_STAMP();
+    __syncthreads();          // LDS stage 0 is reused for the statistics; orders the row table when S == 0
+
+    // ---- epilogue (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic, then stores) ----
+    float* sred = reinterpret_cast<float*>(smem);             // [BM / WM][BN][2]
+    const bool do_stats = a.stats != nullptr;
+    const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
+    const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (NTERMS == 3) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                else acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
+            }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* extra = a.accumulate ? a.y : nullptr;
+    int eoff[AT][AT];
+    float bv[AT][4];
+    {
+        int offs[AT];
+#pragma unroll
+        for (int i = 0; i < AT; ++i) offs[i] = rowoff[wave_m * WM + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < AT; ++j) {
+            const int n4 = n0 + wave_n * WN + j * 16 + 4 * (lane >> 4);
+            const bool nok = n4 < a.N_store;                    // N_store % 4 == 0: all four channels or none
+#pragma unroll
+            for (int i = 0; i < AT; ++i) eoff[i][j] = (nok && offs[i] >= 0) ? offs[i] + n4 : -1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[j][r] = (a.bias != nullptr && n4 + r < a.N) ? a.bias[n4 + r] : 0.f;
+        }
+    }
+    float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+    constexpr int PJ = 2;
+    auto finish = [&](auto has_prev, auto j0c, const f32x4v_ (&prev)[AT][PJ]) {
+        constexpr int j0 = decltype(j0c)::value;
+        constexpr int NJ = decltype(has_prev)::value ? PJ : AT;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = j0 + jj;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < AT; ++i) {
+                const bool stored = eoff[i][j] >= 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = acc[i][j][r] + bv[j][r];
+                    if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
+                    acc[i][j][r] = val;
+                    const float cv = stored ? val : 0.f;
+                    cs[r] += cv;
+                    css[r] += cv * cv;
+                }
+            }
+            if (do_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r]; sdst[(j * 16 + r) * 2 + 1] = css[r]; }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+                if (eoff[i][j0 + jj] >= 0) *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if (extra == nullptr) {
+        const f32x4v_ none[AT][PJ] = {};
+        finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
+    } else {
+        f32x4v_ prev[AT][PJ];
+        auto fetch = [&](int j0) {
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < PJ; ++jj) {
+                    const f32x4v_ zero = {0.f, 0.f, 0.f, 0.f};
+                    prev[i][jj] = eoff[i][j0 + jj] >= 0 ? *reinterpret_cast<const f32x4v_*>(extra + eoff[i][j0 + jj]) : zero;
+                }
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int n = n0 + tid;
+            if (n < a.N_store) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
+                float* dst = a.stats + (size_t)(tile / a.tiles_n) * 2 * a.N_store;
+                dst[n] = sm;
+                dst[a.N_store + n] = sq;
+            }
+        }
+    }
+    if constexpr (STAMPS) {
+        __builtin_amdgcn_sched_barrier(0);
+        PL_STAMP();
+        if (stamper && a.dbg != nullptr)
+            for (int k = 0; k < 256; ++k) a.dbg[(wave != 0) * 256 + k] = k < n_stamp ? stamp_base[(wave != 0) * 256 + k] : 0ull;
+    }
+#undef PL_STAMP
+}
+
+template __global__ void gg_pl_kernel<3, 128>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 256>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 128>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 256>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 128, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 256, true>(const GatherGemmArgs);
+
+
+// geometry / size conditions on top of: A operand given as planes, prepared filter planes present
+
+// geometry / size conditions on top of: A operand given as planes, prepared filter planes present
+bool takes_pl(const GatherGemmArgs& a) {
+    const bool aligned = a.y_pitch % 4 == 0 && a.N_store % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.x_planes) & 15) == 0 && (a.x_plane_stride % 8) == 0 && a.x_pitch % 8 == 0;
+    return a.x_planes != nullptr && a.w_planes != nullptr && aligned && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) &&
+           a.w_plane_stride * 4 < (1ll << 31) && a.ep_scale == nullptr;
+}
+
+template <int NTERMS, int BM>
+static void launch_pl(const GatherGemmArgs& a, unsigned grid, hipStream_t st) {
+    constexpr int lds_bytes = pl_lds_bytes<NTERMS, BM>();
+    if (NTERMS == 3 && (a.dbg != nullptr || (a.dbg_flags & (64 | 128)))) {      // stamped / ablation build (tools/pl_stamps.py, pl_ablate.py)
+        hipLaunchKernelGGL((gg_pl_kernel<3, BM, true>), dim3(grid), dim3(BM * 2), lds_bytes + 4096, st, a);
+        return;
+    }
+    hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+}
+
+int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
+    PYLC_REQUIRE(takes_pl(a), "conv (fp16-plane operands): needs prepared filter planes, Cin %% 8 == 0, pitches %% 8 == 0, 16-byte aligned "
+                              "buffers below 2 GiB per plane");
+    if (a.dh_step > 2 || a.dh_step < -2 || a.dw_step > 2 || a.dw_step < -2) a.dbg_flags |= 4096;      // as launch_gg_pp
+    a.ident = a.TR == 1 && a.TS == 1 && a.in_sh == 1 && a.in_sw == 1 && a.dh0 == 0 && a.dw0 == 0 && a.IH == a.P && a.IW == a.Q &&
+              a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 && a.ow0 == 0 && a.OH == a.P && a.OW == a.Q;
+    // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
+    // tile's prologue / epilogue) -- for long reductions on grids that still fill the chip.  128 rows: two blocks per CU.
+    const long long ksteps = (long long)a.TR * a.TS * cdiv(a.Cin, BK);
+    const long long tiles256 = (long long)cdiv(a.M, 256) * cdiv(a.N_store, PL_BN);
+    bool big = ksteps >= 24 && tiles256 >= kNumCU;
+    if (g_pp_flags & 2048) big = false;               // A/B knobs (pylc_debug_pp_flags)
+    if (g_pp_flags & 8192) big = true;
+    const int bm = big ? 256 : 128;
+    a.tile_bm = bm;
+    a.tiles_n = cdiv(a.N_store, PL_BN);
+    const long long n_tiles = (long long)cdiv(a.M, bm) * a.tiles_n;
+    PYLC_REQUIRE(n_tiles > 0 && n_tiles < (1ll << 31), "conv grid out of range");
+    a.n_tiles = (int)n_tiles;
+    if (a.nterms == 1) {
+        if (big) launch_pl<1, 256>(a, (unsigned)n_tiles, st); else launch_pl<1, 128>(a, (unsigned)n_tiles, st);
+    } else {
+        if (big) launch_pl<3, 256>(a, (unsigned)n_tiles, st); else launch_pl<3, 128>(a, (unsigned)n_tiles, st);
+    }
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+template <typename K>
+static hipError_t opt_in(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int conv_pl_init() {
+    PYLC_HIP(opt_in(gg_pl_kernel<3, 128>, pl_lds_bytes<3, 128>()));
+    PYLC_HIP(opt_in(gg_pl_kernel<3, 256>, pl_lds_bytes<3, 256>()));
+    PYLC_HIP(opt_in(gg_pl_kernel<1, 128>, pl_lds_bytes<1, 128>()));
+    PYLC_HIP(opt_in(gg_pl_kernel<1, 256>, pl_lds_bytes<1, 256>()));
+    PYLC_HIP(opt_in(gg_pl_kernel<3, 128, true>, pl_lds_bytes<3, 128>() + 4096));
+    PYLC_HIP(opt_in(gg_pl_kernel<3, 256, true>, pl_lds_bytes<3, 256>() + 4096));
+
+    return PYLC_OK;
+}
+
+}  // namespace pylc

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYLC_LIB: load another build of the library (same-box A/B of two builds: tools/ab_builds.sh)
 LIB_PATH = os.environ.get('PYLC_LIB') or os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PylcError(RuntimeError):
@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'Cin', 'Cout', 'R', 'S', 'stride', 'pad', 'dil',
                                        'OH', 'OW', 'x_pitch', 'y_pitch')] + \
                [(n, C.c_void_p) for n in ('x_amax', 'w_amax', 'dy_amax',      # operand ranges (precision mode 2)
-                                          'w_planes', 'w_planes_t')]           # prepared filter planes (optional)
+                                          'w_planes', 'w_planes_t')] + \
+               [(n, C.c_int) for n in ('x_fmt', 'dy_fmt')]                      # operand formats: 0 fp32, 1 fp16 planes
 
 
 class WPrepEntry(C.Structure):
@@ -54,6 +55,8 @@ SIGNATURES = {
     'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
+    'pylc_to_planes': (_I, [_P, _I, _P, _I, _LL, _LL, _I, _P, _I, _P]),
+    'pylc_from_planes': (_I, [_P, _I, _LL, _P, _I, _LL, _I, _P, _I, _P]),
     'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),
     'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),

@@ -49,8 +49,74 @@ def pitch_of(t):
     return p
 
 
+# ----------------------------------------------------------------------------------------------
+# fp16-plane tensors (include/pylc_hip.h "fp16 planes")
+# ----------------------------------------------------------------------------------------------
+# A planes tensor is carried through autograd as an ordinary float32 tensor of the logical [B, C, H, W] shape (NHWC memory, pitch ==
+# C) whose BYTES hold the two fp16 planes [2][B*H*W][C] -- the same 4 bytes per element, so no second allocation, and autograd sees
+# the dtype and shape it expects.  The marker attribute names the range bound the planes were scaled with.  Only kernels that know
+# the format may touch the bytes: every other op goes through as_nhwc(), which converts back to fp32 (one pass, counted).
+plane_conversions = [0, 0]      # [planes -> fp32 conversion passes, elements]: diagnostics (0 on the hot path)
+
+
+def is_planes(t):
+    tag = getattr(t, '_pylc_pl', None)
+    return tag is not None and tag[1] == t._version
+
+
+def planes_amax(t):
+    return t._pylc_pl[0]
+
+
+def nplanes():
+    """2 for the f16x3 arithmetic, 1 for plain fp16 operands (precision mode 3)."""
+    return 1 if lib.pylc_get_conv_precision() == 3 else 2
+
+
+def planes_ok(c, pixels):
+    """Can an activation of `c` channels x `pixels` pixels be kept as fp16 planes (16-byte rows per 8 channels, one plane below 2 GiB)?"""
+    return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)
+
+
+def mark_planes(t, amax):
+    t._pylc_pl = (amax, t._version)
+    tag_amax(t, amax)
+    return t
+
+
+def to_planes(x, amax=None):
+    """fp32 NHWC tensor -> planes tensor (one pass); `amax`: device int32[1] range bound (default: the tensor's own range)."""
+    L.init()
+    x = as_nhwc(x)
+    b, c, h, w = x.shape
+    if not planes_ok(c, b * h * w):
+        raise L.PylcError('to_planes: %d channels x %d pixels cannot be held as fp16 planes' % (c, b * h * w))
+    if amax is None:
+        amax = amax_of(x)
+    out = empty_nhwc(b, c, h, w, x.device)
+    m = b * h * w
+    check(lib.pylc_to_planes(ptr(x), pitch_of(x), ptr(out), c, m * c, m, c, ptr(amax), nplanes(), stream()))
+    return mark_planes(out, amax)
+
+
+def from_planes(t):
+    """planes tensor -> fp32 NHWC tensor (one pass)."""
+    L.init()
+    b, c, h, w = t.shape
+    m = b * h * w
+    out = empty_nhwc(b, c, h, w, t.device)
+    check(lib.pylc_from_planes(ptr(t), c, m * c, ptr(out), c, m, c, ptr(planes_amax(t)), nplanes(), stream()))
+    plane_conversions[0] += 1
+    plane_conversions[1] += t.numel()
+    tag_amax(out, planes_amax(t))
+    return out
+
+
 def as_nhwc(t):
-    """Return `t` with NHWC memory (copying through torch only if an upstream op handed us another layout)."""
+    """Return `t` as an fp32 tensor with NHWC memory (copying through torch only if an upstream op handed us another layout;
+    converting if it is an fp16-plane tensor)."""
+    if is_planes(t):
+        return from_planes(t)
     if t.dtype != torch.float32:
         t = t.float()
     try:
@@ -388,7 +454,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
         if ctx.res_link is not None:
             res_link.pending += 1
-        x = as_nhwc(x)
+        x_pl = is_planes(x) and getattr(w, '_pylc_planes', None) is not None and w.shape[1] % 8 == 0
+        if not x_pl:
+            x = as_nhwc(x)
         cout, cin_w, r, s = w.shape
         cin = x.shape[1]
         xp = pitch_of(x)
@@ -416,8 +484,12 @@ class Conv2dFn(torch.autograd.Function):
             yp = _r4(cout)
             y = empty_nhwc(b, cout, oh, ow, x.device, yp)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, xp, yp)
+        if x_pl:
+            d.x_fmt = 1
+            x_amax = planes_amax(x)          # the bound the producer scaled the planes with
         d.x_amax, d.w_amax = ptr(x_amax), ptr(w_amax)
         ctx.ranges = (x_amax, w_amax)
+        ctx.x_pl = x_pl
         planes = getattr(w, '_pylc_planes', None) if (w_amax is not None and w_k is w) else None
         if planes is not None:
             d.w_planes = ptr(planes[0])
@@ -453,6 +525,9 @@ class Conv2dFn(torch.autograd.Function):
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
+        if ctx.x_pl:
+            mark_planes(x, ctx.ranges[0])       # saved tensors come back as new Python objects: restore the marker
+            x = from_planes(x)                  # TEMPORARY until wgrad reads planes
         dy = as_nhwc(dy)
         cout, _, r, s = w.shape
         cin = x.shape[1]
