@@ -196,6 +196,9 @@ int pylc_bn_finalize_from_partial(const float* partial, int n_rows, double n, in
 /* Eval mode: scale/shift from running statistics. */
 int pylc_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma,
                         const float* beta, float eps, int C, float* scale, float* shift, void* stream);
+/* The same plus mean = running_mean and invstd = 1/sqrt(running_var + eps) (what an eval-mode backward reads). */
+int pylc_bn_eval_coeffs_full(const float* running_mean, const float* running_var, const float* gamma, const float* beta, float eps,
+                             int C, float* scale, float* shift, float* mean, float* invstd, void* stream);
 /* out = act(y*scale + shift (+ residual)); relu != 0 applies max(.,0).  y may alias out.  amax_out (may be NULL) is
  * max-accumulated with the bit pattern of max|out| -- the x_amax of the conv that consumes `out` (precision mode 2) at no
  * extra pass; the caller provides it ZERO-INITIALISED (or holding a lower bound). */
@@ -221,6 +224,47 @@ int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float* out, int o
                       const float* gamma, const float* sums, double n,
                       long long M, int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch,
                       unsigned int* amax_dy, const float* scale, const float* shift, void* stream);
+/* Optional extras of the BatchNorm kernels (the *_ex entry points; NULL = plain fp32 behaviour):
+ *   - fp16-plane operands (see "fp16 planes"): when a *_planes pointer is set, the matching fp32 pointer argument must be NULL and the
+ *     pitch argument counts halves; the scale comes from the device scalar next to it (a range BOUND written by pylc_bn_finalize*_ex /
+ *     pylc_bn_bwd_reduce_ex before the apply pass runs -- Samuelson's inequality bounds a BatchNorm output from its statistics alone);
+ *   - dropout fused behind the activation: out = dropout(act(...)) with pylc_dropout's counter-based mask (models/modules/aspp.py:86,
+ *     models/decoder.py:33,37); the backward regenerates the mask from the seed;
+ *   - g_amax: pylc_bn_bwd_reduce_ex max-accumulates max|g| into it (zero-initialised by the caller). */
+typedef struct PylcBnExtra {
+    void* out_planes;        long long out_plane_stride;  const unsigned int* out_bound;   /* bn_apply output; the `out` the backward masks with */
+    const void* res_planes;  long long res_plane_stride;  const unsigned int* res_amax;    /* bn_apply residual input */
+    void* dy_planes;         long long dy_plane_stride;   const unsigned int* dy_bound;    /* bn_bwd_apply output */
+    int nplanes;             /* 2, or 1 = plane 0 only (precision mode 3) */
+    float drop_p;            /* 0 = no dropout */
+    uint64_t drop_seed;
+    unsigned int* g_amax;
+} PylcBnExtra;
+/* pylc_bn_finalize / _from_partial that also max-accumulate into *bound_out (zero-initialised) an upper bound of
+ * |act(BN(y)) (+ residual)| * bound_mul:  max_c (|gamma_c| sqrt(n - 1) + |beta_c|) + *bound_extra (the residual's range, may be NULL). */
+int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                        int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                        float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream);
+int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
+                                     float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
+                                     float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
+                                     float bound_mul, unsigned int* bound_out, void* stream);
+int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
+                     float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, const PylcBnExtra* ex,
+                     void* stream);
+/* dy_bound_out (may be NULL; zero-initialised; needs ex->g_amax, gamma, n): bound of the dy that pylc_bn_bwd_apply_ex will write,
+ * |gamma invstd| (max|g| + |sum g| / n + sqrt(n - 1) |sum g xhat| / n), from the LOCAL sums (single GPU); with all-reduced sums
+ * call pylc_bn_bwd_bound after the exchange instead. */
+int pylc_bn_bwd_reduce_ex(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                          const float* mean, const float* invstd, long long M, int C, int relu, float* sums, float* workspace,
+                          const float* scale, const float* shift, const float* gamma, double n, const PylcBnExtra* ex,
+                          unsigned int* dy_bound_out, void* stream);
+int pylc_bn_bwd_bound(const float* sums, const float* gamma, const float* invstd, double n, int C, const unsigned int* g_amax,
+                      unsigned int* bound_out, void* stream);
+int pylc_bn_bwd_apply_ex(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                         const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
+                         int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy,
+                         const float* scale, const float* shift, const PylcBnExtra* ex, void* stream);
 /* Plain ReLU forward / backward on [M][C] (Xception's stand-alone ReLUs, xception.py:83-84,199-232). */
 int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream);
 int pylc_relu_bwd(const float* dout, int dout_pitch, const float* out, int out_pitch, float* dx, int dx_pitch,

@@ -8,10 +8,76 @@
 // Replaces torch.nn.BatchNorm2d (models/model.py:71-76) + ReLU + residual add at resnet.py:36-51,
 // aspp.py:28-31,81-84, decoder.py:42-44 and last_conv, unet.py:113-118, xception.py:37,60-97; the
 // synchronized variant's wire format follows models/sync_batchnorm/batchnorm.py:48-125.
-#include "common.h"
+#include "conv_common.h"
 #include "slab.h"
 
 namespace pylc {
+
+// ---- fp16-plane tensors (include/pylc_hip.h "fp16 planes"): a thread's float4 channel vector <-> 4 halves per plane ----------
+struct PlanesRef {            // where a planes tensor lives and how it was scaled
+    _Float16* base;           // plane 0; nullptr = the tensor is fp32
+    long long plane_stride;   // halves between the planes
+    int nplanes;              // 2, or 1 (precision mode 3: plane 0 only)
+    float scale;              // power of two the values were multiplied with (pow2_scale_for(bound))
+};
+
+__device__ __forceinline__ void planes_store4(const PlanesRef& p, long long elem, f32x4 v) {
+    uint2 p0, p1;
+    split2(v, p.scale, p0, p1);
+    *reinterpret_cast<uint2*>(p.base + elem) = p0;
+    if (p.nplanes == 2) *reinterpret_cast<uint2*>(p.base + p.plane_stride + elem) = p1;
+}
+
+// raw pieces of a float4 channel vector (loaded in a walk's load pass, decoded in its math pass)
+struct PlanesRaw { uint2 h0, h1; };
+__device__ __forceinline__ PlanesRaw planes_raw4(const PlanesRef& p, long long elem) {
+    PlanesRaw r;
+    r.h0 = *reinterpret_cast<const uint2*>(p.base + elem);
+    r.h1 = p.nplanes == 2 ? *reinterpret_cast<const uint2*>(p.base + p.plane_stride + elem) : make_uint2(0u, 0u);
+    return r;
+}
+__device__ __forceinline__ f32x4 halves4(uint2 u) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const f16x4 h = __builtin_bit_cast(f16x4, u);
+    const f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+}
+// value: (h0 + 2^-11 h1) / s
+__device__ __forceinline__ f32x4 planes_value4(const PlanesRaw& r, float inv_scale) {
+    return (halves4(r.h0) + halves4(r.h1) * (1.f / 2048.f)) * inv_scale;
+}
+// sign carrier for the ReLU mask: positive iff the element is (one of its pieces is; both are >= 0 for a ReLU output)
+__device__ __forceinline__ f32x4 planes_sign4(const PlanesRaw& r) {
+    const f32x4 a = halves4(r.h0), b = halves4(r.h1);
+    const f32x4 v = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+    return v;
+}
+
+// optional extras of the BatchNorm kernels (the *_ex entry points): fp16-plane operands and the dropout fused behind the activation
+struct BnEx {
+    _Float16* out_pl; long long out_ps; const unsigned* out_bound;        // bn_apply's output / the `out` the backward reads its mask from
+    const _Float16* res_pl; long long res_ps; const unsigned* res_amax;   // bn_apply's residual input
+    _Float16* dy_pl; long long dy_ps; const unsigned* dy_bound;           // bn_bwd_apply's dy
+    int nplanes;
+    unsigned drop_thresh; float keep_scale; unsigned long long seed;       // drop_thresh == 0: no dropout
+    unsigned* g_amax;                                                      // bn_bwd_reduce: max |g| (zero-initialised by the caller)
+};
+
+// counter-based hash RNG: one 64-bit mix per float4 -> 4 x 16-bit uniform thresholds (dropout; the backward regenerates the mask)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct DropRef { unsigned thresh16; float keep_scale; unsigned long long seed; };     // thresh16 == 0: no dropout
+__device__ __forceinline__ f32x4 drop4(const DropRef& d, long long r, int CV, int cv, f32x4 v) {
+    const unsigned long long h = mix64(d.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r * CV + cv + 1));
+    v.x = ((h & 0xFFFF) >= d.thresh16) ? v.x * d.keep_scale : 0.f;
+    v.y = (((h >> 16) & 0xFFFF) >= d.thresh16) ? v.y * d.keep_scale : 0.f;
+    v.z = (((h >> 32) & 0xFFFF) >= d.thresh16) ? v.z * d.keep_scale : 0.f;
+    v.w = (((h >> 48) & 0xFFFF) >= d.thresh16) ? v.w * d.keep_scale : 0.f;
+    return v;
+}
 
 __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 o) {
     f32x4 r;
@@ -20,19 +86,27 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 o) {
 }
 
 // ---- reductions --------------------------------------------------------------------------------
-// MODE 0: (sum y, sum y^2).  MODE 1: (sum g, sum g*xhat) with g = dout * (out > 0).
-template <int MODE>
+// MODE 0: (sum y, sum y^2).  MODE 1: (sum g, sum g*xhat) with g = [dropout mask * keep scale *] dout * (out > 0).
+// EX (MODE 1): `out` may be an fp16-plane tensor, dropout is regenerated from its seed, max|g| goes to ex.g_amax.
+template <int MODE, bool EX = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a, int a_pitch,
                                                         const float* __restrict__ out, int out_pitch,
                                                         const float* __restrict__ y, int y_pitch,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         int relu, Slab g, int C, float* __restrict__ partial,
-                                                        const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, BnEx ex) {
     __shared__ f32x4 red[2][256];
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
+    PlanesRef po{};
+    DropRef dr{};
+    if constexpr (EX) {
+        if (ex.out_pl != nullptr) po = PlanesRef{ex.out_pl, ex.out_ps, ex.nplanes, 1.f};
+        dr = DropRef{ex.drop_thresh, ex.keep_scale, ex.seed};
+    }
+    float gmax = 0.f;
     for (int cb = 0; cb < g.CV; cb += g.cols) {
         const int cv = cb + tx;
         const bool active = ty < g.RL && cv < g.CV;
@@ -40,26 +114,34 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         if (active) {
             f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
             f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
-            const bool remask = MODE == 1 && relu && out == nullptr;      // ReLU mask recomputed from y: out = max(y*scale + shift, 0)
+            const bool out_pl = EX && po.base != nullptr;
+            const bool remask = MODE == 1 && relu && out == nullptr && !out_pl;      // ReLU mask recomputed from y: out = max(y*scale + shift, 0)
             if (MODE == 1) { mu = ld4(mean + 4 * cv); is = ld4(invstd + 4 * cv); }
             if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
-            const bool use_out = MODE == 1 && relu && !remask;
+            const bool use_out = MODE == 1 && relu && !remask && !out_pl;
             f32x4 va[kRowBatch], vy[kRowBatch], vo[kRowBatch];
+            PlanesRaw vp[EX ? kRowBatch : 1];
             walk_rows(r_begin + ty, r_end, g.RL,
                 [&](int u, long long r) {
                     va[u] = ld4(a + r * a_pitch + 4 * cv);
                     if (MODE == 1) vy[u] = ld4(y + r * y_pitch + 4 * cv);
                     if (use_out) vo[u] = ld4(out + r * out_pitch + 4 * cv);
+                    if constexpr (EX) { if (out_pl && relu) vp[u] = planes_raw4(po, r * out_pitch + 4 * cv); }
                 },
-                [&](int u, long long, bool valid) {
+                [&](int u, long long r, bool valid) {
                     if (MODE == 0) {
                         if (valid) { s0 += va[u]; s1 += va[u] * va[u]; }
                     } else {
                         f32x4 gg = va[u];
+                        if constexpr (EX) { if (dr.thresh16) gg = drop4(dr, r, g.CV, cv, gg); }
                         if (remask) gg = relu_mask(gg, vy[u] * sc + sh);   // the forward's own expression: identical bits
-                        else if (relu) gg = relu_mask(gg, vo[u]);
+                        else if (use_out) gg = relu_mask(gg, vo[u]);
+                        if constexpr (EX) { if (out_pl && relu) gg = relu_mask(gg, planes_sign4(vp[u])); }
                         const f32x4 xh = (vy[u] - mu) * is;
-                        if (valid) { s0 += gg; s1 += gg * xh; }
+                        if (valid) {
+                            s0 += gg; s1 += gg * xh;
+                            if constexpr (EX) gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(gg.x), fabsf(gg.y))), fmaxf(fabsf(gg.z), fabsf(gg.w)));
+                        }
                     }
                 },
                 [](int, long long) {});
@@ -77,14 +159,28 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         }
         __syncthreads();
     }
+    if constexpr (EX) { if (ex.g_amax != nullptr) amax_commit(gmax, ex.g_amax); }
+}
+
+// Range bound of a BatchNorm output for the fp16-plane format, from what the statistics already give: by Samuelson's inequality
+// |y - mean| <= sigma sqrt(n - 1), so |xhat| <= sqrt(n - 1) and |gamma xhat + beta| <= |gamma| sqrt(n - 1) + |beta| -- loose by
+// sqrt(n) / (the true max |xhat|, a handful), i.e. 5-8 binades of the 29 the format has to spare, but free:
+// no min / max pass, and known BEFORE the apply pass writes the planes.  `extra` = range of the residual input (float bits, may
+// be NULL); `mul` = dropout's 1 / (1 - p).
+__device__ __forceinline__ void bn_commit_bound(float gamma, float beta, double n, const unsigned* extra, float mul, unsigned* bound_out) {
+    float b = fabsf(gamma) * (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) + fabsf(beta);
+    if (extra != nullptr) b += __uint_as_float(*extra);
+    b *= mul;
+    atomicMax(bound_out, __float_as_uint(b));
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
                                    float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                   float* shift) {
+                                   float* shift, const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
     const double mu = (double)sums[c] / n;
     double var = (double)sums[C + c] / n - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -108,7 +204,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int
 __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* __restrict__ partial, int nrows, double n, int C,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                   float momentum, int clamp_eps, float* running_mean, float* running_var,
-                                                                  float* mean, float* invstd, float* scale, float* shift) {
+                                                                  float* mean, float* invstd, float* scale, float* shift,
+                                                                  const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
     __shared__ double red[2][32][9];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + tx;
@@ -134,6 +231,7 @@ __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* _
     red[1][ty][tx] = a1;
     __syncthreads();
     if (ty != 0 || c >= C) return;
+    if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 32; ++k) { s0 += red[0][k][tx]; s1 += red[1][k][tx]; }
@@ -156,46 +254,73 @@ __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* _
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
-                                      int C, float* scale, float* shift) {
+                                      int C, float* scale, float* shift, float* mean, float* invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float sc = gamma[c] / sqrtf(rv[c] + eps);
     scale[c] = sc;
     shift[c] = beta[c] - rm[c] * sc;
+    if (mean != nullptr) {                   // what an eval-mode backward needs (running statistics are constants)
+        mean[c] = rm[c];
+        invstd[c] = 1.f / sqrtf(rv[c] + eps);
+    }
 }
 
 // ---- elementwise -------------------------------------------------------------------------------
+template <bool EX = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_pitch,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ res, int res_pitch, float* __restrict__ out,
-                                                       int out_pitch, int relu, Slab g, unsigned* __restrict__ amax_out) {
+                                                       int out_pitch, int relu, Slab g, unsigned* __restrict__ amax_out, BnEx ex) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
     float amax = 0.f;
+    PlanesRef po{}, pr{};
+    DropRef dr{};
+    float res_inv = 1.f;
+    if constexpr (EX) {
+        if (ex.out_pl != nullptr) po = PlanesRef{ex.out_pl, ex.out_ps, ex.nplanes, pow2_scale_for(*ex.out_bound)};
+        if (ex.res_pl != nullptr) {
+            pr = PlanesRef{const_cast<_Float16*>(ex.res_pl), ex.res_ps, ex.nplanes, 1.f};
+            res_inv = 1.f / pow2_scale_for(*ex.res_amax);
+        }
+        dr = DropRef{ex.drop_thresh, ex.keep_scale, ex.seed};
+    }
+    const bool res_pl = EX && pr.base != nullptr, out_pl = EX && po.base != nullptr;
     if (ty < g.RL) {
         for (int cv = tx; cv < g.CV; cv += g.cols) {
             const f32x4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
             f32x4 vy[kRowBatch], vr[kRowBatch];
+            PlanesRaw vp[EX ? kRowBatch : 1];
             walk_rows(r_begin + ty, r_end, g.RL,
                 [&](int u, long long r) {
                     vy[u] = ld4(y + r * y_pitch + 4 * cv);
                     if (res != nullptr) vr[u] = ld4(res + r * res_pitch + 4 * cv);
+                    if constexpr (EX) { if (res_pl) vp[u] = planes_raw4(pr, r * res_pitch + 4 * cv); }
                 },
-                [&](int u, long long, bool valid) {
+                [&](int u, long long r, bool valid) {
                     f32x4 v = vy[u] * sc + sh;
                     if (res != nullptr) v += vr[u];
+                    if constexpr (EX) { if (res_pl) v += planes_value4(vp[u], res_inv); }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if constexpr (EX) { if (dr.thresh16) v = drop4(dr, r, g.CV, cv, v); }
                     vy[u] = v;
                     if (valid) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 },
-                [&](int u, long long r) { st4(out + r * out_pitch + 4 * cv, vy[u]); });
+                [&](int u, long long r) {
+                    if (out_pl) { if constexpr (EX) planes_store4(po, r * out_pitch + 4 * cv, vy[u]); }
+                    else st4(out + r * out_pitch + 4 * cv, vy[u]);
+                });
         }
     }
     if (amax_out != nullptr) amax_commit(amax, amax_out);      // range of the output for the f16x3 conv that consumes it
 }
 
+// EX: `out` (ReLU mask) may be an fp16-plane tensor, the forward's dropout is regenerated, dy may be written as fp16 planes scaled
+// with the bound in ex.dy_bound (bn_bwd_sums_kernel).
+template <bool EX = false>
 __global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
                                                            const float* __restrict__ out, int out_pitch,
                                                            const float* __restrict__ y, int y_pitch,
@@ -204,33 +329,45 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __res
                                                            float inv_n, int C, int relu, float* __restrict__ dy, int dy_pitch,
                                                            float* __restrict__ g_out, int g_pitch, Slab g,
                                                            unsigned* __restrict__ amax_dy, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift) {
+                                                           const float* __restrict__ shift, BnEx ex) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
     if (r_end > g.M) r_end = g.M;
     float amax = 0.f;
+    PlanesRef po{}, pd{};
+    DropRef dr{};
+    if constexpr (EX) {
+        if (ex.out_pl != nullptr) po = PlanesRef{ex.out_pl, ex.out_ps, ex.nplanes, 1.f};
+        if (ex.dy_pl != nullptr) pd = PlanesRef{ex.dy_pl, ex.dy_ps, ex.nplanes, pow2_scale_for(*ex.dy_bound)};
+        dr = DropRef{ex.drop_thresh, ex.keep_scale, ex.seed};
+    }
+    const bool out_pl = EX && po.base != nullptr, dy_pl = EX && pd.base != nullptr;
     if (ty < g.RL) {
         for (int cv = tx; cv < g.CV; cv += g.cols) {
             const f32x4 mu = ld4(mean + 4 * cv), is = ld4(invstd + 4 * cv);
             const f32x4 k = ld4(gamma + 4 * cv) * is;
             const f32x4 sgx = ld4(sums + 4 * cv) * inv_n, sg = ld4(sums + C + 4 * cv) * inv_n;
-            const bool remask = relu && out == nullptr;
+            const bool remask = relu && out == nullptr && !out_pl;
             f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
             if (remask) { sc = ld4(scale + 4 * cv); sh = ld4(shift + 4 * cv); }
-            const bool use_out = relu && !remask;
+            const bool use_out = relu && !remask && !out_pl;
             constexpr int NB = 4;            // 4 rows x 3 tensors in flight per wave; 136 registers = 3 waves per SIMD = the 3 blocks per CU of a 768-slab launch
             f32x4 vg[NB], vy[NB], vo[NB];
+            PlanesRaw vp[EX ? NB : 1];
             walk_rows<NB>(r_begin + ty, r_end, g.RL,
                 [&](int u, long long r) {
                     vg[u] = ld4(dout + r * dout_pitch + 4 * cv);
                     vy[u] = ld4(y + r * y_pitch + 4 * cv);
                     if (use_out) vo[u] = ld4(out + r * out_pitch + 4 * cv);
+                    if constexpr (EX) { if (out_pl && relu) vp[u] = planes_raw4(po, r * out_pitch + 4 * cv); }
                 },
-                [&](int u, long long, bool valid) {
+                [&](int u, long long r, bool valid) {
                     f32x4 gg = vg[u];
+                    if constexpr (EX) { if (dr.thresh16) gg = drop4(dr, r, g.CV, cv, gg); }
                     if (remask) gg = relu_mask(gg, vy[u] * sc + sh);
-                    else if (relu) gg = relu_mask(gg, vo[u]);
+                    else if (use_out) gg = relu_mask(gg, vo[u]);
+                    if constexpr (EX) { if (out_pl && relu) gg = relu_mask(gg, planes_sign4(vp[u])); }
                     const f32x4 xh = (vy[u] - mu) * is;
                     const f32x4 v = k * (gg - sg - xh * sgx);
                     vg[u] = gg;                                      // the masked gradient (residual branch) and dy, kept for the store pass
@@ -239,11 +376,59 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __res
                 },
                 [&](int u, long long r) {
                     if (g_out != nullptr) st4(g_out + r * g_pitch + 4 * cv, vg[u]);
-                    st4(dy + r * dy_pitch + 4 * cv, vy[u]);
+                    if (dy_pl) { if constexpr (EX) planes_store4(pd, r * dy_pitch + 4 * cv, vy[u]); }
+                    else st4(dy + r * dy_pitch + 4 * cv, vy[u]);
                 });
         }
     }
     if (amax_dy != nullptr) amax_commit(amax, amax_dy);
+}
+
+// Column combine of bn_reduce_kernel<1>'s partials (column_sum_kernel's arithmetic: fp64, fixed order) for BOTH halves of 8 channels
+// per block, plus the range bound of the dy that bn_bwd_apply is about to write as fp16 planes:
+//     dy = k (g - sg - xhat sgx),  k = gamma invstd  =>  |dy| <= |k| (max|g| + |sg| + sqrt(n - 1) |sgx|)       (|xhat| <= sqrt(n - 1))
+// with the actual per-channel means sg = sum g / n, sgx = sum g xhat / n (sgx is O(max|g| / sqrt(n)) for uncorrelated g, so the last
+// term stays O(max|g|)).  `sums` = [sum g xhat | sum g] (parameter order).
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int nrows, int C, float* __restrict__ sums,
+                                                          const float* __restrict__ gamma, const float* __restrict__ invstd, double n,
+                                                          const unsigned* __restrict__ g_amax, unsigned* __restrict__ bound_out) {
+    __shared__ double red[2][32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        int r = ty;
+        for (; r + 7 * 32 < nrows; r += 8 * 32) {          // eight loads in flight per column; row order of the adds unchanged
+            float v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v0[u] = partial[(size_t)(r + u * 32) * 2 * C + c];
+                v1[u] = partial[(size_t)(r + u * 32) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 += (double)v0[u]; a1 += (double)v1[u]; }
+        }
+        for (; r < nrows; r += 32) {
+            a0 += (double)partial[(size_t)r * 2 * C + c];
+            a1 += (double)partial[(size_t)r * 2 * C + C + c];
+        }
+    }
+    red[0][ty][tx] = a0;
+    red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s0 += red[0][k][tx]; s1 += red[1][k][tx]; }
+    const float sgx = (float)s0, sg = (float)s1;
+    sums[c] = sgx;
+    sums[C + c] = sg;
+    if (bound_out != nullptr) {
+        const float gmax = __uint_as_float(*g_amax);
+        const float inv_n = (float)(1.0 / n);
+        const float b = fabsf(gamma[c] * invstd[c]) * (gmax + fabsf(sg) * inv_n + (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * fabsf(sgx) * inv_n);
+        atomicMax(bound_out, __float_as_uint(b));
+    }
 }
 
 template <int MODE>
@@ -271,12 +456,6 @@ __global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ a, 
     }
 }
 
-// counter-based hash RNG: one 64-bit mix per float4 -> 4 x 16-bit uniform thresholds
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ out, int out_pitch,
                                                       unsigned thresh16, float keep_scale, unsigned long long seed, Slab g) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
@@ -301,6 +480,33 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+static BnEx make_ex(const PylcBnExtra* e) {
+    BnEx x{};
+    if (e == nullptr) return x;
+    x.out_pl = static_cast<_Float16*>(e->out_planes); x.out_ps = e->out_plane_stride; x.out_bound = e->out_bound;
+    x.res_pl = static_cast<const _Float16*>(e->res_planes); x.res_ps = e->res_plane_stride; x.res_amax = e->res_amax;
+    x.dy_pl = static_cast<_Float16*>(e->dy_planes); x.dy_ps = e->dy_plane_stride; x.dy_bound = e->dy_bound;
+    x.nplanes = e->nplanes == 1 ? 1 : 2;
+    if (e->drop_p > 0.f) {
+        x.drop_thresh = (unsigned)(e->drop_p * 65536.0f + 0.5f);      // == pylc_dropout's threshold and scale
+        x.keep_scale = 1.0f / (1.0f - e->drop_p);
+        x.seed = (unsigned long long)e->drop_seed;
+    }
+    x.g_amax = e->g_amax;
+    return x;
+}
+
+static int check_ex(const PylcBnExtra* e, int C, const char* what) {
+    if (e == nullptr) return PYLC_OK;
+    PYLC_REQUIRE(e->drop_p >= 0.f && e->drop_p < 1.f, "%s: dropout p must be in [0,1)", what);
+    PYLC_REQUIRE(!e->out_planes || (e->nplanes == 1 || e->out_plane_stride > 0), "%s: bad out plane stride", what);
+    PYLC_REQUIRE(!e->out_planes || (reinterpret_cast<uintptr_t>(e->out_planes) & 7) == 0, "%s: planes must be 8-byte aligned", what);
+    PYLC_REQUIRE(!e->res_planes || e->res_amax, "%s: residual planes need their range (res_amax)", what);
+    PYLC_REQUIRE(!e->dy_planes || e->dy_bound, "%s: dy planes need dy_bound", what);
+    (void)C;
+    return PYLC_OK;
+}
+
 static int check_mc(long long M, int C, int pitch, const char* what) {
     PYLC_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "%s: need M > 0 and C %% 4 == 0 (M=%lld C=%d)", what, M, C);
     PYLC_REQUIRE(pitch >= C && pitch % 4 == 0, "%s: pitch %d invalid for C=%d", what, pitch, C);
@@ -322,7 +528,7 @@ extern "C" int pylc_bn_stats(const float* y, long long M, int C, int y_pitch, fl
     const Slab g = make_slab(M, C);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nslab), dim3(256), 0, st, y, y_pitch, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, g, C,
-                       workspace);
+                       workspace, nullptr, nullptr, BnEx{});
     PYLC_LAUNCH_CHECK();
     hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
@@ -336,13 +542,33 @@ extern "C" int pylc_bn_stats_from_partial(const float* partial, int n_rows, int 
     return PYLC_OK;
 }
 
-extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
-                                int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                float* shift, void* stream) {
+extern "C" int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                   int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                   float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream) {
     PYLC_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be set or both NULL");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums, n, C, gamma, beta, eps, momentum,
-                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift);
+                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                float* shift, void* stream) {
+    return pylc_bn_finalize_ex(sums, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift,
+                               nullptr, 1.f, nullptr, stream);
+}
+
+extern "C" int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
+                                                float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
+                                                float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
+                                                float bound_mul, unsigned int* bound_out, void* stream) {
+    PYLC_REQUIRE(partial && n_rows > 0 && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0,
+                 "bn_finalize_from_partial: bad arguments");
+    PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_from_partial: running stats must both be set or both NULL");
+    hipLaunchKernelGGL(bn_finalize_partial_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, n, C, gamma, beta, eps,
+                       momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -350,32 +576,81 @@ extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float*
 extern "C" int pylc_bn_finalize_from_partial(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
                                              float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    PYLC_REQUIRE(partial && n_rows > 0 && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0,
-                 "bn_finalize_from_partial: bad arguments");
-    PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_from_partial: running stats must both be set or both NULL");
-    hipLaunchKernelGGL(bn_finalize_partial_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, n, C, gamma, beta, eps,
-                       momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift);
-    PYLC_LAUNCH_CHECK();
-    return PYLC_OK;
+    return pylc_bn_finalize_from_partial_ex(partial, n_rows, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean,
+                                            invstd, scale, shift, nullptr, 1.f, nullptr, stream);
 }
 
 extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,
                                    float* shift, void* stream) {
     PYLC_REQUIRE(rm && rv && gamma && beta && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), rm, rv, gamma, beta, eps, C, scale, shift);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), rm, rv, gamma, beta, eps, C, scale, shift,
+                       nullptr, nullptr);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_eval_coeffs_full(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,
+                                        float* shift, float* mean, float* invstd, void* stream) {
+    PYLC_REQUIRE(rm && rv && gamma && beta && scale && shift && mean && invstd && C > 0, "bn_eval_coeffs_full: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), rm, rv, gamma, beta, eps, C, scale, shift,
+                       mean, invstd);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
+                                float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, const PylcBnExtra* ex,
+                                void* stream) {
+    if (int rc = check_mc(M, C, y_pitch, "bn_apply")) return rc;
+    if (int rc = check_mc(M, C, out_pitch, "bn_apply(out)")) return rc;
+    if (int rc = check_ex(ex, C, "bn_apply")) return rc;
+    const bool out_pl = ex && ex->out_planes, res_pl = ex && ex->res_planes;
+    PYLC_REQUIRE(y && scale && shift && (out != nullptr) != out_pl, "bn_apply: null pointer (exactly one of out / ex->out_planes)");
+    PYLC_REQUIRE(!out_pl || ex->out_bound, "bn_apply: planes output needs out_bound");
+    PYLC_REQUIRE(!(residual && res_pl), "bn_apply: residual given twice");
+    PYLC_REQUIRE((residual == nullptr && !res_pl) || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
+    const Slab g = make_slab(M, C);
+    if (ex != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
+                           out, out_pitch, relu, g, amax_out, make_ex(ex));
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
+                           out, out_pitch, relu, g, amax_out, BnEx{});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
 
 extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
                              float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, void* stream) {
-    if (int rc = check_mc(M, C, y_pitch, "bn_apply")) return rc;
-    if (int rc = check_mc(M, C, out_pitch, "bn_apply(out)")) return rc;
-    PYLC_REQUIRE(y && scale && shift && out, "bn_apply: null pointer");
-    PYLC_REQUIRE(residual == nullptr || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
+    return pylc_bn_apply_ex(y, y_pitch, scale, shift, residual, res_pitch, out, out_pitch, M, C, relu, amax_out, nullptr, stream);
+}
+
+extern "C" int pylc_bn_bwd_reduce_ex(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                                     const float* mean, const float* invstd, long long M, int C, int relu, float* sums, float* workspace,
+                                     const float* scale, const float* shift, const float* gamma, double n, const PylcBnExtra* ex,
+                                     unsigned int* dy_bound_out, void* stream) {
+    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_reduce")) return rc;
+    if (int rc = check_mc(M, C, y_pitch, "bn_bwd_reduce(y)")) return rc;
+    if (int rc = check_ex(ex, C, "bn_bwd_reduce")) return rc;
+    PYLC_REQUIRE(dout && y && mean && invstd && sums && workspace, "bn_bwd_reduce: null pointer");
+    const bool out_pl = ex && ex->out_planes;
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C && out_pitch % 4 == 0) || out_pl || (!out && scale && shift),
+                 "bn_bwd_reduce: relu needs `out` (fp32 or planes), or scale and shift to recompute the mask from y");
+    PYLC_REQUIRE(!dy_bound_out || (ex && ex->g_amax && gamma && n > 0), "bn_bwd_reduce: the dy bound needs ex->g_amax, gamma and n");
     const Slab g = make_slab(M, C);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch, out,
-                       out_pitch, relu, g, amax_out);
+    hipStream_t st = as_stream(stream);
+    if (ex != nullptr)
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
+                           relu, g, C, workspace, scale, shift, make_ex(ex));
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
+                           relu, g, C, workspace, scale, shift, BnEx{});
+    PYLC_LAUNCH_CHECK();
+    if (dy_bound_out != nullptr)
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, workspace, g.nslab, C, sums, gamma, invstd, n, ex->g_amax,
+                           dy_bound_out);
+    else
+        hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -383,17 +658,49 @@ extern "C" int pylc_bn_apply(const float* y, int y_pitch, const float* scale, co
 extern "C" int pylc_bn_bwd_reduce(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
                                   const float* mean, const float* invstd, long long M, int C, int relu, float* sums, float* workspace,
                                   const float* scale, const float* shift, void* stream) {
-    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_reduce")) return rc;
-    if (int rc = check_mc(M, C, y_pitch, "bn_bwd_reduce(y)")) return rc;
-    PYLC_REQUIRE(dout && y && mean && invstd && sums && workspace, "bn_bwd_reduce: null pointer");
-    PYLC_REQUIRE(!relu || (out && out_pitch >= C && out_pitch % 4 == 0) || (!out && scale && shift),
-                 "bn_bwd_reduce: relu needs `out`, or scale and shift to recompute the mask from y");
-    const Slab g = make_slab(M, C);
-    hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
-                       relu, g, C, workspace, scale, shift);
+    return pylc_bn_bwd_reduce_ex(dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd, M, C, relu, sums, workspace, scale, shift,
+                                 nullptr, 0.0, nullptr, nullptr, stream);
+}
+
+// dy bound from ALL-REDUCED sums (data parallel: the local bound of bn_bwd_reduce_ex would use local means)
+__global__ void bn_bwd_bound_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                    double n, int C, const unsigned* __restrict__ g_amax, unsigned* __restrict__ bound_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv_n = (float)(1.0 / n);
+    const float b = fabsf(gamma[c] * invstd[c]) *
+                    (__uint_as_float(*g_amax) + fabsf(sums[C + c]) * inv_n + (float)sqrt(n > 1.0 ? n - 1.0 : 1.0) * fabsf(sums[c]) * inv_n);
+    atomicMax(bound_out, __float_as_uint(b));
+}
+
+extern "C" int pylc_bn_bwd_bound(const float* sums, const float* gamma, const float* invstd, double n, int C, const unsigned int* g_amax,
+                                 unsigned int* bound_out, void* stream) {
+    PYLC_REQUIRE(sums && gamma && invstd && g_amax && bound_out && C > 0 && n > 0, "bn_bwd_bound: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums, gamma, invstd, n, C, g_amax, bound_out);
     PYLC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, st, workspace, g.nslab, 2 * C, sums);
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_bwd_apply_ex(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
+                                    const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
+                                    int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy,
+                                    const float* scale, const float* shift, const PylcBnExtra* ex, void* stream) {
+    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_apply")) return rc;
+    if (int rc = check_mc(M, C, dy_pitch, "bn_bwd_apply(dy)")) return rc;
+    if (int rc = check_ex(ex, C, "bn_bwd_apply")) return rc;
+    const bool out_pl = ex && ex->out_planes, dy_pl = ex && ex->dy_planes;
+    PYLC_REQUIRE(dout && y && mean && invstd && gamma && sums && n > 0 && (dy != nullptr) != dy_pl,
+                 "bn_bwd_apply: bad arguments (exactly one of dy / ex->dy_planes)");
+    PYLC_REQUIRE(!relu || (out && out_pitch >= C) || out_pl || (!out && scale && shift),
+                 "bn_bwd_apply: relu needs `out` (fp32 or planes), or scale and shift to recompute the mask from y");
+    PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
+    const Slab g = make_slab(M, C);
+    if (ex != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
+                           mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift, make_ex(ex));
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
+                           mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift, BnEx{});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -402,17 +709,8 @@ extern "C" int pylc_bn_bwd_apply(const float* dout, int dout_pitch, const float*
                                  const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
                                  int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy,
                                  const float* scale, const float* shift, void* stream) {
-    if (int rc = check_mc(M, C, dout_pitch, "bn_bwd_apply")) return rc;
-    if (int rc = check_mc(M, C, dy_pitch, "bn_bwd_apply(dy)")) return rc;
-    PYLC_REQUIRE(dout && y && mean && invstd && gamma && sums && dy && n > 0, "bn_bwd_apply: bad arguments");
-    PYLC_REQUIRE(!relu || (out && out_pitch >= C) || (!out && scale && shift),
-                 "bn_bwd_apply: relu needs `out`, or scale and shift to recompute the mask from y");
-    PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
-    const Slab g = make_slab(M, C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
-                       mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift);
-    PYLC_LAUNCH_CHECK();
-    return PYLC_OK;
+    return pylc_bn_bwd_apply_ex(dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd, gamma, sums, n, M, C, relu, dy, dy_pitch, g_out,
+                                g_pitch, amax_dy, scale, shift, nullptr, stream);
 }
 
 extern "C" int pylc_relu_fwd(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, void* stream) {

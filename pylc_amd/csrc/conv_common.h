@@ -128,6 +128,45 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 
+// ---- wgrad (conv_igemm.hip: fp32 operands; wgrad_pl.hip: fp16-plane operands) ----
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* out;             // dw, or split-K slab base
+    int M, P, Q;            // pixels of dy (dense, pitch dy_pitch)
+    int IH, IW, Cin, x_pitch, in_sh, in_sw;
+    int TR, TS, dh0, dh_step, dw0, dw_step;
+    int N, N_ld, dy_pitch;  // N valid couts; N_ld = couts readable from dy (rounded up to 4)
+    int out_row_stride;     // floats between couts in dw = T*Cin
+    int tiles_n, tiles_c;   // tiles over cout / (cin or taps*4)
+    int splits, m_per_split;
+    long long slab_stride;
+    const unsigned* amax_dy;   // f16x3: device scalars with the float bits of max|dy| and max|x|
+    const unsigned* amax_x;
+    long long x_bytes, dy_bytes;   // buffer extents (FAST path: raw buffer loads)
+    const void* x_planes;          // wgrad_pl.hip: both operands as fp16 planes (plane 1 at + *_plane_stride halves)
+    const void* dy_planes;
+    long long x_plane_stride, dy_plane_stride;
+    int nterms;                    // 3 = f16x3, 1 = plain fp16 (plane 0 only)
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__host__ __device__ constexpr int wg_rowb(int w) { return w * 2 + (w == 32 ? 0 : 64); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * rowb));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+
+int launch_wg_pl(WgradArgs& a, int cfg, long long grid, hipStream_t st);      // cfg: plan_wgrad's tile configuration (0, 1, 2)
+int wgrad_pl_init();
+
 // conv_pl.hip: the gather-GEMM whose A operand arrives as fp16 planes (GatherGemmArgs::x_planes != nullptr)
 bool takes_pl(const GatherGemmArgs& a);
 int launch_gg_pl(GatherGemmArgs& a, hipStream_t st);

@@ -1041,22 +1041,6 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
 // -------------------------------------------------------------------------------------------------
 // wgrad
 // -------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* x;
-    const float* dy;
-    float* out;             // dw, or split-K slab base
-    int M, P, Q;            // pixels of dy (dense, pitch dy_pitch)
-    int IH, IW, Cin, x_pitch, in_sh, in_sw;
-    int TR, TS, dh0, dh_step, dw0, dw_step;
-    int N, N_ld, dy_pitch;  // N valid couts; N_ld = couts readable from dy (rounded up to 4)
-    int out_row_stride;     // floats between couts in dw = T*Cin
-    int tiles_n, tiles_c;   // tiles over cout / (cin or taps*4)
-    int splits, m_per_split;
-    long long slab_stride;
-    const unsigned* amax_dy;   // f16x3: device scalars with the float bits of max|dy| and max|x|
-    const unsigned* amax_x;
-    long long x_bytes, dy_bytes;   // buffer extents (FAST path: raw buffer loads)
-};
 
 template <int BN, int BC, int WN, int WC, bool CIN4>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
@@ -1187,19 +1171,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // exactly as they are loaded ([32 pixels][channels], rows padded so that 4 consecutive rows fall in different
 // bank quarters) and the fragments are fetched with the hardware transpose read ds_read_b64_tr_b16: per 16-lane
 // group, lane 4q+p addresses row q / columns 4p..4p+3 and lane i receives column i of the 4 rows.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-
-__host__ __device__ constexpr int wg_rowb(int w) { return w * 2 + (w == 32 ? 0 : 64); }
-
-__device__ __forceinline__ bf16x8 tr_frag(const char* p, int rowb) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * rowb));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 // FAST (chosen by launch_wg when OW % 32 == 0, not the thin-input mode, both tensors below 4 GiB): every 32-pixel reduction
 // tile then lies inside one output row, so the whole gather geometry of a tile is wave-uniform (scalar unit, updated by
 // counters) and the per-lane work per row is one add, one compare and one select; operands come through raw buffer loads
@@ -1618,6 +1589,7 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 
 int conv_init() {
     if (int rc = conv_pl_init()) return rc;
+    if (int rc = wgrad_pl_init()) return rc;
 #define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, true, 0>, gg_smem<BM, BN, 0>()));                  \
@@ -1931,6 +1903,7 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     if (int rc = check_desc(d)) return rc;
     PYLC_REQUIRE(x && dy && dw, "null pointer");
     PYLC_REQUIRE(dbias == nullptr, "dbias: use pylc_bn_stats on dy (column sums)");
+    PYLC_REQUIRE(d->x_fmt == d->dy_fmt, "conv2d_wgrad: x and dy must be in the same format (both fp32 or both fp16 planes; pylc_to_planes converts)");
     hipStream_t st = as_stream(stream);
     const WgradPlan p = plan_wgrad(d);
     const size_t need = p.splits > 1 ? (size_t)p.splits * p.slab * sizeof(float) : 0;
@@ -1954,6 +1927,17 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
     a.amax_dy = d->dy_amax; a.amax_x = d->x_amax;
     const long long grid = (long long)p.tiles_n * p.tiles_c * (p.cin4 ? 1 : T) * p.splits;
     int rc;
+    if (d->x_fmt == 1) {           // both operands pre-split by their producers: wgrad_pl.hip
+        PYLC_REQUIRE(g_conv_precision >= 2 && !p.cin4 && d->Cout % 8 == 0, "conv2d_wgrad: fp16-plane operands need precision mode 2 or 3, "
+                     "a dense geometry and Cout %% 8 == 0");
+        a.x_planes = x; a.dy_planes = dy; a.x = nullptr; a.dy = nullptr;
+        a.x_plane_stride = (long long)d->B * d->H * d->W * d->x_pitch;
+        a.dy_plane_stride = (long long)d->B * d->OH * d->OW * d->y_pitch;
+        a.N_ld = d->Cout;
+        a.x_bytes /= 2; a.dy_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + a.N_ld) * 2;
+        a.nterms = g_conv_precision == 3 ? 1 : 3;
+        rc = launch_wg_pl(a, p.cfg, grid, st);
+    } else
     switch (p.cfg) {
         case 0: rc = launch_wg<128, 128, 64, 64, false>(a, grid, st); break;
         case 1: rc = launch_wg<64, 64, 32, 32, false>(a, grid, st); break;

@@ -1,0 +1,270 @@
+// wgrad with BOTH operands given as fp16 planes:  dW[n][tap][c] = sum_m dY[m][n] * X[gather(m, tap)][c].
+//
+// Same tiling, LDS image (pixel-major planes, fragments by the hardware transpose read ds_read_b64_tr_b16), MFMA order and split-K
+// slabs as conv_igemm.hip's wgrad_split_kernel -- so the result is bit-identical to it -- but the operand tiles are 16-byte copies
+// global -> register -> LDS: no vector-ALU split of fp32 values (the 128 x 128 configuration spent 144 vector instructions per 24 MFMAs
+// on it), half the load instructions (8 halves per lane and plane instead of 4 floats).  dY comes from pylc_bn_bwd_apply_ex, X from
+// pylc_bn_apply_ex / pylc_to_planes.  Register staging rather than LDS-DMA: the rows are padded (conflict-free transpose reads), and
+// an LDS-DMA instruction writes 1 KB contiguously.
+//
+// Geometry paths as wgrad_split_kernel: FAST 1 (OW % 32 == 0: every 32-pixel reduction tile lies in one output row, wave-uniform
+// gather state) and FAST 2 (any OW >= 16: per-row pixel coordinates as counters).  NTERMS 3 = f16x3, 1 = plane 0 only (mode 3).
+#include "conv_common.h"
+
+namespace pylc {
+
+template <int BN, int BC, int WN, int WC, int NTERMS, int FAST>
+__global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
+    constexpr int NPL = NTERMS == 3 ? 2 : 1;
+    constexpr int WAVES_C = BC / WC;
+    constexpr int NT = WN / 32, CT = WC / 32;
+    constexpr int VA = BN / 8, RA = 256 / VA, IA = 32 / RA > 0 ? 32 / RA : 1;      // dy tile: 8 halves per lane, RA rows per pass
+    constexpr int VB = BC / 8, RB = 256 / VB, IB = 32 / RB > 0 ? 32 / RB : 1;
+    constexpr bool A_ALL = RA <= 32, B_ALL = RB <= 32;                             // else only threads with row < 32 take part (BN = 32)
+    constexpr int ROWA = wg_rowb(BN), ROWB = wg_rowb(BC);
+    constexpr int PLA = 32 * ROWA, PLB = 32 * ROWB;          // bytes per plane
+    static_assert((BN / WN) * (BC / WC) == 4, "4 waves per block");
+    static_assert(FAST == 1 || FAST == 2, "buffer-load geometry paths only");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sA = reinterpret_cast<char*>(smem);               // NPL planes of dy
+    char* sB = sA + NPL * PLA;                               // NPL planes of gathered x
+
+    const int T = a.TR * a.TS;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = id % a.tiles_c; id /= a.tiles_c;
+    const int tn = id % a.tiles_n; id /= a.tiles_n;
+    const int tap = id % T; id /= T;
+    const int split = id;
+    const int n0 = tn * BN, c0 = tc * BC;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const int S = (m_end - m_begin + 31) / 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_n = wave / WAVES_C, wave_c = wave % WAVES_C;
+    const int va = tid % VA, pra = tid / VA;
+    const int vb = tid % VB, prb = tid / VB;
+    const int dh = a.dh0 + (tap / a.TS) * a.dh_step, dw = a.dw0 + (tap % a.TS) * a.dw_step;
+    const bool b_col_ok = c0 + 8 * vb < a.Cin && (B_ALL || prb < 32);          // Cin % 8 == 0
+    const bool a_col_ok = n0 + 8 * va < a.N_ld && (A_ALL || pra < 32);         // N_ld % 8 == 0 (launch_wg_pl)
+
+    f32x16 acc[NT][CT];
+    f32x16 acc_lo[NTERMS == 3 ? NT : 1][NTERMS == 3 ? CT : 1];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+            }
+    const float scale_a = pow2_scale_for(*a.amax_dy), scale_b = pow2_scale_for(*a.amax_x);
+
+    constexpr unsigned OOB = 0xFFFFFFF0u;                 // >= num_records: the load returns zeros
+    const __amdgpu_buffer_rsrc_t rdy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy_planes), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.dy_planes) + a.dy_plane_stride * 2), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(unsigned)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(unsigned)a.x_bytes, 0x00020000);
+
+    uint4 ra[IA][NPL], rb[IB][NPL];
+    int f_mb = m_begin, f_q0 = 0, f_p = 0, f_b = 0;
+    unsigned f_va[IA], f_tx[IB];
+    int f_wc[IB];
+    int g_q[FAST == 2 ? IB : 1], g_p[FAST == 2 ? IB : 1], g_b[FAST == 2 ? IB : 1];      // FAST 2: per-row pixel coordinates
+    if constexpr (FAST == 2) {
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int m = m_begin + prb + RB * i;
+            g_q[i] = m % a.Q;
+            const int t = m / a.Q;
+            g_p[i] = t % a.P;
+            g_b[i] = t / a.P;
+        }
+    }
+    {
+        f_q0 = m_begin % a.Q;
+        const int t = m_begin / a.Q;
+        f_p = t % a.P;
+        f_b = t / a.P;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch + n0 + 8 * va) * 2u : OOB;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch + c0 + 8 * vb) * 2u;
+            f_wc[i] = (prb + RB * i) * a.in_sw + dw;
+        }
+    }
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, unsigned voff, unsigned soff, uint4 (&dst)[NPL]) {
+        dst[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r0, voff, soff, 0));
+        if constexpr (NPL == 2) dst[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, soff, 0));
+    };
+    auto load_tile = [&]() {
+        const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 2u;
+        if constexpr (FAST == 2) {
+            const unsigned colb = (unsigned)(c0 + 8 * vb);
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int hi = g_p[i] * a.in_sh + dh, wi = g_q[i] * a.in_sw + dw;
+                const bool ok = b_col_ok & (f_mb + prb + RB * i < m_end) & ((unsigned)hi < (unsigned)a.IH) & ((unsigned)wi < (unsigned)a.IW);
+                const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch + colb) * 2u;
+                ldp(rx0, rx1, ok ? off : OOB, 0u, rb[i]);
+                g_q[i] += 32;
+                while (g_q[i] >= a.Q) { g_q[i] -= a.Q; ++g_p[i]; }
+                while (g_p[i] >= a.P) { g_p[i] -= a.P; ++g_b[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const bool ok = f_mb + pra + RA * i < m_end;
+                ldp(rdy0, rdy1, ok ? f_va[i] : OOB, soff, ra[i]);
+            }
+            f_mb += 32;
+            return;
+        }
+        // FAST 1: tile = 32 consecutive output pixels of row (f_b, f_p) starting at column f_q0
+        const int hi = f_p * a.in_sh + dh;
+        const bool row_ok = b_col_ok && (unsigned)hi < (unsigned)a.IH;
+        const unsigned delta = (unsigned)((((f_b * a.IH + hi) * a.IW + f_q0 * a.in_sw + dw) * a.x_pitch) * 2);
+        const int wq = f_q0 * a.in_sw;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const bool ok = row_ok & ((unsigned)(f_wc[i] + wq) < (unsigned)a.IW);
+            ldp(rx0, rx1, ok ? f_tx[i] + delta : OOB, 0u, rb[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < IA; ++i) ldp(rdy0, rdy1, f_va[i], soff, ra[i]);
+        f_mb += 32;
+        f_q0 += 32;
+        if (f_q0 == a.Q) {
+            f_q0 = 0;
+            if (++f_p == a.P) { f_p = 0; ++f_b; }
+        }
+    };
+    auto store_tile = [&]() {
+        if (A_ALL || pra < 32) {
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sA + pl * PLA + (pra + RA * i) * ROWA + 16 * va) = ra[i][pl];
+        }
+        if (B_ALL || prb < 32) {
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sB + pl * PLB + (prb + RB * i) * ROWB + 16 * vb) = rb[i][pl];
+        }
+    };
+    // transpose-read addressing (as wgrad_split_kernel): group g = lane>>4 covers channels 16*(g&1).., reduction half h = g>>1
+    const int g = lane >> 4, h = g >> 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const char* fa_base = sA + (8 * h + q4) * ROWA + 2 * (wave_n * WN + 16 * (g & 1) + 4 * p4);
+    const char* fb_base = sB + (8 * h + q4) * ROWB + 2 * (wave_c * WC + 16 * (g & 1) + 4 * p4);
+
+    if (S > 0) {
+        load_tile();
+        for (int s = 0; s < S; ++s) {
+            if (s > 0) __syncthreads();
+            store_tile();
+            __syncthreads();
+            if (s + 1 < S) load_tile();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[NT][NPL], fb[CT][NPL];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        const f16x8 a0 = __builtin_bit_cast(f16x8, fa[i][0]), b0 = __builtin_bit_cast(f16x8, fb[j][0]);
+                        if constexpr (NTERMS == 3) {
+                            const f16x8 a1 = __builtin_bit_cast(f16x8, fa[i][NPL - 1]), b1 = __builtin_bit_cast(f16x8, fb[j][NPL - 1]);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
+                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+    float* out = a.out + (size_t)split * a.slab_stride;
+    const int col_base = tap * a.Cin;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int c = c0 + wave_c * WC + j * 32 + (lane & 31);
+        if (c >= a.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wave_n * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float val = acc[i][j][r];
+                if constexpr (NTERMS == 3) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                else val = val * unscale_a * unscale_b;
+                if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = val;
+            }
+        }
+    }
+}
+
+template <int BN, int BC, int NTERMS>
+constexpr size_t wgpl_smem() { return (size_t)(NTERMS == 3 ? 2 : 1) * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
+
+template <int BN, int BC, int WN, int WC>
+static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
+    const int fast = a.Q % 32 == 0 ? 1 : 2;
+    const dim3 g((unsigned)grid), b(256);
+    if (a.nterms == 1) {
+        constexpr size_t lds = wgpl_smem<BN, BC, 1>();
+        if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>), g, b, lds, st, a);
+    } else {
+        constexpr size_t lds = wgpl_smem<BN, BC, 3>();
+        if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1>), g, b, lds, st, a);
+        else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2>), g, b, lds, st, a);
+    }
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+int launch_wg_pl(WgradArgs& a, int cfg, long long grid, hipStream_t st) {
+    PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
+    PYLC_REQUIRE(a.x_planes && a.dy_planes && a.amax_dy && a.amax_x, "wgrad (fp16-plane operands): null planes / ranges");
+    PYLC_REQUIRE(a.Q >= 16 && a.Cin % 8 == 0 && a.N_ld % 8 == 0 && a.x_pitch % 8 == 0 && a.dy_pitch % 8 == 0,
+                 "wgrad (fp16-plane operands): needs OW >= 16 and channel counts / pitches that are multiples of 8");
+    PYLC_REQUIRE(a.x_bytes < 0xFFFFFFF0ll && a.dy_bytes < 0xFFFFFFF0ll, "wgrad (fp16-plane operands): a plane must stay below 4 GiB");
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 64, 64>(a, grid, st);
+        case 1: return launch_cfg<64, 64, 32, 32>(a, grid, st);
+        default: return launch_cfg<32, 128, 32, 32>(a, grid, st);
+    }
+}
+
+template <typename K>
+static hipError_t opt_in(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int wgrad_pl_init() {
+#define PYLC_OPT(BN, BC, WN, WC)                                                                      \
+    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 3, 1>, wgpl_smem<BN, BC, 3>()));                  \
+    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 3, 2>, wgpl_smem<BN, BC, 3>()));                  \
+    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>, wgpl_smem<BN, BC, 1>()));                  \
+    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>, wgpl_smem<BN, BC, 1>()));
+    PYLC_OPT(128, 128, 64, 64)
+    PYLC_OPT(64, 64, 32, 32)
+    PYLC_OPT(32, 128, 32, 32)
+#undef PYLC_OPT
+    return PYLC_OK;
+}
+
+}  // namespace pylc

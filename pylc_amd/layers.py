@@ -35,6 +35,10 @@ class Conv2d(nn.Module):
     def forward(self, x, res_link=None, out=None):
         return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.feeds_bn and self.training, res_link, out)
 
+    def takes_planes(self):
+        """Static part of ops.conv_takes_planes: a BatchNorm that feeds ONLY convs for which this holds may write fp16 planes."""
+        return self.cout > 64 and self.cout % 4 == 0 and self.cin % 8 == 0
+
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,
                                                       '' if self.bias is None else ', bias')
@@ -70,12 +74,14 @@ class BatchNorm2d(nn.Module):
     def evaluate(cls, c):          # the reference's U-Net calls normalizer.evaluate(out_size) (unet.py:113,117)
         return cls(c)
 
-    def forward(self, y, residual=None, relu=False, res_link=None):
+    def forward(self, y, residual=None, relu=False, res_link=None, out_planes=False, drop=None):
+        """out_planes: every consumer of the output is a conv with takes_planes() (or a BatchNorm residual input) -- write fp16 planes.
+        drop: the Dropout module that follows the activation in the reference, fused into this pass."""
         if self.training:
             self._nbt_pending += 1          # no per-layer device add: 113 tiny launches per step otherwise
         return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, residual, relu,
                           self.training, self.eps, self.momentum, runtime.sync_group if self.training else None,
-                          runtime.bn_clamp_eps, res_link)
+                          runtime.bn_clamp_eps, res_link, out_planes, drop.spec() if drop is not None else None)
 
     def flush_counter(self):
         if self._nbt_pending:
@@ -94,14 +100,15 @@ class BatchNorm2d(nn.Module):
         return '%d' % self.num_features
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, conv_link=None):
-    """bn(conv(x), residual, relu).  In inference (eval mode, autograd off) the BatchNorm, the residual add and the ReLU run
-    inside the conv epilogue (ops.conv_bn_act_eval); otherwise the two modules are called as usual."""
+def conv_bn(conv, bn, x, residual=None, relu=False, conv_link=None, out_planes=False, drop=None):
+    """[drop](bn(conv(x), residual, relu)).  In inference (eval mode, autograd off) the BatchNorm, the residual add and the ReLU run
+    inside the conv epilogue (ops.conv_bn_act_eval); otherwise the two modules are called as usual (the conv output has ONE consumer,
+    the BatchNorm: that is what lets its backward hand dy back as fp16 planes)."""
     if (not bn.training and not torch.is_grad_enabled() and runtime.fuse_eval_bn and conv.cin % 4 == 0
             and (residual is None or ops.pitch_of(ops.as_nhwc(residual)) == ((conv.cout + 3) & ~3))):
         return ops.conv_bn_act_eval(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn.running_mean,
                                     bn.running_var, bn.weight, bn.bias, bn.eps, residual, relu)
-    return bn(conv(x, res_link=conv_link), residual=residual, relu=relu)
+    return bn(conv(x, res_link=conv_link), residual=residual, relu=relu, out_planes=out_planes, drop=drop)
 
 
 class Dropout(nn.Module):
@@ -113,6 +120,12 @@ class Dropout(nn.Module):
         if self.training and runtime.dropout_enabled and self.p > 0:
             return ops.dropout(x, self.p, runtime.next_seed())
         return x
+
+    def spec(self):
+        """(p, seed) for a BatchNorm pass that applies this dropout itself (BatchNorm2d.forward(drop=...)), None when inactive."""
+        if self.training and runtime.dropout_enabled and self.p > 0:
+            return (self.p, runtime.next_seed())
+        return None
 
 
 class Named(nn.Module):

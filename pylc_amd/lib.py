@@ -32,6 +32,14 @@ class WPrepEntry(C.Structure):
                 ('tile_begin', C.c_longlong), ('K', C.c_int), ('RS', C.c_int), ('C', C.c_int), ('amax_index', C.c_int)]
 
 
+class BnExtra(C.Structure):
+    """PylcBnExtra: fp16-plane operands / fused dropout of the BatchNorm *_ex entry points."""
+    _fields_ = [('out_planes', C.c_void_p), ('out_plane_stride', C.c_longlong), ('out_bound', C.c_void_p),
+                ('res_planes', C.c_void_p), ('res_plane_stride', C.c_longlong), ('res_amax', C.c_void_p),
+                ('dy_planes', C.c_void_p), ('dy_plane_stride', C.c_longlong), ('dy_bound', C.c_void_p),
+                ('nplanes', C.c_int), ('drop_p', C.c_float), ('drop_seed', C.c_uint64), ('g_amax', C.c_void_p)]
+
+
 class DwDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'C', 'stride', 'dil', 'OH', 'OW', 'x_pitch', 'y_pitch')]
 
@@ -76,7 +84,15 @@ SIGNATURES = {
     'pylc_bn_stats_from_partial': (_I, [_P, _I, _I, _P, _P]),
     'pylc_bn_finalize': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    'pylc_bn_eval_coeffs_full': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     'pylc_bn_finalize_from_partial': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'pylc_bn_finalize_ex': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    'pylc_bn_finalize_from_partial_ex': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    'pylc_bn_apply_ex': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P, C.POINTER(BnExtra), _P]),
+    'pylc_bn_bwd_reduce_ex': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P, _D, C.POINTER(BnExtra), _P, _P]),
+    'pylc_bn_bwd_bound': (_I, [_P, _P, _P, _D, _I, _P, _P, _P]),
+    'pylc_bn_bwd_apply_ex': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _D, _LL, _I, _I, _P, _I, _P, _I, _P, _P, _P,
+                                  C.POINTER(BnExtra), _P]),
     'pylc_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P, _P]),
     'pylc_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P]),
     'pylc_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _D, _LL, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),

@@ -42,7 +42,7 @@ class ASPP(nn.Module):
         link = ops.grad_link(x)                  # the four branch dgrads sum into one buffer (ops.ResidualLink)
         branches = [self.aspp1(x, link), self.aspp2(x, link), self.aspp3(x, link), self.aspp4(x, link), ops.bilinear(g, h, w)]
         y = ops.cat_channels(branches)           # channel concat of NHWC tensors (plumbing; the branches' ranges travel along)
-        return self.dropout(conv_bn(self.conv1, self.bn1, y, relu=True))
+        return conv_bn(self.conv1, self.bn1, y, relu=True, drop=self.dropout)      # dropout fused into the BatchNorm passes
 
 
 class Decoder(nn.Module):
@@ -59,8 +59,8 @@ class Decoder(nn.Module):
         low = conv_bn(self.conv1, self.bn1, low, relu=True, conv_link=ops.grad_link(low))
         x = ops.cat_channels((ops.bilinear(x, low.shape[2], low.shape[3]), low))
         lc = self.last_conv
-        x = self.drop3(conv_bn(lc.child(0), lc.child(1), x, relu=True))
-        x = self.drop7(conv_bn(lc.child(4), lc.child(5), x, relu=True))
+        x = conv_bn(lc.child(0), lc.child(1), x, relu=True, out_planes=lc.child(4).takes_planes(), drop=self.drop3)
+        x = conv_bn(lc.child(4), lc.child(5), x, relu=True, drop=self.drop7)
         return lc.child(8)(x)
 
 

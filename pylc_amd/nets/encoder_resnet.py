@@ -23,14 +23,18 @@ class Bottleneck(nn.Module):
             self.downsample = Named(_0=Conv2d(inplanes, planes * 4, 1, stride, bn=True), _1=BatchNorm2d(planes * 4))
         else:
             self.downsample = None
+        # activation formats: a BatchNorm writes fp16 planes when the conv(s) reading its output copy operand tiles (layers.Conv2d.takes_planes);
+        # out_planes (the block output: next block's conv1 / downsample / residual input, ASPP) is set by ResNet101
+        self.pl1, self.pl2 = self.conv2.takes_planes(), self.conv3.takes_planes()
+        self.out_planes = False
 
     def forward(self, x):
         # x's gradient has two producers: conv1's dgrad and either bn3's residual branch (identity blocks) or the downsample
         # conv's dgrad (projection blocks; the low-level features add the decoder's conv1).  The link makes them sum into one
         # buffer in their own epilogues instead of leaving several tensors for autograd to add
         link = ops.grad_link(x)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True, conv_link=link)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, conv_link=link, out_planes=self.pl1)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True, out_planes=self.pl2)
         if self.downsample is not None:
             res = conv_bn(self.downsample.child(0), self.downsample.child(1), x, conv_link=link)
             return self._tail(out, res, None)
@@ -39,8 +43,8 @@ class Bottleneck(nn.Module):
     def _tail(self, out, res, link):
         # relu(bn3(conv3(.)) + residual): one BatchNorm pass in training, the conv epilogue alone in inference
         if link is None:
-            return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True)
-        return self.bn3(self.conv3(out), residual=res, relu=True, res_link=link)
+            return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True, out_planes=self.out_planes)
+        return self.bn3(self.conv3(out), residual=res, relu=True, res_link=link, out_planes=self.out_planes)
 
 
 class ResNet101(nn.Module):
@@ -71,6 +75,13 @@ class ResNet101(nn.Module):
             blocks.append(Bottleneck(inpl, 512, s, mg * dils[3], b == 0 and (s != 1 or inpl != 2048)))
             inpl = 2048
         self.layer4 = nn.Sequential(*blocks)
+        # block outputs: planes when the next block's first conv takes them; the last block feeds the ASPP convs (2048 -> 256); the
+        # low-level features (end of layer1) also feed the decoder's narrow 1x1 conv, which reads fp32, so they stay fp32
+        chain = [b for l in (self.layer1, self.layer2, self.layer3, self.layer4) for b in l]
+        for cur, nxt in zip(chain, chain[1:]):
+            cur.out_planes = nxt.conv1.takes_planes()
+        chain[-1].out_planes = True
+        self.layer1[-1].out_planes = False
 
     def forward(self, x4):
         """x4: normalised image packed to 4 NHWC channels. Returns (features/16, low-level features/4)."""

@@ -78,6 +78,15 @@ def planes_ok(c, pixels):
     return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)
 
 
+def conv_takes_planes(w, pixels_in, pixels_out):
+    """Will conv2d() run this filter on the fp16-plane kernels (conv_pl.hip / wgrad_pl.hip)?  Needs the prepared filter planes (flat
+    arena), channel counts the 16-byte plane rows allow, and more than 64 output channels: narrower convs keep the 256x64-tile
+    kernels of conv_igemm.hip, which read fp32."""
+    cout, cin, r, s_ = w.shape
+    return (lib.pylc_get_conv_precision() >= 2 and getattr(w, '_pylc_planes', None) is not None and cin % 8 == 0 and cout % 4 == 0
+            and cout > 64 and planes_ok(cin, pixels_in) and not _runtime.no_planes)
+
+
 def mark_planes(t, amax):
     t._pylc_pl = (amax, t._version)
     tag_amax(t, amax)
@@ -151,13 +160,18 @@ class KernelTimer:
     mode, >= 192 tiles of 256x128, reduction channels % 8 == 0) are bracketed; FLOPs are algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 3 (f16x3) or
     6 (bf16x6) 16-bit MFMA FLOPs per algorithmic FLOP, so its roofline is the dense 16-bit MFMA peak / 3 (or / 6)."""
 
-    TERMS = {1: 6, 2: 3}
+    TERMS = {1: 6, 2: 3, 3: 1}
 
     def __init__(self):
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
-        self.KERNEL = 'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else 'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode
+        self.planes = self.mode >= 2 and not _runtime.no_planes
+        # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
+        # activations travel as planes; '*' = both instantiations (rocprof lists them as two rows)
+        self.KERNEL = ('gg_pl_kernel<%d,*>' % (3 if self.mode == 2 else 1) if self.planes else
+                       'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
+                       'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
 
     def bracket(self, flops, launches, kind, nbytes=0.0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -179,6 +193,7 @@ class KernelTimer:
         peak = peak_16bit_tflops / terms
         arith = ('3-term scaled fp16 split ("f16x3": a0b0 + 2^-11 (a1b0 + a0b1), cross terms in their own fp32 accumulator) '
                  'on v_mfma_f32_16x16x32_f16' if self.mode == 2 else
+                 'plain fp16 operands (scaled per tensor), fp32 accumulation, on v_mfma_f32_16x16x32_f16' if self.mode == 3 else
                  '6-term bf16 split ("bf16x6") on v_mfma_f32_32x32x16_bf16')
         return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                 'kernel': self.KERNEL, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1),
@@ -346,7 +361,7 @@ def amax_slot(device):
 def ranges_needed():
     """True when the conv kernels run the f16x3 arithmetic (precision mode 2), which scales every operand by a power of
     two taken from its max magnitude."""
-    return lib.pylc_get_conv_precision() == 2
+    return lib.pylc_get_conv_precision() >= 2
 
 
 def tag_amax(t, amax):
@@ -454,10 +469,22 @@ class Conv2dFn(torch.autograd.Function):
         ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
         if ctx.res_link is not None:
             res_link.pending += 1
-        x_pl = is_planes(x) and getattr(w, '_pylc_planes', None) is not None and w.shape[1] % 8 == 0
+        cout, cin_w, r, s = w.shape
+        b_, _, h_, w_ = x.shape
+        takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None
+        if takes and not is_planes(x):
+            # one pass; the forward AND the wgrad then copy their operand tiles instead of splitting them.  A tensor read by several
+            # convs (projection blocks, the ASPP input) is converted once: the planes copy rides on the tensor object
+            cache = getattr(x, '_pylc_plcache', None)
+            if cache is not None and cache[1] == x._version:
+                x = cache[0]
+            else:
+                src = x
+                x = to_planes(x, x_amax)
+                src._pylc_plcache = (x, src._version)
+        x_pl = takes and is_planes(x)
         if not x_pl:
             x = as_nhwc(x)
-        cout, cin_w, r, s = w.shape
         cin = x.shape[1]
         xp = pitch_of(x)
         w_k = w
@@ -494,7 +521,7 @@ class Conv2dFn(torch.autograd.Function):
         if planes is not None:
             d.w_planes = ptr(planes[0])
         ev = None
-        if _timer is not None and _is_dominant_tile(b * oh * ow, yp, cin, r * s):
+        if _timer is not None and (x_pl if _timer.planes else _is_dominant_tile(b * oh * ow, yp, cin, r * s)):
             ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
                                 4.0 * (b * h * wd * cin + cout * r * s * cin + b * oh * ow * cout))
             ev[0].record()
@@ -511,6 +538,8 @@ class Conv2dFn(torch.autograd.Function):
         if ev is not None:
             ev[1].record()
         ctx.save_for_backward(x, w_k)
+        # dy may come back as fp16 planes (BatchNorm backward writes them) when the backward kernels can take them
+        ctx.dy_pl_ok = x_pl and cout % 8 == 0 and ow >= 16 and planes_ok(cout, b * oh * ow) and yp == cout
         ctx.geom = (stride, pad, dil, cin_w, bias is not None)
         ctx.w_param, ctx.b_param = w, bias
         if want_stats:
@@ -525,10 +554,21 @@ class Conv2dFn(torch.autograd.Function):
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
-        if ctx.x_pl:
+        x_pl = ctx.x_pl
+        if x_pl:
             mark_planes(x, ctx.ranges[0])       # saved tensors come back as new Python objects: restore the marker
-            x = from_planes(x)                  # TEMPORARY until wgrad reads planes
-        dy = as_nhwc(dy)
+        dy_pl = is_planes(dy)
+        if dy_pl and not x_pl:
+            dy, dy_pl = from_planes(dy), False
+        elif x_pl and not dy_pl:
+            dy = as_nhwc(dy)
+            if dy.shape[1] % 8 == 0 and pitch_of(dy) == dy.shape[1] and planes_ok(dy.shape[1], dy.shape[0] * dy.shape[2] * dy.shape[3]) \
+                    and dy.shape[3] >= 16:
+                dy, dy_pl = to_planes(dy), True           # one pass; dgrad and wgrad then both read planes
+            else:
+                x, x_pl = from_planes(x), False
+        if not dy_pl:
+            dy = as_nhwc(dy)
         cout, _, r, s = w.shape
         cin = x.shape[1]
         yp = pitch_of(dy)
@@ -537,12 +577,13 @@ class Conv2dFn(torch.autograd.Function):
             t.copy_(dy)
             dy, yp = t, _r4(cout)
         d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, pitch_of(x), yp)
+        d.x_fmt, d.dy_fmt = int(x_pl), int(dy_pl)
         x_amax, w_amax = ctx.ranges
         dy_amax = None
         if ranges_needed():
             if x_amax is None or w_amax is None:
                 raise L.PylcError('conv backward in f16x3 mode, but the forward ran without operand ranges')
-            dy_amax = amax_of(dy)
+            dy_amax = planes_amax(dy) if dy_pl else amax_of(dy)
             d.x_amax, d.w_amax, d.dy_amax = ptr(x_amax), ptr(w_amax), ptr(dy_amax)
             planes = getattr(w, '_pylc_planes', None) if w_k is w else None
             if planes is not None:
@@ -564,7 +605,7 @@ class Conv2dFn(torch.autograd.Function):
                 check(lib.pylc_weight_transpose(ptr(w_k), ptr(wt), cout, r * s, cin, st))
             ev = None
             n_launch = 1 if stride == 1 else min(r, 2) * min(s, 2)     # one launch per non-empty output parity class
-            if _timer is not None and _is_dominant_tile(x.shape[0] * x.shape[2] * x.shape[3] // n_launch, cin, kp, 2):
+            if _timer is not None and (dy_pl if _timer.planes else _is_dominant_tile(x.shape[0] * x.shape[2] * x.shape[3] // n_launch, cin, kp, 2)):
                 ev = _timer.bracket(2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * cout * r * s * cin, n_launch, 'dgrad%dx%d' % (r, s),
                                     4.0 * (dy.numel() + cout * r * s * cin + x.numel()))
                 ev[0].record()
@@ -605,6 +646,8 @@ class Conv2dFn(torch.autograd.Function):
                 torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
             dw = _deliver_grad(w, dw)
         if has_bias and ctx.needs_input_grad[2]:
+            if dy_pl:
+                dy, yp = from_planes(dy), _r4(cout)
             m = dy.shape[0] * dy.shape[2] * dy.shape[3]
             cp = _r4(cout)
             sums = torch.empty(2 * cp, device=x.device)
@@ -630,8 +673,12 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=N
     if want_stats:
         y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link, out)
         y._pylc_sums = sums
-        return y
-    return Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out)
+    else:
+        y = Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out)
+    fn = y.grad_fn
+    if fn is not None and getattr(fn, 'dy_pl_ok', False):
+        y._pylc_dy_pl = True          # the BatchNorm that consumes y (its ONLY consumer, layers.conv_bn) may hand dy back as fp16 planes
+    return y
 
 
 def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False):
@@ -730,14 +777,27 @@ def dwconv3x3(x, w, stride=1, dil=1):
 # ----------------------------------------------------------------------------------------------
 # BatchNorm (+ ReLU, + residual), optionally synchronised across a process group
 # ----------------------------------------------------------------------------------------------
+def _bn_extra(**kw):
+    ex = L.BnExtra()
+    ex.nplanes = nplanes()
+    for k, v in kw.items():
+        setattr(ex, k, v)
+    return ex
+
+
 class BnActFn(torch.autograd.Function):
-    """out = act(BN(y) (+ residual)).  Training: batch statistics (all-reduced over `group` when given --
+    """out = [dropout](act(BN(y) (+ residual))).  Training: batch statistics (all-reduced over `group` when given --
     the SyncBN exchange of models/sync_batchnorm/batchnorm.py:48-125 as one RCCL all-reduce of
-    [sum, sumsq, count]); eval: running statistics."""
+    [sum, sumsq, count]); eval: running statistics.
+
+    out_planes: write the output as fp16 planes (ops.is_planes) for a conv that copies its operand tiles (conv_pl.hip); the scale
+    comes from a range BOUND that the statistics give before the apply pass runs (pylc_bn_finalize*_ex).  The backward hands dy back as
+    planes when the conv that produced y asked for it (y._pylc_dy_pl).  drop = (p, seed): the nn.Dropout that follows the activation
+    in the reference (aspp.py:86, decoder.py:33,37), fused into both passes."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None,
-                want_amax=False, res_link=None):
+                want_amax=False, res_link=None, out_planes=False, drop=None, dy_planes=False):
         L.init()
         ctx.set_materialize_grads(False)
         ctx.res_link = res_link
@@ -753,13 +813,25 @@ class BnActFn(torch.autograd.Function):
         if training and m == 1 and group is None:
             # torch.nn.BatchNorm2d's behaviour (the ASPP image-pool branch normalises over the batch only: B must be > 1)
             raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(y.shape),))
+        drop_p, drop_seed = drop if (drop is not None and training) else (0.0, 0)
+        out_planes = bool(out_planes and training and planes_ok(c, m))
+        res = res_pl = res_amax = None
+        if residual is not None:
+            if is_planes(residual) and training:
+                res_pl, res_amax = residual, planes_amax(residual)
+            else:
+                res = as_nhwc(residual)
+                if out_planes:
+                    res_amax = amax_of(res)
+        bound = amax_slot(dev) if out_planes else None
+        mul = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         if training:
             partial = pre_sums if (pre_sums is not None and pre_sums.dim() == 2 and pre_sums.shape[1] == 2 * c) else None
             if partial is not None and group is None:
                 # statistics came out of the conv epilogue as per-tile partials: combine + coefficients in one launch
-                check(lib.pylc_bn_finalize_from_partial(ptr(partial), partial.shape[0], n_global, c, ptr(gamma), ptr(beta), eps, momentum,
-                                                        int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
-                                                        ptr(scale), ptr(shift), st))
+                check(lib.pylc_bn_finalize_from_partial_ex(ptr(partial), partial.shape[0], n_global, c, ptr(gamma), ptr(beta), eps, momentum,
+                                                           int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
+                                                           ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound), st))
             else:
                 sums = torch.empty(2 * c + 1, device=dev)                 # [sum | sumsq | count slot for SyncBN]
                 if partial is not None:
@@ -769,28 +841,39 @@ class BnActFn(torch.autograd.Function):
                     check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
                 if group is not None:
                     sums[2 * c] = float(m)
-                    dist.all_reduce(sums, group=group)
-                    n_global = float(m) * dist.get_world_size(group)      # equal shards (drop_last loader)
-                check(lib.pylc_bn_finalize(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
-                                           ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st))
+                    _runtime.sync_all_reduce(sums, group)
+                    n_global = float(m) * dist.get_world_size(group)      # equal shards (checked by parallel.init_from_env / DataParallel setup)
+                check(lib.pylc_bn_finalize_ex(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
+                                              ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                              ptr(res_amax), mul, ptr(bound), st))
         else:
-            check(lib.pylc_bn_eval_coeffs(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
-                                          ptr(scale), ptr(shift), st))
-            mean.copy_(running_mean)
-            invstd.copy_(torch.rsqrt(running_var + eps))
-        res = None
-        if residual is not None:
-            res = as_nhwc(residual)
+            check(lib.pylc_bn_eval_coeffs_full(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
+                                               ptr(scale), ptr(shift), ptr(mean), ptr(invstd), st))
         out = empty_nhwc(b, c, h, w, dev)
-        amax = amax_slot(dev) if want_amax else None
-        check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
-                                ptr(out), c, m, c, int(relu), ptr(amax), st))
+        amax = amax_slot(dev) if (want_amax and not out_planes) else None
+        if out_planes or res_pl is not None or drop_p > 0:
+            ex = _bn_extra(drop_p=drop_p, drop_seed=drop_seed)
+            if out_planes:
+                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(bound)
+            if res_pl is not None:
+                ex.res_planes, ex.res_plane_stride, ex.res_amax = ptr(res_pl), m * c, ptr(res_amax)
+            check(lib.pylc_bn_apply_ex(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else (c if res_pl is not None else 0),
+                                       None if out_planes else ptr(out), c, m, c, int(relu), ptr(amax), C.byref(ex), st))
+        else:
+            check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
+                                    ptr(out), c, m, c, int(relu), ptr(amax), st))
         # ReLU mask in backward: without a residual it is recomputed from y (y*scale + shift > 0, the forward's own
         # expression), so `out` is neither kept alive for it nor read again
-        ctx.save_for_backward(y, out if (relu and residual is not None) else None, coef)
+        ctx.save_for_backward(y, out if (relu and residual is not None) else None, coef, bound)
         ctx.cfg = (relu, training, group, n_global, residual is not None)
         ctx.g_param, ctx.b_param = gamma, beta
         ctx.want_amax = want_amax
+        ctx.out_pl = out_planes
+        ctx.drop = (drop_p, drop_seed)
+        ctx.dy_pl = bool(dy_planes and training and planes_ok(c, m) and yp == c)
+        if out_planes:
+            ctx.mark_non_differentiable(bound)
+            return out, bound
         if want_amax:
             ctx.mark_non_differentiable(amax)
             return out, amax
@@ -799,8 +882,8 @@ class BnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         if dout is None:
-            return (None,) * 15
-        y, out, coef = ctx.saved_tensors
+            return (None,) * 18
+        y, out, coef, out_bound = ctx.saved_tensors
         relu, training, group, n_global, has_res = ctx.cfg
         gamma, beta = ctx.g_param, ctx.b_param
         dout = as_nhwc(dout)
@@ -816,28 +899,60 @@ class BnActFn(torch.autograd.Function):
                   and ctx.needs_input_grad[1] and ctx.needs_input_grad[2])
         sums = torch.as_strided(tg, (2 * c,), (1,)) if direct else torch.empty(2 * c, device=dev)
         ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
-        op = pitch_of(out) if out is not None else 0
-        check(lib.pylc_bn_bwd_reduce(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
-                                     m, c, int(relu), ptr(sums), ptr(ws), ptr(scale), ptr(shift), st))
+        out_pl = ctx.out_pl and out is not None
+        drop_p, drop_seed = ctx.drop
+        dy_pl = ctx.dy_pl
+        use_ex = out_pl or drop_p > 0 or dy_pl
+        op = (c if out_pl else pitch_of(out)) if out is not None else 0
+        ex = None
+        dy_bound = None
+        if use_ex:
+            ex = _bn_extra(drop_p=drop_p, drop_seed=drop_seed)
+            if out_pl:
+                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(out_bound)
+            if dy_pl:
+                g_amax, dy_bound = amax_slot(dev), amax_slot(dev)
+                ex.g_amax = ptr(g_amax)
+            local_bound = dy_pl and not (training and group is not None)
+            check(lib.pylc_bn_bwd_reduce_ex(ptr(dout), pitch_of(dout), None if out_pl else ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                            m, c, int(relu), ptr(sums), ptr(ws), ptr(scale), ptr(shift), ptr(gamma), n_global, C.byref(ex),
+                                            ptr(dy_bound) if local_bound else None, st))
+        else:
+            check(lib.pylc_bn_bwd_reduce(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                         m, c, int(relu), ptr(sums), ptr(ws), ptr(scale), ptr(shift), st))
         local_sums = sums
         if training and group is not None:
             sums = local_sums.clone()          # parameter grads stay local (the gradient all-reduce sums them later)
-            dist.all_reduce(sums, group=group)
+            _runtime.sync_all_reduce(sums, group)
+            if dy_pl:
+                check(lib.pylc_bn_bwd_bound(ptr(sums), ptr(gamma), ptr(invstd), n_global, c, ptr(g_amax), ptr(dy_bound), st))
         if not training:
             sums_apply = torch.zeros(2 * c, device=dev)   # running statistics are constants: dy = gamma*invstd*g
+            if dy_pl:
+                check(lib.pylc_bn_bwd_bound(ptr(sums_apply), ptr(gamma), ptr(invstd), n_global, c, ptr(g_amax), ptr(dy_bound), st))
         else:
             sums_apply = sums
         dy = empty_nhwc(b, c, h, w, dev)
         want_res = has_res and ctx.needs_input_grad[5]
-        # without a ReLU the residual's gradient IS dout: hand the tensor on instead of having the kernel write a copy (unless a
-        # conv is going to accumulate its dgrad into the buffer, which must then be ours)
-        res_is_dout = want_res and not relu and not (ctx.res_link is not None and ctx.res_link.armed)
+        # without a ReLU (and without dropout) the residual's gradient IS dout: hand the tensor on instead of having the kernel write a
+        # copy (unless a conv is going to accumulate its dgrad into the buffer, which must then be ours)
+        res_is_dout = want_res and not relu and drop_p == 0 and not (ctx.res_link is not None and ctx.res_link.armed)
         g_out = empty_nhwc(b, c, h, w, dev) if (want_res and not res_is_dout) else None
-        amax_dy = amax_slot(dev) if ctx.want_amax else None
-        check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
-                                    ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
-                                    ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), st))
-        if amax_dy is not None:
+        amax_dy = amax_slot(dev) if (ctx.want_amax and not dy_pl) else None
+        if use_ex:
+            if dy_pl:
+                ex.dy_planes, ex.dy_plane_stride, ex.dy_bound = ptr(dy), m * c, ptr(dy_bound)
+            check(lib.pylc_bn_bwd_apply_ex(ptr(dout), pitch_of(dout), None if out_pl else ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                           ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), None if dy_pl else ptr(dy), c,
+                                           ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), C.byref(ex), st))
+        else:
+            check(lib.pylc_bn_bwd_apply(ptr(dout), pitch_of(dout), ptr(out), op, ptr(y), pitch_of(y), ptr(mean), ptr(invstd),
+                                        ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), ptr(dy), c,
+                                        ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), st))
+        if dy_pl:
+            mark_planes(dy, dy_bound)   # the conv backward that receives dy reads it as planes (autograd hands the tensor on unchanged:
+                                        # y has ONE consumer, this BatchNorm)
+        elif amax_dy is not None:
             tag_amax(dy, amax_dy)       # the conv backward that receives dy reuses it (when autograd hands the tensor on unchanged)
         dgamma = dbeta = None
         if direct:
@@ -862,19 +977,32 @@ class BnActFn(torch.autograd.Function):
         if g_out is not None and link is not None and link.armed and link.buf is None and tuple(g_out.shape) == tuple(y.shape):
             link.buf = g_out         # the first conv's dgrad accumulates into it and returns it as x's whole gradient
             g_out = None
-        return dy, dgamma, dbeta, None, None, g_out, None, None, None, None, None, None, None, None, None
+        return (dy, dgamma, dbeta, None, None, g_out) + (None,) * 12
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
-           group=None, clamp_eps=False, res_link=None):
+           group=None, clamp_eps=False, res_link=None, out_planes=False, drop=None):
     pre = getattr(y, '_pylc_sums', None) if training else None
+    dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes
+    out_planes = bool(out_planes) and ranges_needed() and not _runtime.no_planes
+    if drop is not None and not (training and _runtime.dropout_enabled and drop[0] > 0):
+        drop = None
     if ranges_needed():
-        out, amax = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
-                                  True, res_link)
-        tag_amax(out, amax)
+        out, tagv = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
+                                  True, res_link, out_planes, drop, dy_pl)
+        if is_planes_candidate(out_planes, training, y):
+            mark_planes(out, tagv)
+        else:
+            tag_amax(out, tagv)
         return out
     return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
-                         False, res_link)
+                         False, res_link, False, drop, False)
+
+
+def is_planes_candidate(out_planes, training, y):
+    """Mirror of BnActFn.forward's decision whether the output was written as planes."""
+    b, c, h, w = y.shape
+    return bool(out_planes and training and planes_ok(c, b * h * w))
 
 
 class ReluFn(torch.autograd.Function):
@@ -1139,7 +1267,7 @@ class MultiLossFn(torch.autograd.Function):
         check(lib.pylc_multiloss_stats(ptr(logits), pitch_of(logits), ptr(target), n, c, ptr(class_weights), ptr(stats), ptr(ws), st))
         n_global = float(n)
         if group is not None:
-            dist.all_reduce(stats, group=group)      # Dice / weighted CE are not shard-decomposable
+            _runtime.sync_all_reduce(stats, group)   # Dice / weighted CE are not shard-decomposable
             n_global = float(n) * dist.get_world_size(group)
         losses = torch.empty(4, device=dev)
         check(lib.pylc_multiloss_finalize(ptr(stats), n_global, c, w_ce, w_dice, w_focal, ptr(losses), st))

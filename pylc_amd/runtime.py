@@ -15,8 +15,17 @@ class _Runtime:
         self.fuse_eval_bn = True      # inference: eval-mode BatchNorm (+ residual + ReLU) inside the conv epilogue (layers.conv_bn)
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
+        # PYLC_NO_PLANES=1: keep every activation fp32 (the conv kernels split operands themselves) -- A/B and bit-identity tests
+        self.no_planes = bool(os.environ.get('PYLC_NO_PLANES'))
+        self.collectives = 0          # SyncBN / loss collectives issued (diagnostics: bench.py collectives_per_step)
         self.seed = 0x5EED
         self._counter = itertools.count(1)
+
+    def sync_all_reduce(self, t, group):
+        """The SUM all-reduce of a SyncBN / loss statistics message (counted)."""
+        import torch.distributed as dist
+        self.collectives += 1
+        dist.all_reduce(t, group=group)
 
     def next_seed(self):
         """Distinct, reproducible seed per dropout call (rank-offset so data-parallel ranks draw different masks)."""
