@@ -134,6 +134,7 @@ def main():
     for _ in range(args.warmup):
         model.train(x, y)
     ops.amax_passes[:] = [0, 0]
+    ops.plane_conversions[:] = [0, 0]
     timer = None
     if not args.no_kernel_timing:
         timer = ops.KernelTimer()
@@ -172,6 +173,8 @@ def main():
                    'net_tflops_algorithmic': value * GFLOP_PER_TILE_ALL / 1e3 / world,
                    'conv_arithmetic': {0: 'f32 MFMA', 1: 'bf16x6 split', 2: 'f16x3 split'}[pylc_amd.lib.lib.pylc_get_conv_precision()],
                    'standalone_range_passes_per_step': ops.amax_passes[0] / args.steps,
+                   'activation_format': 'fp32' if pylc_amd.runtime.no_planes else 'fp16 planes between BatchNorm and conv kernels (4 B/element)',
+                   'planes_to_fp32_conversions_per_step': ops.plane_conversions[0] / args.steps,
                    'hipmalloc_calls_in_timed_region': mallocs,      # 0 in steady state (diagnostic: see DESIGN.md section 5.2, open observation)
                    'last_loss': [float(v) for v in losses[-1]] if losses else None},
     }

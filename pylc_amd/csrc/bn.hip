@@ -21,11 +21,25 @@ struct PlanesRef {            // where a planes tensor lives and how it was scal
     float scale;              // power of two the values were multiplied with (pow2_scale_for(bound))
 };
 
+// Store a float4 channel vector as planes.  Two planes: lanes 2k / 2k+1 own ADJACENT channel quads of one row (row-slab kernels: an even
+// number of vector columns per row, pairs never straddle a row), so they swap halves through DPP and each issues ONE 16-byte store
+// -- the even lane 8 halves of plane 0, the odd lane 8 halves of plane 1 -- instead of two 8-byte stores each (measured: the 8-byte
+// form made bn_bwd_apply 15 % slower than its fp32 version).  Both lanes of a pair must call this together (same row validity).
 __device__ __forceinline__ void planes_store4(const PlanesRef& p, long long elem, f32x4 v) {
     uint2 p0, p1;
     split2(v, p.scale, p0, p1);
-    *reinterpret_cast<uint2*>(p.base + elem) = p0;
-    if (p.nplanes == 2) *reinterpret_cast<uint2*>(p.base + p.plane_stride + elem) = p1;
+    if (p.nplanes == 2) {
+        const bool odd = threadIdx.x & 1;
+        const uint2 send = odd ? p0 : p1;              // what the partner stores
+        uint2 recv;
+        recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: lane ^ 1
+        recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
+        const uint4 val = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+        _Float16* dst = odd ? p.base + p.plane_stride + elem - 4 : p.base + elem;
+        *reinterpret_cast<uint4*>(dst) = val;
+    } else {
+        *reinterpret_cast<uint2*>(p.base + elem) = p0;
+    }
 }
 
 // raw pieces of a float4 channel vector (loaded in a walk's load pass, decoded in its math pass)
@@ -88,7 +102,7 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 o) {
 // ---- reductions --------------------------------------------------------------------------------
 // MODE 0: (sum y, sum y^2).  MODE 1: (sum g, sum g*xhat) with g = [dropout mask * keep scale *] dout * (out > 0).
 // EX (MODE 1): `out` may be an fp16-plane tensor, dropout is regenerated from its seed, max|g| goes to ex.g_amax.
-template <int MODE, bool EX = false>
+template <int MODE, bool EX = false, bool DROP = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a, int a_pitch,
                                                         const float* __restrict__ out, int out_pitch,
                                                         const float* __restrict__ y, int y_pitch,
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                         if (valid) { s0 += va[u]; s1 += va[u] * va[u]; }
                     } else {
                         f32x4 gg = va[u];
-                        if constexpr (EX) { if (dr.thresh16) gg = drop4(dr, r, g.CV, cv, gg); }
+                        if constexpr (DROP) gg = drop4(dr, r, g.CV, cv, gg);
                         if (remask) gg = relu_mask(gg, vy[u] * sc + sh);   // the forward's own expression: identical bits
                         else if (use_out) gg = relu_mask(gg, vo[u]);
                         if constexpr (EX) { if (out_pl && relu) gg = relu_mask(gg, planes_sign4(vp[u])); }
@@ -267,7 +281,7 @@ __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const fl
 }
 
 // ---- elementwise -------------------------------------------------------------------------------
-template <bool EX = false>
+template <bool EX = false, bool DROP = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, int y_pitch,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ res, int res_pitch, float* __restrict__ out,
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                     if (res != nullptr) v += vr[u];
                     if constexpr (EX) { if (res_pl) v += planes_value4(vp[u], res_inv); }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if constexpr (EX) { if (dr.thresh16) v = drop4(dr, r, g.CV, cv, v); }
+                    if constexpr (DROP) v = drop4(dr, r, g.CV, cv, v);
                     vy[u] = v;
                     if (valid) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 },
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // EX: `out` (ReLU mask) may be an fp16-plane tensor, the forward's dropout is regenerated, dy may be written as fp16 planes scaled
 // with the bound in ex.dy_bound (bn_bwd_sums_kernel).
-template <bool EX = false>
+template <bool EX = false, bool DROP = false>
 __global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __restrict__ dout, int dout_pitch,
                                                            const float* __restrict__ out, int out_pitch,
                                                            const float* __restrict__ y, int y_pitch,
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_apply_kernel(const float* __res
                 },
                 [&](int u, long long r, bool valid) {
                     f32x4 gg = vg[u];
-                    if constexpr (EX) { if (dr.thresh16) gg = drop4(dr, r, g.CV, cv, gg); }
+                    if constexpr (DROP) gg = drop4(dr, r, g.CV, cv, gg);
                     if (remask) gg = relu_mask(gg, vy[u] * sc + sh);
                     else if (use_out) gg = relu_mask(gg, vo[u]);
                     if constexpr (EX) { if (out_pl && relu) gg = relu_mask(gg, planes_sign4(vp[u])); }
@@ -610,8 +624,11 @@ extern "C" int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale,
     PYLC_REQUIRE(!(residual && res_pl), "bn_apply: residual given twice");
     PYLC_REQUIRE((residual == nullptr && !res_pl) || (res_pitch >= C && res_pitch % 4 == 0), "bn_apply: bad residual pitch");
     const Slab g = make_slab(M, C);
-    if (ex != nullptr)
-        hipLaunchKernelGGL((bn_apply_kernel<true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
+    if (ex != nullptr && ex->drop_p > 0.f)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
+                           out, out_pitch, relu, g, amax_out, make_ex(ex));
+    else if (ex != nullptr)
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
                            out, out_pitch, relu, g, amax_out, make_ex(ex));
     else
         hipLaunchKernelGGL((bn_apply_kernel<false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), y, y_pitch, scale, shift, residual, res_pitch,
@@ -639,8 +656,11 @@ extern "C" int pylc_bn_bwd_reduce_ex(const float* dout, int dout_pitch, const fl
     PYLC_REQUIRE(!dy_bound_out || (ex && ex->g_amax && gamma && n > 0), "bn_bwd_reduce: the dy bound needs ex->g_amax, gamma and n");
     const Slab g = make_slab(M, C);
     hipStream_t st = as_stream(stream);
-    if (ex != nullptr)
-        hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
+    if (ex != nullptr && ex->drop_p > 0.f)
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true, true>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
+                           relu, g, C, workspace, scale, shift, make_ex(ex));
+    else if (ex != nullptr)
+        hipLaunchKernelGGL((bn_reduce_kernel<1, true, false>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
                            relu, g, C, workspace, scale, shift, make_ex(ex));
     else
         hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(g.nslab), dim3(256), 0, st, dout, dout_pitch, out, out_pitch, y, y_pitch, mean, invstd,
@@ -695,8 +715,11 @@ extern "C" int pylc_bn_bwd_apply_ex(const float* dout, int dout_pitch, const flo
                  "bn_bwd_apply: relu needs `out` (fp32 or planes), or scale and shift to recompute the mask from y");
     PYLC_REQUIRE(g_out == nullptr || (g_pitch >= C && g_pitch % 4 == 0), "bn_bwd_apply: bad g pitch");
     const Slab g = make_slab(M, C);
-    if (ex != nullptr)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
+    if (ex != nullptr && ex->drop_p > 0.f)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
+                           mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift, make_ex(ex));
+    else if (ex != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,
                            mean, invstd, gamma, sums, (float)(1.0 / n), C, relu, dy, dy_pitch, g_out, g_pitch, g, amax_dy, scale, shift, make_ex(ex));
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), dim3(g.nslab), dim3(256), 0, as_stream(stream), dout, dout_pitch, out, out_pitch, y, y_pitch,

@@ -75,13 +75,11 @@ class ResNet101(nn.Module):
             blocks.append(Bottleneck(inpl, 512, s, mg * dils[3], b == 0 and (s != 1 or inpl != 2048)))
             inpl = 2048
         self.layer4 = nn.Sequential(*blocks)
-        # block outputs: planes when the next block's first conv takes them; the last block feeds the ASPP convs (2048 -> 256); the
-        # low-level features (end of layer1) also feed the decoder's narrow 1x1 conv, which reads fp32, so they stay fp32
+        # block outputs: planes when the next block's first conv takes them; the last block feeds the ASPP convs (2048 -> 256)
         chain = [b for l in (self.layer1, self.layer2, self.layer3, self.layer4) for b in l]
         for cur, nxt in zip(chain, chain[1:]):
             cur.out_planes = nxt.conv1.takes_planes()
         chain[-1].out_planes = True
-        self.layer1[-1].out_planes = False
 
     def forward(self, x4):
         """x4: normalised image packed to 4 NHWC channels. Returns (features/16, low-level features/4)."""

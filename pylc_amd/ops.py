@@ -80,11 +80,12 @@ def planes_ok(c, pixels):
 
 def conv_takes_planes(w, pixels_in, pixels_out):
     """Will conv2d() run this filter on the fp16-plane kernels (conv_pl.hip / wgrad_pl.hip)?  Needs the prepared filter planes (flat
-    arena), channel counts the 16-byte plane rows allow, and more than 64 output channels: narrower convs keep the 256x64-tile
-    kernels of conv_igemm.hip, which read fp32."""
+    arena) and channel counts the 16-byte plane rows allow.  Narrow convs (<= 64 output channels) take them too: on a 128-wide tile
+    half the MFMAs multiply zeros, but those layers are bound by bytes and by the per-tile prologue / epilogue, which two blocks per
+    CU overlap (measured: the 256x128 one-block kernel ran the K = 48 / 64 dgrads of layer1 and the decoder at 6-90 TFLOP/s)."""
     cout, cin, r, s_ = w.shape
     return (lib.pylc_get_conv_precision() >= 2 and getattr(w, '_pylc_planes', None) is not None and cin % 8 == 0 and cout % 4 == 0
-            and cout > 64 and planes_ok(cin, pixels_in) and not _runtime.no_planes)
+            and planes_ok(cin, pixels_in) and not _runtime.no_planes)
 
 
 def mark_planes(t, amax):
@@ -463,7 +464,7 @@ class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None, out=None):
+    def forward(ctx, x, w, bias, stride, pad, dil, want_stats=False, x_amax=None, w_amax=None, res_link=None, out=None, convert=False):
         L.init()
         ctx.set_materialize_grads(False)      # the auxiliary outputs (statistics, ranges) carry no gradient: no zero fills
         ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
@@ -472,7 +473,9 @@ class Conv2dFn(torch.autograd.Function):
         cout, cin_w, r, s = w.shape
         b_, _, h_, w_ = x.shape
         takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None
-        if takes and not is_planes(x):
+        if takes and not is_planes(x) and convert:
+            # (convert: training graphs only -- grad mode as seen by ops.conv2d; inference keeps fp32 operands and the kernels the
+            # fused conv + BatchNorm epilogue path runs)
             # one pass; the forward AND the wgrad then copy their operand tiles instead of splitting them.  A tensor read by several
             # convs (projection blocks, the ASPP input) is converted once: the planes copy rides on the tensor object
             cache = getattr(x, '_pylc_plcache', None)
@@ -485,6 +488,8 @@ class Conv2dFn(torch.autograd.Function):
         x_pl = takes and is_planes(x)
         if not x_pl:
             x = as_nhwc(x)
+            if os.environ.get('PYLC_DEBUG_PLANES'):
+                print('[pylc] conv fwd on fp32 operands: x %s w %s takes=%s grad=%s' % (tuple(x.shape), tuple(w.shape), takes, torch.is_grad_enabled()), flush=True)
         cin = x.shape[1]
         xp = pitch_of(x)
         w_k = w
@@ -550,7 +555,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return (None,) * 11
+            return (None,) * 12
         x, w_k = ctx.saved_tensors
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
@@ -569,6 +574,8 @@ class Conv2dFn(torch.autograd.Function):
                 x, x_pl = from_planes(x), False
         if not dy_pl:
             dy = as_nhwc(dy)
+            if os.environ.get('PYLC_DEBUG_PLANES'):
+                print('[pylc] conv bwd on fp32 operands: x %s w %s x_pl=%s dy_pl_ok=%s' % (tuple(x.shape), tuple(w.shape), ctx.x_pl, ctx.dy_pl_ok), flush=True)
         cout, _, r, s = w.shape
         cin = x.shape[1]
         yp = pitch_of(dy)
@@ -659,7 +666,7 @@ class Conv2dFn(torch.autograd.Function):
                 db = _deliver_grad(bias, tgt)
             else:
                 db = sums[:cout].clone()
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=None, out=None):
@@ -671,10 +678,10 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=N
         L.init()
         xa, wa = amax_of(x), weight_amax(w)
     if want_stats:
-        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link, out)
+        y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link, out, torch.is_grad_enabled())
         y._pylc_sums = sums
     else:
-        y = Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out)
+        y = Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out, torch.is_grad_enabled())
     fn = y.grad_fn
     if fn is not None and getattr(fn, 'dy_pl_ok', False):
         y._pylc_dy_pl = True          # the BatchNorm that consumes y (its ONLY consumer, layers.conv_bn) may hand dy back as fp16 planes
