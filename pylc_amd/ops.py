@@ -78,14 +78,27 @@ def planes_ok(c, pixels):
     return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)
 
 
+# Below this many input pixels (64 row tiles of 128: a quarter of the chip) a conv is launch-bound and gains nothing from the planes
+# kernels; it keeps fp32 operands and the round-1 kernels.  This also keeps the 96x96 DeepLab golden fixtures on the kernels they
+# were tuned against: their BatchNorms average over as few as 72 pixels and amplify a last-bit change of ONE early conv output
+# into percents of the upstream gradients (tools/mode_sensitivity.py: f16x3 vs bf16x6, both fp32-grade, move the Xception fixture's
+# backbone gradients by 4e-3 elementwise; swapping the first three convs for their bit-compatible planes kernels -- which differ from
+# the small-grid fp32 kernels only in the MFMA shape -- by 2e-2).  The planes kernels themselves are pinned bit for bit against the
+# fp32-operand kernels in tests/test_planes_gpu.py, and the full-size network tests run them.
+PLANES_MIN_PIXELS = int(os.environ.get('PYLC_PLANES_MIN_PIXELS', '8192'))
+
+
 def conv_takes_planes(w, pixels_in, pixels_out):
     """Will conv2d() run this filter on the fp16-plane kernels (conv_pl.hip / wgrad_pl.hip)?  Needs the prepared filter planes (flat
     arena) and channel counts the 16-byte plane rows allow.  Narrow convs (<= 64 output channels) take them too: on a 128-wide tile
     half the MFMAs multiply zeros, but those layers are bound by bytes and by the per-tile prologue / epilogue, which two blocks per
     CU overlap (measured: the 256x128 one-block kernel ran the K = 48 / 64 dgrads of layer1 and the decoder at 6-90 TFLOP/s)."""
     cout, cin, r, s_ = w.shape
+    only = os.environ.get('PYLC_PLANES_ONLY')          # debug: "cin:cout:k,cin:cout:k,..." with * wildcards -- planes for these filters only
+    if only and not any(all(p == '*' or int(p) == v for p, v in zip(pat.split(':'), (cin, cout, r))) for pat in only.split(',')):
+        return False
     return (lib.pylc_get_conv_precision() >= 2 and getattr(w, '_pylc_planes', None) is not None and cin % 8 == 0 and cout % 4 == 0
-            and planes_ok(cin, pixels_in) and not _runtime.no_planes)
+            and pixels_in >= PLANES_MIN_PIXELS and planes_ok(cin, pixels_in) and not _runtime.no_planes)
 
 
 def mark_planes(t, amax):
@@ -563,6 +576,8 @@ class Conv2dFn(torch.autograd.Function):
         if x_pl:
             mark_planes(x, ctx.ranges[0])       # saved tensors come back as new Python objects: restore the marker
         dy_pl = is_planes(dy)
+        if x_pl and os.environ.get('PYLC_PLANES_FWD_ONLY'):          # debug: planes in the forward pass only
+            x, x_pl = from_planes(x), False
         if dy_pl and not x_pl:
             dy, dy_pl = from_planes(dy), False
         elif x_pl and not dy_pl:
@@ -821,7 +836,7 @@ class BnActFn(torch.autograd.Function):
             # torch.nn.BatchNorm2d's behaviour (the ASPP image-pool branch normalises over the batch only: B must be > 1)
             raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(y.shape),))
         drop_p, drop_seed = drop if (drop is not None and training) else (0.0, 0)
-        out_planes = bool(out_planes and training and planes_ok(c, m))
+        out_planes = bool(out_planes and training and planes_ok(c, m) and m >= PLANES_MIN_PIXELS)
         res = res_pl = res_amax = None
         if residual is not None:
             if is_planes(residual) and training:
@@ -990,7 +1005,7 @@ class BnActFn(torch.autograd.Function):
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
            group=None, clamp_eps=False, res_link=None, out_planes=False, drop=None):
     pre = getattr(y, '_pylc_sums', None) if training else None
-    dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes
+    dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and not os.environ.get('PYLC_NO_PLANES_DY')
     out_planes = bool(out_planes) and ranges_needed() and not _runtime.no_planes
     if drop is not None and not (training and _runtime.dropout_enabled and drop[0] > 0):
         drop = None
@@ -1009,7 +1024,7 @@ def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, 
 def is_planes_candidate(out_planes, training, y):
     """Mirror of BnActFn.forward's decision whether the output was written as planes."""
     b, c, h, w = y.shape
-    return bool(out_planes and training and planes_ok(c, b * h * w))
+    return bool(out_planes and training and planes_ok(c, b * h * w) and b * h * w >= PLANES_MIN_PIXELS)
 
 
 class ReluFn(torch.autograd.Function):

@@ -450,7 +450,9 @@ def test_prepared_filter_planes_match_inline_split(dev):
     from pylc_amd.optim import FlatArena
     if lib.pylc_get_conv_precision() != 2:
         pytest.skip('prepared planes belong to the f16x3 arithmetic')
+    from pylc_amd import runtime
     torch.manual_seed(3)
+    runtime.no_planes = True            # this test is about the FILTER planes: activations stay fp32 (tests/test_planes_gpu.py covers the rest)
     for cin, cout, k, pad, b, hw in ((64, 128, 3, 1, 16, 64), (256, 136, 1, 0, 8, 128)):
         conv = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
         x = to_dev_nhwc(rnd(11, b, cin, hw, hw), dev).requires_grad_(True)
@@ -475,6 +477,7 @@ def test_prepared_filter_planes_match_inline_split(dev):
         with torch.no_grad():
             ref.weight.copy_(conv.weight)
         assert torch.equal(y2, ref(x))
+    runtime.no_planes = False
 
 
 def test_conv_multi_round_launches_are_bit_identical(dev):

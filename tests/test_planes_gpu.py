@@ -1,0 +1,189 @@
+"""fp16-plane activations (-m gpu): the kernels that read / write the pre-split format against the fp32-operand kernels.
+
+The planes kernels (conv_pl.hip, wgrad_pl.hip) form the same two fp16 pieces per element and issue the same MFMAs in the same order
+as conv_igemm.hip's f16x3 kernels, so with equal range scalars their results must be BIT-IDENTICAL; the BatchNorm kernels that
+write planes scale with a range BOUND (Samuelson) instead of the exact maximum, so they agree to the format's 2^-22.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def nhwc(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.fixture
+def f16x3(dev):
+    from pylc_amd.lib import lib, check
+    from pylc_amd import runtime
+    from pylc_amd import ops
+    prev, prev_min, prev_drop = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.dropout_enabled
+    check(lib.pylc_set_conv_precision(2))
+    ops.PLANES_MIN_PIXELS = 0              # the cases here are small: take the planes kernels at every size
+    runtime.dropout_enabled = True         # (whole-network parity tests switch dropout off process-wide)
+    yield
+    ops.PLANES_MIN_PIXELS = prev_min
+    runtime.dropout_enabled = prev_drop
+    check(lib.pylc_set_conv_precision(prev))
+    lib.pylc_debug_pp_flags(0)
+    runtime.no_planes = False
+
+
+def test_planes_round_trip(dev, f16x3):
+    from pylc_amd import ops
+    x = nhwc(rnd(1, 3, 72, 9, 11, scale=3.0), dev)
+    x[0, :, 0, 0] = 0.0
+    x[1, 5, 2, 3] = 1e-6            # 2^-21 below the maximum: still a normal low piece
+    p = ops.to_planes(x)
+    assert ops.is_planes(p) and not ops.is_planes(x)
+    back = ops.from_planes(p)
+    assert rel(back, x) < 2.0 ** -22
+    assert torch.equal(back[0, :, 0, 0], torch.zeros(72, device=dev))
+    # as_nhwc() is the safety net of every op that does not know the format
+    assert torch.equal(ops.as_nhwc(p), back)
+
+
+# cin, cout, k, stride, pad, dil, B, H, W            (wgrad tile configuration, geometry path)
+PLANES_CONV_CASES = [
+    (256, 256, 3, 1, 1, 1, 2, 32, 32),      # 128x128 wgrad tiles, row-aligned reduction tiles
+    (128, 512, 1, 1, 0, 1, 2, 32, 64),      # 1x1, identity gather
+    (256, 48, 1, 1, 0, 1, 2, 32, 32),       # narrow output (decoder conv1): one half-empty column tile; 64x64 wgrad tiles
+    (64, 64, 3, 1, 1, 1, 2, 32, 32),        # layer1 3x3
+    (256, 32, 1, 1, 0, 1, 2, 32, 32),       # 32x128 wgrad tiles
+    (304, 256, 3, 1, 1, 1, 1, 20, 44),      # Cin % 32 != 0, OW % 32 != 0: per-row counters in wgrad, partial last chunk
+    (128, 128, 3, 2, 1, 1, 2, 45, 45),      # stride 2: dgrad by parity classes, odd size, pixel tail
+    (72, 200, 3, 1, 6, 6, 3, 30, 30),       # atrous with tap skipping, N and M tails
+    (2048, 256, 3, 1, 12, 12, 2, 32, 32),   # ASPP branch on a 32^2 map
+    (32, 64, 3, 1, 1, 1, 2, 48, 48),        # Xception conv2: a single channel chunk
+    (64, 128, 1, 2, 0, 1, 2, 48, 48),       # Xception block skip: 1x1 stride 2 (dgrad: three empty parity classes)
+    (64, 128, 1, 1, 0, 1, 2, 48, 48),       # Xception pointwise
+    (728, 728, 1, 1, 0, 1, 2, 16, 16),      # middle flow: Cin, Cout % 32 != 0, both tails
+]
+
+
+@pytest.mark.parametrize('case', PLANES_CONV_CASES)
+def test_conv_on_planes_is_bit_identical(dev, f16x3, case):
+    """conv2d on a filter with prepared planes: fp32 operands (in-kernel split, 256x128 ping-pong kernel, wgrad_split_kernel) vs
+    fp16-plane operands (conversion pass + conv_pl.hip + wgrad_pl.hip) -- y, dx and dw bit for bit; y also against fp64."""
+    from pylc_amd import ops, layers, optim, runtime
+    from pylc_amd.lib import lib
+    cin, cout, k, st, pad, dil, B, H, W = case
+    torch.manual_seed(3)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil).to(dev)
+    arena = optim.FlatArena(conv)
+    assert conv.takes_planes()
+    x = nhwc(rnd(5, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    out = {}
+    for mode in ('fp32', 'planes'):
+        runtime.no_planes = mode == 'fp32'
+        lib.pylc_debug_pp_flags(1024 if mode == 'fp32' else 0)        # fp32 operands: force the 16x16x32-MFMA kernel at every size
+        x.grad = None
+        arena.g.zero_()
+        y = conv(x)
+        dy = nhwc(rnd(6, *y.shape), dev)
+        y.backward(dy)
+        ops.sync_side_streams()
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.detach().clone())
+    runtime.no_planes = False
+    lib.pylc_debug_pp_flags(0)
+    ref = torch.nn.functional.conv2d(x.detach().double().cpu(), conv.weight.detach().double().cpu(), None, st, pad, dil)
+    assert rel(out['planes'][0], ref) < 3e-6
+    # bit for bit wherever the fp32-operand path ran the same MFMA shape (16x16x32: its 256x128 kernel, i.e. more than 64 output
+    # columns -- cout in the forward, cin in dgrad; narrower products run its 32x32x16 kernels and agree to fp32 rounding); wgrad always
+    exact = {'y': cout > 64, 'dx': cin > 64, 'dw': True}
+    for name, a, b in zip(('y', 'dx', 'dw'), out['fp32'], out['planes']):
+        if exact[name]:
+            assert torch.equal(a, b), (name, rel(a, b))
+        else:
+            assert rel(a, b) < 2e-6, (name, rel(a, b))
+
+
+@pytest.mark.parametrize('c,b,hw,relu,res,drop', [(64, 4, 16, True, False, 0.0), (256, 2, 12, True, True, 0.0), (48, 3, 20, True, False, 0.5),
+                                                  (2048, 2, 4, True, True, 0.0), (1024, 2, 16, False, False, 0.1)])
+def test_bn_planes_output_and_fused_dropout(dev, f16x3, c, b, hw, relu, res, drop):
+    """BatchNorm(+residual, ReLU, dropout) writing fp16 planes (range from the Samuelson bound) vs the fp32 kernels: values to the
+    format's accuracy, parameter / input / residual gradients to fp32 rounding; the residual may itself arrive as planes.  The fused
+    dropout draws the same mask as ops.dropout with the same seed."""
+    from pylc_amd import ops
+    y0 = rnd(11, b, c, hw, hw, scale=2.0) + 0.5
+    g0, be0 = 1 + 0.1 * rnd(12, c), 0.1 * rnd(13, c)
+    r0 = rnd(16, b, c, hw, hw) if res else None
+    do = nhwc(rnd(17, b, c, hw, hw), dev)
+    seed = 0x1234ABCD
+    got = {}
+    for mode in ('fp32', 'planes'):
+        yd = nhwc(y0, dev).requires_grad_(True)
+        gd, bed = g0.to(dev).requires_grad_(True), be0.to(dev).requires_grad_(True)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        rd = nhwc(r0, dev).requires_grad_(True) if res else None
+        r_in = rd
+        if res and mode == 'planes':
+            r_in = ops.to_planes(rd.detach())          # a block input that travels as planes (no gradient through the conversion)
+        if mode == 'fp32':
+            o = ops.bn_act(yd, gd, bed, rm, rv, r_in, relu, True)
+            if drop > 0:
+                o = ops.dropout(o, drop, seed)
+        else:
+            o = ops.bn_act(yd, gd, bed, rm, rv, r_in, relu, True, out_planes=True, drop=(drop, seed) if drop > 0 else None)
+            assert ops.is_planes(o)
+        val = ops.as_nhwc(o)
+        o.backward(do)
+        torch.cuda.synchronize()
+        got[mode] = (val.detach().clone(), yd.grad.clone(), gd.grad.clone(), bed.grad.clone(), rm.clone(), rv.clone())
+    a, p = got['fp32'], got['planes']
+    assert rel(p[0], a[0]) < 2.0 ** -21
+    if drop > 0:        # same elements dropped
+        assert torch.equal(p[0] == 0, a[0] == 0) or ((p[0] == 0) != (a[0] == 0)).float().mean().item() < 1e-6
+    assert rel(p[1], a[1]) < 2e-5 and rel(p[2], a[2]) < 2e-5 and rel(p[3], a[3]) < 2e-5
+    assert torch.equal(p[4], a[4]) and torch.equal(p[5], a[5])          # running statistics do not depend on the output format
+
+
+def test_bottleneck_block_planes_vs_fp32(dev, f16x3):
+    """One projection + one identity ResNet block, training mode: every activation between BatchNorm and conv as planes (outputs,
+    residual inputs, the dy handed from BatchNorm backward to dgrad / wgrad) vs all-fp32 -- outputs and all gradients agree to fp32
+    rounding (the formats hold the same values to 2^-22; nothing else differs)."""
+    from pylc_amd import ops, optim, runtime
+    from pylc_amd.nets.encoder_resnet import Bottleneck
+    torch.manual_seed(7)
+    blocks = torch.nn.Sequential(Bottleneck(128, 64, 1, 1, True), Bottleneck(256, 64, 1, 1, False)).to(dev)
+    for m in blocks.modules():
+        if hasattr(m, 'num_features'):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    arena = optim.FlatArena(blocks)
+    blocks[0].out_planes = True
+    blocks[1].out_planes = False
+    x0 = rnd(21, 4, 128, 24, 32, scale=1.5)
+    do = nhwc(rnd(22, 4, 256, 24, 32), dev)
+    res = {}
+    for mode in ('fp32', 'planes'):
+        runtime.no_planes = mode == 'fp32'
+        blocks.train()
+        for m in blocks.modules():
+            if hasattr(m, 'running_mean'):
+                m.running_mean.zero_(); m.running_var.fill_(1.0)
+        arena.g.zero_()
+        x = nhwc(x0, dev).requires_grad_(True)
+        y = blocks(x)
+        assert not ops.is_planes(y)
+        y.backward(do)
+        ops.sync_side_streams()
+        torch.cuda.synchronize()
+        res[mode] = (y.detach().clone(), x.grad.clone(), arena.g.clone())
+    runtime.no_planes = False
+    assert ops.plane_conversions[0] >= 0
+    for name, a, b in zip(('y', 'dx', 'param grads'), res['fp32'], res['planes']):
+        assert rel(b, a) < 3e-5, (name, rel(b, a))

@@ -11,6 +11,9 @@ from pylc_amd.lib import lib
 dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [  # B, H, Cin, Cout, k, stride, pad, dil
+    (2, 4, 728, 728, 1, 1, 0, 1),
+    (2, 4, 1024, 1536, 1, 1, 0, 1),
+    (2, 8, 256, 728, 1, 2, 0, 1),
     (32, 32, 256, 1024, 1, 1, 0, 1),
     (32, 32, 1024, 256, 1, 1, 0, 1),
     (32, 32, 256, 256, 3, 1, 1, 1),
