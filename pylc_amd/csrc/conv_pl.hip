@@ -49,6 +49,124 @@ constexpr int pl_stages() { return BM == 256 ? 3 : 2; }
 template <int NTERMS, int BM>
 constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, BM>() + BM * 4 + 64; }
 
+// Epilogue shared by the planes kernels (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic,
+// then stores): fold the cross-term accumulator, undo the operand scales, bias, optional accumulation into y, BatchNorm statistics
+// partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
+template <int NTERMS, int BM>
+__device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[4][4], f32x4v (&acc_lo)[NTERMS == 3 ? 4 : 1][NTERMS == 3 ? 4 : 1],
+                                            const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid) {
+    constexpr int BN = PL_BN, WM = 64, WN = 64, AT = 4;
+    typedef f32x4v f32x4v_;
+    // ---- epilogue (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic, then stores) ----
+    float* sred = smem;             // [BM / WM][BN][2]
+    const bool do_stats = a.stats != nullptr;
+    const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
+    const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
+    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (NTERMS == 3) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                else acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
+            }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* extra = a.accumulate ? a.y : nullptr;
+    int eoff[AT][AT];
+    float bv[AT][4];
+    {
+        int offs[AT];
+#pragma unroll
+        for (int i = 0; i < AT; ++i) offs[i] = rowoff[wave_m * WM + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < AT; ++j) {
+            const int n4 = n0 + wave_n * WN + j * 16 + 4 * (lane >> 4);
+            const bool nok = n4 < a.N_store;                    // N_store % 4 == 0: all four channels or none
+#pragma unroll
+            for (int i = 0; i < AT; ++i) eoff[i][j] = (nok && offs[i] >= 0) ? offs[i] + n4 : -1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[j][r] = (a.bias != nullptr && n4 + r < a.N) ? a.bias[n4 + r] : 0.f;
+        }
+    }
+    float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+    constexpr int PJ = 2;
+    auto finish = [&](auto has_prev, auto j0c, const f32x4v_ (&prev)[AT][PJ]) {
+        constexpr int j0 = decltype(j0c)::value;
+        constexpr int NJ = decltype(has_prev)::value ? PJ : AT;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = j0 + jj;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < AT; ++i) {
+                const bool stored = eoff[i][j] >= 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = acc[i][j][r] + bv[j][r];
+                    if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
+                    acc[i][j][r] = val;
+                    const float cv = stored ? val : 0.f;
+                    cs[r] += cv;
+                    css[r] += cv * cv;
+                }
+            }
+            if (do_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+                if ((lane & 15) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r]; sdst[(j * 16 + r) * 2 + 1] = css[r]; }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+                if (eoff[i][j0 + jj] >= 0) *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if (extra == nullptr) {
+        const f32x4v_ none[AT][PJ] = {};
+        finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
+    } else {
+        f32x4v_ prev[AT][PJ];
+        auto fetch = [&](int j0) {
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < PJ; ++jj) {
+                    const f32x4v_ zero = {0.f, 0.f, 0.f, 0.f};
+                    prev[i][jj] = eoff[i][j0 + jj] >= 0 ? *reinterpret_cast<const f32x4v_*>(extra + eoff[i][j0 + jj]) : zero;
+                }
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int n = n0 + tid;
+            if (n < a.N_store) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
+                float* dst = a.stats + (size_t)tile_m * 2 * a.N_store;
+                dst[n] = sm;
+                dst[a.N_store + n] = sq;
+            }
+        }
+    }
+}
+
 // STAMPS (tools/pl_stamps.py): lane 0 of the first and the last wave of block `dbg_flags >> 16` records s_memtime at the phase
 // boundaries of every K-step into LDS (dumped to a.dbg at the end); production launches use STAMPS = false.
 template <int NTERMS, int BM, bool STAMPS = false>
@@ -162,9 +280,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     const int ntaps = __popcll(T >= 64 ? tapmask : (tapmask & ((1ull << T) - 1)));
     const int S = ntaps * nchunks;
 
-    typedef float f32x4v_ __attribute__((ext_vector_type(4)));
-    f32x4v_ acc[AT][AT];
-    f32x4v_ acc_lo[NTERMS == 3 ? AT : 1][NTERMS == 3 ? AT : 1];
+    f32x4v acc[AT][AT];
+    f32x4v acc_lo[NTERMS == 3 ? AT : 1][NTERMS == 3 ? AT : 1];
 #pragma unroll
     for (int i = 0; i < AT; ++i)
 #pragma unroll
@@ -306,114 +423,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     PL_STAMP();
     __syncthreads();          // LDS stage 0 is reused for the statistics; orders the row table when S == 0
 
-    // ---- epilogue (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic, then stores) ----
-    float* sred = reinterpret_cast<float*>(smem);             // [BM / WM][BN][2]
-    const bool do_stats = a.stats != nullptr;
-    const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
-    const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
-    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
-#pragma unroll
-    for (int i = 0; i < AT; ++i)
-#pragma unroll
-        for (int j = 0; j < AT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (NTERMS == 3) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
-                else acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
-            }
-    __builtin_amdgcn_sched_barrier(0);
-    const float* extra = a.accumulate ? a.y : nullptr;
-    int eoff[AT][AT];
-    float bv[AT][4];
-    {
-        int offs[AT];
-#pragma unroll
-        for (int i = 0; i < AT; ++i) offs[i] = rowoff[wave_m * WM + i * 16 + (lane & 15)];
-#pragma unroll
-        for (int j = 0; j < AT; ++j) {
-            const int n4 = n0 + wave_n * WN + j * 16 + 4 * (lane >> 4);
-            const bool nok = n4 < a.N_store;                    // N_store % 4 == 0: all four channels or none
-#pragma unroll
-            for (int i = 0; i < AT; ++i) eoff[i][j] = (nok && offs[i] >= 0) ? offs[i] + n4 : -1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[j][r] = (a.bias != nullptr && n4 + r < a.N) ? a.bias[n4 + r] : 0.f;
-        }
-    }
-    float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
-    constexpr int PJ = 2;
-    auto finish = [&](auto has_prev, auto j0c, const f32x4v_ (&prev)[AT][PJ]) {
-        constexpr int j0 = decltype(j0c)::value;
-        constexpr int NJ = decltype(has_prev)::value ? PJ : AT;
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int j = j0 + jj;
-            float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < AT; ++i) {
-                const bool stored = eoff[i][j] >= 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float val = acc[i][j][r] + bv[j][r];
-                    if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
-                    acc[i][j][r] = val;
-                    const float cv = stored ? val : 0.f;
-                    cs[r] += cv;
-                    css[r] += cv * cv;
-                }
-            }
-            if (do_stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
-                if ((lane & 15) == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r]; sdst[(j * 16 + r) * 2 + 1] = css[r]; }
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-            for (int i = 0; i < AT; ++i)
-                if (eoff[i][j0 + jj] >= 0) *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
-    };
-    __builtin_amdgcn_sched_barrier(0);
-    if (extra == nullptr) {
-        const f32x4v_ none[AT][PJ] = {};
-        finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
-    } else {
-        f32x4v_ prev[AT][PJ];
-        auto fetch = [&](int j0) {
-#pragma unroll
-            for (int i = 0; i < AT; ++i)
-#pragma unroll
-                for (int jj = 0; jj < PJ; ++jj) {
-                    const f32x4v_ zero = {0.f, 0.f, 0.f, 0.f};
-                    prev[i][jj] = eoff[i][j0 + jj] >= 0 ? *reinterpret_cast<const f32x4v_*>(extra + eoff[i][j0 + jj]) : zero;
-                }
-        };
-        fetch(0);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(2);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
-    }
-    if (do_stats) {
-        __syncthreads();
-        if (tid < BN) {
-            const int n = n0 + tid;
-            if (n < a.N_store) {
-                float sm = 0.f, sq = 0.f;
-#pragma unroll
-                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
-                float* dst = a.stats + (size_t)(tile / a.tiles_n) * 2 * a.N_store;
-                dst[n] = sm;
-                dst[a.N_store + n] = sq;
-            }
-        }
-    }
+    pl_epilogue<NTERMS, BM>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tile / a.tiles_n, n0, wave_m, wave_n, lane, tid);
     if constexpr (STAMPS) {
         __builtin_amdgcn_sched_barrier(0);
         PL_STAMP();
@@ -422,6 +432,193 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     }
 #undef PL_STAMP
 }
+
+// -------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / dilation 1 with the input HALO kept in LDS.
+// -------------------------------------------------------------------------------------------------------------------------
+// gg_pl_kernel re-fetches a pixel-row tile for each of the nine taps: per channel chunk 9 x (32 + 16) KB of operand DMA for a
+// 256 x 128 tile, and the L2 -> LDS path is what bounds that kernel (header).  Here an M-tile is a 16 x 16 PATCH of output pixels of
+// one image; per 32-channel chunk the 18 x 18 input halo of the patch is brought to LDS ONCE (324 rows of 64 bytes per plane, 24
+// DMA pieces) and the nine taps read their fragments from it at shifted rows: pixel (py, px), tap (r, s) -> halo row
+// (py + r') * 18 + px + s'.  A-operand DMA per chunk drops from 288 KB to 48 KB; with the filter tiles (16 KB per tap) the kernel moves
+// 21 KB per K-step instead of 48.  The chunk swizzle ((row >> 2) & 1) << 1 depends on the row's position within its group of
+// eight only, so 16 consecutive halo rows starting ANYWHERE read conflict-free (the four rows of a bank-quarter residue get
+// four different positions).  Padding pixels are DMA'd as zeros (out-of-range offsets), so no tap is ever skipped or masked.
+//
+// Block: 8 waves (4 patch-row groups x 2 channel halves, 64 x 64 outputs each as in gg_pl_kernel), one per CU.  LDS: two halo
+// buffers of 48 KB (chunk c+1 arrives while chunk c is computed) + a ring of three filter stages of 16 KB = 144 KB.  One raw
+// barrier per K-step; DMA order per wave: [filter tile s+2] at every step, [halo c+1] at the first tap of chunk c; the counted
+// vmcnt at the top of a step leaves exactly the younger requests in flight.
+// Conditions (launch_gg_pl): 3 x 3 taps with unit steps (forward pad 1 / valid, and the stride-1 dgrad of either), output height
+// and width multiples of 16, output geometry == pixel geometry.
+constexpr int PLH_HW = 18;                                   // halo width / height (16 + 2)
+constexpr int PLH_PIECES = 24;                               // 16-row DMA pieces per plane (21 cover the 324 halo rows; 3 per wave)
+constexpr int PLH_HROWS = PLH_PIECES * 16;                   // 384
+template <int NTERMS>
+constexpr int plh_halo_bytes() { return (NTERMS == 3 ? 2 : 1) * PLH_HROWS * PL_ROW; }
+template <int NTERMS>
+constexpr int plh_bstage_bytes() { return (NTERMS == 3 ? 2 : 1) * PL_BN * PL_ROW; }
+template <int NTERMS>
+constexpr int plh_lds_bytes() { return 2 * plh_halo_bytes<NTERMS>() + 3 * plh_bstage_bytes<NTERMS>() + 256 * 4 + 64; }
+
+template <int NTERMS>
+__global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) {
+    constexpr int BM = 256, BN = PL_BN, WM = 64, WN = 64, AT = 4, ROW = PL_ROW;
+    constexpr int NPL = NTERMS == 3 ? 2 : 1;
+    constexpr int HALO = plh_halo_bytes<NTERMS>(), HPL = PLH_HROWS * ROW;          // one halo buffer / one plane of it
+    constexpr int BST = plh_bstage_bytes<NTERMS>();
+    constexpr int NB = NPL, NH = 3 * NPL;                     // DMA instructions per wave: filter tile / halo
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    char* const ldsB = lds + 2 * HALO;
+    int* rowoff = reinterpret_cast<int*>(lds + 2 * HALO + 3 * BST);
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / a.tiles_n;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int lc = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    // patch position: tm -> (image, patch row, patch column); P, Q multiples of 16
+    const int pw = a.Q >> 4, ph = a.P >> 4;
+    const int tx = tm % pw, t1 = tm / pw;
+    const int ty = t1 % ph, b = t1 / ph;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int hmin_h = a.dh_step > 0 ? a.dh0 : a.dh0 + 2 * a.dh_step;          // smallest tap offset = origin of the halo
+    const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
+
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+
+    // filter row of this thread (one 16-row piece per wave)
+    const int nrow = n0 + 16 * wave + (lane >> 2);
+    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride + 8u * lc) * 2u : OOB;
+    const unsigned plane1_w = (unsigned)(a.w_plane_stride * 2);
+    // halo rows of this thread: pieces wave, wave + 8, wave + 16 -> rows 16 g + (lane >> 2); input pixel or padding (zeros)
+    unsigned hoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int h = 16 * (wave + 8 * j) + (lane >> 2);
+        const int hy = h / PLH_HW, hx = h - hy * PLH_HW;
+        const int yy = y0 + hmin_h + hy, xx = x0 + hmin_w + hx;
+        const bool ok = (h < PLH_HW * PLH_HW) & ((unsigned)yy < (unsigned)a.IH) & ((unsigned)xx < (unsigned)a.IW);
+        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch + 8u * lc) * 2u : OOB;
+    }
+    // output rows: patch pixel (py, px) = (row >> 4, row & 15)
+    if (tid < BM) {
+        const int py = tid >> 4, px = tid & 15;
+        rowoff[tid] = (int)(((long long)(b * a.OH + y0 + py) * a.OW + x0 + px) * a.y_pitch);
+    }
+
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    const int S = 9 * nchunks;
+    f32x4v acc[AT][AT];
+    f32x4v acc_lo[NTERMS == 3 ? AT : 1][NTERMS == 3 ? AT : 1];
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+            }
+
+    auto issue_halo = [&](int c) {                            // chunk c -> halo buffer c & 1
+        char* const dst = lds + (c & 1) * HALO + (16 * wave) * ROW;
+        const bool cok = c * BK + 8 * lc < a.Cin;
+        const unsigned cb = (unsigned)(c * BK * 2);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned vo = (cok & (hoff[j] != OOB)) ? hoff[j] + cb : OOB;
+            char* const d = dst + (128 * j) * ROW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)d, 16, vo, 0, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(d + HPL), 16, vo, 0, 0, 0);
+        }
+    };
+    auto issue_b = [&](int s, int slot) {                      // filter tile of step s = (chunk, tap) -> ring slot
+        const int c = s / 9, t = s - 9 * c;
+        const int tr = t / 3, ts = t - 3 * tr;
+        const bool cok = c * BK + 8 * lc < a.Cin;
+        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2);
+        const unsigned vo = cok ? woff_row : OOB;
+        const unsigned vo1 = cok ? woff_row + plane1_w : OOB;
+        char* const d = ldsB + slot * BST + (16 * wave) * ROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)d, 16, vo, so, 0, 0);
+        if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(d + BN * ROW), 16, vo1, so, 0, 0);
+    };
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int koffB = 16 * (kq ^ (((lane >> 2) & 1) << 1));
+    const char* const rb_base = ldsB + (wave_n * WN + l15) * ROW + koffB;
+    auto compute = [&](int c, int t, int slot) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const int oh = a.dh0 + tr * a.dh_step - hmin_h, ow = a.dw0 + ts * a.dw_step - hmin_w;      // 0 .. 2
+        const char* const ha = lds + (c & 1) * HALO;
+        const char* pb = rb_base + slot * BST;
+        f16x8 fb[AT][NPL];
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+        const int hr0 = (wave_m * 4 + oh) * PLH_HW + ow + l15;                 // halo row of this lane's pixel in patch row 4 wave_m
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
+            const int hr = hr0 + i * PLH_HW;
+            const char* pa = ha + hr * ROW + 16 * (kq ^ (((hr >> 2) & 1) << 1));
+            f16x8 fa[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+                if constexpr (NTERMS == 3) {
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[NPL - 1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[0], acc_lo[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // prologue: halo 0, filter tiles 0 and 1
+    issue_halo(0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    int c = 0, t = 0, slot = 0, nslot = 2;
+    for (int s = 0; s < S; ++s) {
+        // younger than filter tile s (and, at a chunk's first tap, than its halo) and allowed to stay in flight: filter tile s+1,
+        // plus the halo of the next chunk if it was requested at one of the last two steps (first tap of this chunk = step s - t)
+        const bool more = c + 1 < nchunks;
+        const int young = (s + 1 < S ? NB : 0) + ((more && (t == 1 || t == 2)) ? NH : 0);
+        if (young == NB + NH) {
+            if constexpr (NPL == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (young == NB) {
+            if constexpr (NPL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S) issue_b(s + 2, nslot);
+        if (t == 0 && more) issue_halo(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(c, t, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+        nslot = nslot == 2 ? 0 : nslot + 1;
+        if (++t == 9) { t = 0; ++c; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // LDS is reused for the statistics; orders the row table
+    pl_epilogue<NTERMS, BM>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid);
+}
+
+template __global__ void gg_plh_kernel<3>(const GatherGemmArgs);
+template __global__ void gg_plh_kernel<1>(const GatherGemmArgs);
 
 template __global__ void gg_pl_kernel<3, 128>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 256>(const GatherGemmArgs);
@@ -459,6 +656,20 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
               a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 && a.ow0 == 0 && a.OH == a.P && a.OW == a.Q;
     // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
     // tile's prologue / epilogue) -- for long reductions on grids that still fill the chip.  128 rows: two blocks per CU.
+    // 3x3 / unit steps / 16-aligned output: the halo kernel (A-operand DMA once per channel chunk instead of once per tap)
+    const bool halo_geom = a.TR == 3 && a.TS == 3 && a.in_sh == 1 && a.in_sw == 1 && (a.dh_step == 1 || a.dh_step == -1) &&
+                           a.dw_step == a.dh_step && a.P % 16 == 0 && a.Q % 16 == 0 && a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 &&
+                           a.ow0 == 0 && a.OH == a.P && a.OW == a.Q && a.w_step_s * 3 == a.w_step_r;
+    if (halo_geom && !(g_pp_flags & 16384) && (long long)(a.M / 256) * cdiv(a.N_store, PL_BN) >= kNumCU / 2) {
+        a.tile_bm = 256;
+        a.tiles_n = cdiv(a.N_store, PL_BN);
+        const long long n_tiles = (long long)(a.M / 256) * a.tiles_n;
+        a.n_tiles = (int)n_tiles;
+        if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
+        else hipLaunchKernelGGL((gg_plh_kernel<3>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     const long long ksteps = (long long)a.TR * a.TS * cdiv(a.Cin, BK);
     const long long tiles256 = (long long)cdiv(a.M, 256) * cdiv(a.N_store, PL_BN);
     bool big = ksteps >= 24 && tiles256 >= kNumCU;
@@ -489,6 +700,8 @@ int conv_pl_init() {
     PYLC_HIP(opt_in(gg_pl_kernel<3, 256>, pl_lds_bytes<3, 256>()));
     PYLC_HIP(opt_in(gg_pl_kernel<1, 128>, pl_lds_bytes<1, 128>()));
     PYLC_HIP(opt_in(gg_pl_kernel<1, 256>, pl_lds_bytes<1, 256>()));
+    PYLC_HIP(opt_in(gg_plh_kernel<3>, plh_lds_bytes<3>()));
+    PYLC_HIP(opt_in(gg_plh_kernel<1>, plh_lds_bytes<1>()));
     PYLC_HIP(opt_in(gg_pl_kernel<3, 128, true>, pl_lds_bytes<3, 128>() + 4096));
     PYLC_HIP(opt_in(gg_pl_kernel<3, 256, true>, pl_lds_bytes<3, 256>() + 4096));
 

@@ -9,6 +9,12 @@
 //
 // Geometry paths as wgrad_split_kernel: FAST 1 (OW % 32 == 0: every 32-pixel reduction tile lies in one output row, wave-uniform
 // gather state) and FAST 2 (any OW >= 16: per-row pixel coordinates as counters).  NTERMS 3 = f16x3, 1 = plane 0 only (mode 3).
+//
+// Measured and dropped (round 2): the 128 x 128 tile as ONE 8-wave block per CU with 32 x 64 outputs per wave (64 accumulator
+// registers, 120 registers per wave, LDS reservation so that a second block cannot join): half of every SIMD's register file stays
+// free and the BatchNorm kernels of the main stream do run next to it (bn_bwd_apply 17.5 -> 12.6 ms per step), but the wgrad itself
+// takes 33 instead of 20 ms on the side queue and overlaps -- and slows -- the matrix-bound dgrads (3x3 dgrad 307 -> 219 TFLOP/s):
+// 360 vs 371 tiles/s.
 #include "conv_common.h"
 
 namespace pylc {
