@@ -32,6 +32,24 @@ GFLOP_PER_TILE_ALL = 531.40
 GFLOP_PER_TILE_3X3 = 366.0
 
 
+# BASELINE.json configurations that fit this contract (one line per run; c3 is the headline the driver records)
+CONFIGS = {
+    'c2': dict(arch='unet', backbone='resnet', ch=3, batch=16, tile=512, classes=9, precision=2, losses=(1.0, 0.0, 0.0),
+               metric='512x512 tiles/sec fwd+bwd (U-Net, 9-class, CE only)', gflop_tile=673.66,
+               label='U-Net valid 3x3, 3-ch 512x512 tiles -> 324x324, 9 classes, CE only, bs=16/GPU (BASELINE.json configs[1])'),
+    'c3': dict(arch='deeplab', backbone='resnet', ch=3, batch=32, tile=512, classes=9, precision=2, losses=(0.5, 0.5, 0.5),
+               metric='512x512 tiles/sec fwd+bwd (DeepLabV3+/ResNet101, 9-class)', gflop_tile=531.40, label=None),
+    'c4': dict(arch='deeplab', backbone='resnet', ch=3, batch=32, tile=512, classes=11, precision=2, losses=(0.5, 0.5, 0.5),
+               metric='512x512 tiles/sec fwd+bwd (DeepLabV3+/ResNet101, 11-class schema_b)', gflop_tile=531.45,
+               label='DeepLabV3+ ResNet101 OS16, 3-ch 512x512 tiles, 11 classes, bs=32/GPU (BASELINE.json configs[3]: the per-GPU shard of global bs 256)'),
+    # configs[4]: Xception, grayscale 1024^2, bs 8 per GPU, 16-bit MFMA operands with fp32 accumulation and fp32 master weights (precision
+    # mode 3: activations between BatchNorm and conv as ONE fp16 plane, 2 bytes per element)
+    'c5': dict(arch='deeplab', backbone='xception', ch=1, batch=8, tile=1024, classes=11, precision=3, losses=(0.5, 0.5, 0.5),
+               metric='1024x1024 tiles/sec fwd+bwd (DeepLabV3+/Xception, 1-ch, fp16 MFMA)', gflop_tile=1984.0,
+               label='DeepLabV3+ Aligned-Xception OS16, 1-ch 1024x1024 tiles, 11 classes, bs=8/GPU, fp16 MFMA operands / fp32 accumulate (BASELINE.json configs[4], training leg)'),
+}
+
+
 def synth(rank, b, ch, hw, n_cls, dev):
     x = torch.from_numpy(np.random.RandomState(1234 + rank).randint(0, 256, (b, ch, hw, hw)).astype(np.float32)).to(dev)
     y = torch.from_numpy(np.random.RandomState(4321 + rank).randint(0, n_cls, (b, hw, hw)).astype(np.int64)).to(dev)
@@ -92,7 +110,13 @@ def main():
     ap.add_argument('--classes', type=int, default=9)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-dp-overhead', action='store_true', help='N=1: skip the extra steps that time the data-parallel code path at world size 1')
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS), help='BASELINE.json configuration (default c3 = configs[2], the headline)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.config != 'c3':
+        args.batch, args.tile, args.classes = cfg['batch'], cfg['tile'], cfg['classes']
+        os.environ.setdefault('PYLC_CONV_PRECISION', str(cfg['precision']))
 
     import pylc_amd
     from pylc_amd import parallel, ops
@@ -101,11 +125,13 @@ def main():
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', torch.cuda.current_device())
     torch.manual_seed(0)
-    meta = Meta(arch='deeplab', backbone='resnet', ch=3, n_classes=args.classes, report=10 ** 9)
+    w_ce, w_dice, w_focal = cfg['losses']
+    meta = Meta(arch=cfg['arch'], backbone=cfg['backbone'], ch=cfg['ch'], n_classes=args.classes, report=10 ** 9,
+                ce_weight=w_ce, dice_weight=w_dice, focal_weight=w_focal)
     model = Model(meta, dev).build()
     if world > 1:
         parallel.broadcast_parameters(model.arena)
-    x, y = synth(rank, args.batch, 3, args.tile, args.classes, dev)
+    x, y = synth(rank, args.batch, cfg['ch'], args.tile, args.classes, dev)
 
     # Settle (untimed, before the W warm-up steps): a process started right after another GPU job may see that job's
     # memory teardown for a few seconds (measured: back-to-back launches lose up to 35 % for some runs, 3 s apart none).
@@ -140,6 +166,7 @@ def main():
         timer = ops.KernelTimer()
         ops.set_kernel_timer(timer)
     mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0)
+    pylc_amd.runtime.collectives = 0
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -150,6 +177,29 @@ def main():
     dt = time.perf_counter() - t0
     mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0) - mallocs
     ops.set_kernel_timer(None)
+    range_passes, conversions = ops.amax_passes[0] / args.steps, ops.plane_conversions[0] / args.steps
+    n_buckets = len(model._bucketer.buckets) if model._bucketer is not None else 0
+    collectives = pylc_amd.runtime.collectives / args.steps + n_buckets if world > 1 else 0.0
+    # N = 1: what the data-parallel code path costs before any fabric is involved -- the same model, a one-rank RCCL group switched on
+    # (SyncBN + loss collectives, their stream hops, the bucketed gradient all-reduce), a few more steps
+    dp_overhead = dp_collectives = None
+    if world == 1 and not args.no_dp_overhead and not torch.distributed.is_initialized():
+        try:
+            parallel.init_single_rank_group()
+            for _ in range(3):
+                model.train(x, y)
+            pylc_amd.runtime.collectives = 0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_dp = max(3, args.steps // 2)
+            for _ in range(n_dp):
+                model.train(x, y)
+            torch.cuda.synchronize()
+            dp_overhead = (time.perf_counter() - t1) / n_dp / (dt / args.steps) - 1.0
+            dp_collectives = pylc_amd.runtime.collectives / n_dp + len(model._bucketer.buckets)
+        except Exception as e:          # no RCCL on this box: report that rather than fail the benchmark
+            dp_overhead = 'unavailable: %s' % str(e)[:80]
+        pylc_amd.runtime.sync_group = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -163,25 +213,33 @@ def main():
     tiles = args.batch * world * args.steps
     value = tiles / dt
     out = {
-        'metric': '512x512 tiles/sec fwd+bwd (DeepLabV3+/ResNet101, 9-class)',
+        'metric': cfg['metric'],
         'value': value, 'unit': 'tiles/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'DeepLabV3+ ResNet101 OS16, 3-ch %dx%d tiles, %d classes, CE+Dice+Focal, clip 0.5 + AdamW, '
-                               'bs=%d/GPU (BASELINE.json configs[2])' % (args.tile, args.tile, args.classes, args.batch),
+        'dtype': 'f16' if pylc_amd.lib.lib.pylc_get_conv_precision() == 3 else 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg['label'] or ('DeepLabV3+ ResNet101 OS16, 3-ch %dx%d tiles, %d classes, CE+Dice+Focal, clip 0.5 + AdamW, '
+                                                'bs=%d/GPU (BASELINE.json configs[2])' % (args.tile, args.tile, args.classes, args.batch)),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                   'net_tflops_algorithmic': value * GFLOP_PER_TILE_ALL / 1e3 / world,
-                   'conv_arithmetic': {0: 'f32 MFMA', 1: 'bf16x6 split', 2: 'f16x3 split'}[pylc_amd.lib.lib.pylc_get_conv_precision()],
-                   'standalone_range_passes_per_step': ops.amax_passes[0] / args.steps,
+                   'net_tflops_algorithmic': value * cfg['gflop_tile'] / 1e3 / world,
+                   'conv_arithmetic': {0: 'f32 MFMA', 1: 'bf16x6 split', 2: 'f16x3 split (fp32-grade)',
+                                       3: 'fp16 operands (one plane, 2 B/element), fp32 accumulation, fp32 master weights'}[pylc_amd.lib.lib.pylc_get_conv_precision()],
+                   # data-parallel diagnostics (so that a scaling run is checkable): ranks on RCCL, collectives issued per step and rank
+                   # (SyncBN forward + backward per BatchNorm layer, loss statistics, gradient buckets), and at N = 1 the cost of that
+                   # code path at world size 1
+                   'rccl_ranks': world if (world > 1 and torch.distributed.is_available()) else 0,
+                   'sync_bn': bool(pylc_amd.runtime.sync_bn),
+                   'collectives_per_step': collectives if world > 1 else dp_collectives,
+                   'dp_codepath_overhead': dp_overhead,
+                   'standalone_range_passes_per_step': range_passes,
                    'activation_format': 'fp32' if pylc_amd.runtime.no_planes else 'fp16 planes between BatchNorm and conv kernels (4 B/element)',
-                   'planes_to_fp32_conversions_per_step': ops.plane_conversions[0] / args.steps,
+                   'planes_to_fp32_conversions_per_step': conversions,
                    'hipmalloc_calls_in_timed_region': mallocs,      # 0 in steady state (diagnostic: see DESIGN.md section 5.2, open observation)
                    'last_loss': [float(v) for v in losses[-1]] if losses else None},
     }
     if timer is not None:
         out['roofline'] = timer.roofline(PEAK_BF16_MFMA_TFLOPS)
         out['roofline']['traffic'] = pmc_traffic(out['roofline']['kernel'])
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == 'c3':
         out['cpu_baseline'] = cpu_baseline(args.tile, args.classes)
     print(json.dumps(out), flush=True)
     del model, x, y

@@ -330,6 +330,11 @@ int pylc_colourize_resize(const unsigned char* mask, int h, int w, const unsigne
 int pylc_confusion_matrix(const void* y_true, int true_bytes, const void* y_pred, int pred_bytes, long long n, int C,
                           int force_coverage, unsigned long long* cm, void* stream);
 
+/* The general form: ((x - mean[c]) / std[c]) / denom on float (is_u8 = 0) or uint8 (is_u8 = 1) tiles.  denom = 255 is
+ * pylc_image_pack[_u8]; denom = 1 is the reference's grayscale `default=True` branch, which omits the division by 255
+ * (models/model.py:428-430). */
+int pylc_image_pack_denom(const void* img_nchw, int is_u8, int B, int Cimg, int H, int W, const float* mean3, const float* std3,
+                          float denom, float* out_nhwc4, void* stream);
 /* pylc_image_pack for uint8 tiles (the dtype the HDF5 database stores, db/database.py:218-233; db/buffer.py:62 converts to
  * float32 on the host): the H2D copy carries 1 byte per sample instead of 4. */
 int pylc_image_pack_u8(const unsigned char* img_nchw, int B, int Cimg, int H, int W, const float* mean3,

@@ -8,3 +8,4 @@ the package without the built library fails loudly -- there is no CPU / eager fa
 from . import lib  # noqa: F401  (raises if libpylc_hip.so is missing)
 from .runtime import runtime  # noqa: F401
 from .nets import DeepLab, UNet  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.pylc_hip.*)

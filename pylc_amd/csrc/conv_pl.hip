@@ -463,7 +463,7 @@ constexpr int plh_lds_bytes() { return 2 * plh_halo_bytes<NTERMS>() + 3 * plh_bs
 
 template <int NTERMS>
 __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) {
-    constexpr int BM = 256, BN = PL_BN, WM = 64, WN = 64, AT = 4, ROW = PL_ROW;
+    constexpr int BM = 256, BN = PL_BN, WN = 64, AT = 4, ROW = PL_ROW;
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
     constexpr int HALO = plh_halo_bytes<NTERMS>(), HPL = PLH_HROWS * ROW;          // one halo buffer / one plane of it
     constexpr int BST = plh_bstage_bytes<NTERMS>();

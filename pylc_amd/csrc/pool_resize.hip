@@ -216,7 +216,8 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__
 }
 
 // ---- image ingest / layout ---------------------------------------------------------------------
-__global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg, int HW, f32x4 mean, f32x4 istd, float* __restrict__ out) {
+__global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg, int HW, f32x4 mean, f32x4 istd, float* __restrict__ out,
+                                  float denom) {
     const long long total = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / HW, p = i % HW;
@@ -228,9 +229,9 @@ __global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg
         v.w = 0.f;
         // ((x - mean) / std) / 255, evaluated in the reference's operation order (model.py:444-445)
         f32x4 r;
-        r.x = ((v.x - mean.x) / istd.x) / 255.f;
-        r.y = ((v.y - mean.y) / istd.y) / 255.f;
-        r.z = ((v.z - mean.z) / istd.z) / 255.f;
+        r.x = ((v.x - mean.x) / istd.x) / denom;          // denom = 255; 1 for the grayscale defaults branch (model.py:428-430)
+        r.y = ((v.y - mean.y) / istd.y) / denom;
+        r.z = ((v.z - mean.z) / istd.z) / denom;
         r.w = 0.f;
         st4(out + 4 * i, r);
     }
@@ -238,7 +239,7 @@ __global__ void image_pack_kernel(const float* __restrict__ img, int B, int Cimg
 
 // same as image_pack_kernel for uint8 tiles as stored in the HDF5 database (db/database.py:218-233): 4x fewer PCIe bytes
 __global__ void image_pack_u8_kernel(const unsigned char* __restrict__ img, int B, int Cimg, int HW, f32x4 mean, f32x4 sd,
-                                     float* __restrict__ out) {
+                                     float* __restrict__ out, float denom) {
     const long long total = (long long)B * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / HW, p = i % HW;
@@ -247,9 +248,9 @@ __global__ void image_pack_u8_kernel(const unsigned char* __restrict__ img, int 
         const float y = Cimg == 3 ? (float)src[HW] : x;
         const float z = Cimg == 3 ? (float)src[2 * (long long)HW] : x;
         f32x4 r;
-        r.x = ((x - mean.x) / sd.x) / 255.f;
-        r.y = ((y - mean.y) / sd.y) / 255.f;
-        r.z = ((z - mean.z) / sd.z) / 255.f;
+        r.x = ((x - mean.x) / sd.x) / denom;
+        r.y = ((y - mean.y) / sd.y) / denom;
+        r.z = ((z - mean.z) / sd.z) / denom;
         r.w = 0.f;
         st4(out + 4 * i, r);
     }
@@ -360,21 +361,27 @@ extern "C" int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, vo
     return PYLC_OK;
 }
 
-extern "C" int pylc_image_pack(const float* img, int B, int Cimg, int H, int W, const float* mean3, const float* std3, float* out, void* stream) {
-    PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3), "image_pack: bad arguments");
+extern "C" int pylc_image_pack_denom(const void* img, int is_u8, int B, int Cimg, int H, int W, const float* mean3, const float* std3,
+                                     float denom, float* out, void* stream) {
+    PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3) && denom > 0.f, "image_pack: bad arguments");
     f32x4 mean = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
-    hipLaunchKernelGGL(image_pack_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream), img, B, Cimg, H * W, mean, sd, out);
+    if (is_u8)
+        hipLaunchKernelGGL(image_pack_u8_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream),
+                           static_cast<const unsigned char*>(img), B, Cimg, H * W, mean, sd, out, denom);
+    else
+        hipLaunchKernelGGL(image_pack_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream),
+                           static_cast<const float*>(img), B, Cimg, H * W, mean, sd, out, denom);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
 
+extern "C" int pylc_image_pack(const float* img, int B, int Cimg, int H, int W, const float* mean3, const float* std3, float* out, void* stream) {
+    return pylc_image_pack_denom(img, 0, B, Cimg, H, W, mean3, std3, 255.f, out, stream);
+}
+
 extern "C" int pylc_image_pack_u8(const unsigned char* img, int B, int Cimg, int H, int W, const float* mean3, const float* std3, float* out,
                                   void* stream) {
-    PYLC_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && (Cimg == 1 || Cimg == 3), "image_pack_u8: bad arguments");
-    f32x4 mean = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
-    hipLaunchKernelGGL(image_pack_u8_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, as_stream(stream), img, B, Cimg, H * W, mean, sd, out);
-    PYLC_LAUNCH_CHECK();
-    return PYLC_OK;
+    return pylc_image_pack_denom(img, 1, B, Cimg, H, W, mean3, std3, 255.f, out, stream);
 }
 
 extern "C" int pylc_nhwc_to_nchw(const float* x, int x_pitch, float* y, int B, int H, int W, int C, void* stream) {

@@ -11,9 +11,40 @@ size (utils/tools.py:77-206); callers pass the fitted image."""
 import ctypes as C
 
 import torch
+import torch.distributed as dist
 
 from . import ops, lib as L
 from .lib import lib, check, ptr, stream
+from .runtime import runtime
+
+
+# ---- multi-GPU inference: replicas, no data-path collective except the final gather (SURVEY.md section 8e "Inference") ------------
+def shard_batches(n_tiles, batch, rank, world):
+    """Tile batches of one image dealt round-robin over the ranks (test.py:69-84 walks them serially): the (first tile, count)
+    pairs this rank runs, in order."""
+    starts = list(range(0, n_tiles, batch))
+    return [(k, min(batch, n_tiles - k)) for i, k in enumerate(starts) if i % world == rank]
+
+
+def gather_tiles(local, n_tiles, batch, group, dst=0):
+    """Collect the per-rank logit tiles on rank `dst`.  local: [n_local_tiles, ...] in the order of shard_batches().  Every rank
+    contributes one equally sized slab (the collective needs equal shapes: short shards are zero-padded), rank dst puts the tiles
+    back into image order.  Returns [n_tiles, ...] on dst, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [sum(c for _, c in shard_batches(n_tiles, batch, r, world)) for r in range(world)]
+    slab = local.new_zeros((max(counts),) + tuple(local.shape[1:]))
+    slab[:local.shape[0]] = local
+    parts = [torch.empty_like(slab) for _ in range(world)] if rank == dst else None
+    dist.gather(slab, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = local.new_empty((n_tiles,) + tuple(local.shape[1:]))
+    for r in range(world):
+        pos = 0
+        for k, c in shard_batches(n_tiles, batch, r, world):
+            out[k:k + c] = parts[r][pos:pos + c]
+            pos += c
+    return out
 
 
 def tile_grid(h, w, tile, stride):
@@ -22,8 +53,12 @@ def tile_grid(h, w, tile, stride):
     return (h - tile) // stride + 1, (w - tile) // stride + 1
 
 
-def predict_image(model, image, tile=512, stride=None, batch=8):
-    """image: [C,H,W] raw 0..255 float tensor (host or device), fitted.  Returns the uint8 class mask [H,W] (device)."""
+def predict_image(model, image, tile=512, stride=None, batch=8, group=None):
+    """image: [C,H,W] raw 0..255 float tensor (host or device), fitted.  Returns the uint8 class mask [H,W] (device).
+
+    With a process group (default: runtime.sync_group, i.e. the data-parallel job this process belongs to) the tile batches are dealt
+    round-robin over the ranks -- every rank holds the image and a replica of the model -- and the logit tiles are gathered to rank 0,
+    which stitches; the other ranks return None."""
     L.init()
     stride = tile // 2 if stride is None else stride          # test.py:63
     dev = model.device
@@ -33,25 +68,36 @@ def predict_image(model, image, tile=512, stride=None, batch=8):
         raise ValueError('model expects %d-channel images' % model.meta.ch)
     rows, cols = tile_grid(h, w, tile, stride)
     n = rows * cols
-    mean, std = model._stats(model.meta.normalize_default)
+    mean, std, denom = model._stats(model.meta.normalize_default)
+    if denom != 255.0:                  # the tile cutter divides by 255: fold the grayscale-defaults branch's missing division into std
+        std = [v * denom / 255.0 for v in std]
+    group = group if group is not None else runtime.sync_group
+    world = dist.get_world_size(group) if group is not None else 1
+    rank = dist.get_rank(group) if group is not None else 0
+    mine = shard_batches(n, batch, rank, world)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(v) for v in std])
     ncls = model.meta.n_classes
     cp = (ncls + 3) & ~3
-    logits = torch.empty((n, tile, tile, cp), device=dev)
+    logits = torch.empty((sum(c for _, c in mine), tile, tile, cp), device=dev)
     was_training = model.net.training
     model.net.eval()
     with torch.no_grad():
-        for k in range(0, n, batch):
-            b = min(batch, n - k)
+        pos = 0
+        for k, b in mine:
             x4 = ops.empty_nhwc(b, 4, tile, tile, dev)
             check(lib.pylc_image_pack_tiles(ptr(img), cimg, h, w, tile, stride, k, b, m, s, ptr(x4), stream()))
             y = model.net(x4)                                  # [b, ncls, tile', tile'] NHWC memory, pitch cp
             if y.shape[2] != tile or y.shape[3] != tile:
                 raise ValueError('sliding-window stitching needs a same-size network (DeepLab); got %s' % (tuple(y.shape),))
-            logits[k:k + b].copy_(torch.as_strided(y, (b, tile, tile, cp), (tile * tile * ops.pitch_of(y), tile * ops.pitch_of(y), ops.pitch_of(y), 1),
-                                                   y.storage_offset()))
+            logits[pos:pos + b].copy_(torch.as_strided(y, (b, tile, tile, cp), (tile * tile * ops.pitch_of(y), tile * ops.pitch_of(y), ops.pitch_of(y), 1),
+                                                       y.storage_offset()))
+            pos += b
     model.net.train(was_training)
+    if world > 1:
+        logits = gather_tiles(logits, n, batch, group)
+        if logits is None:
+            return None
     mask = torch.empty((rows * stride + tile - stride, cols * stride + tile - stride), device=dev, dtype=torch.uint8)
     check(lib.pylc_stitch_argmax(ptr(logits), cp, rows, cols, tile, stride, ncls, ptr(mask), stream()))
     return mask

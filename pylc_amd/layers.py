@@ -37,7 +37,7 @@ class Conv2d(nn.Module):
 
     def takes_planes(self):
         """Static part of ops.conv_takes_planes: a BatchNorm that feeds ONLY convs for which this holds may write fp16 planes."""
-        return self.cout % 4 == 0 and self.cin % 8 == 0
+        return self.cout % 4 == 0 and self.cin % 8 == 0 and self.bias is None
 
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,
@@ -80,7 +80,7 @@ class BatchNorm2d(nn.Module):
         if self.training:
             self._nbt_pending += 1          # no per-layer device add: 113 tiny launches per step otherwise
         return ops.bn_act(y, self.weight, self.bias, self.running_mean, self.running_var, residual, relu,
-                          self.training, self.eps, self.momentum, runtime.sync_group if self.training else None,
+                          self.training, self.eps, self.momentum, runtime.sync_group if (self.training and runtime.sync_bn) else None,
                           runtime.bn_clamp_eps, res_link, out_planes, drop.spec() if drop is not None else None)
 
     def flush_counter(self):

@@ -110,6 +110,7 @@ SIGNATURES = {
     'pylc_image_pack_tiles': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     'pylc_stitch_argmax': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'pylc_colourize_resize': (_I, [_P, _I, _I, _P, _P, _I, _I, _P]),
+    'pylc_image_pack_denom': (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _P, _P]),
     'pylc_image_pack_u8': (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     'pylc_confusion_matrix': (_I, [_P, _I, _P, _I, _LL, _I, _I, _P, _P]),
     'pylc_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),

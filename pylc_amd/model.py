@@ -149,14 +149,14 @@ class Model:
     def _stats(self, default=False):
         m = self.meta
         if m.ch == 1:
-            if default:
-                raise NotImplementedError('normalize_default for grayscale omits the /255 (model.py:431-432); not built')
+            if default:        # model.py:428-430: (img - px_grayscale_mean) / px_grayscale_std, WITHOUT the division by 255 (reference quirk)
+                return [float(m.px_grayscale_mean)] * 3, [float(m.px_grayscale_std)] * 3, 1.0
             mean = float(np.mean(np.asarray(m.px_mean, np.float32)))
             std = float(np.mean(np.asarray(m.px_std, np.float32)))
-            return [mean] * 3, [std] * 3
+            return [mean] * 3, [std] * 3, 255.0
         if default:
-            return [132.47, 144.47, 149.45], [24.85, 22.04, 18.77]
-        return list(m.px_mean), list(m.px_std)
+            return [132.47, 144.47, 149.45], [24.85, 22.04, 18.77], 255.0
+        return list(m.px_mean), list(m.px_std), 255.0
 
     def pack_input(self, x, default=False):
         """raw [B,ch,H,W] 0..255 (host or device) -> normalised NHWC4 device tensor."""
@@ -165,8 +165,8 @@ class Model:
         if x.dtype != torch.uint8:
             x = x.to(dtype=torch.float32)
         x = x.to(self.device, non_blocking=True)
-        mean, std = self._stats(default)
-        return ops.image_pack(x, mean, std)
+        mean, std, denom = self._stats(default)
+        return ops.image_pack(x, mean, std, denom)
 
     def crop_target(self, y):
         if self.meta.arch == 'unet':
@@ -186,7 +186,8 @@ class Model:
         self.optim.zero_grad()
         if runtime.sync_group is not None:
             if self._bucketer is None:
-                from .parallel import GradBucketer
+                from .parallel import GradBucketer, assert_equal_shards
+                assert_equal_shards(x.shape[0], runtime.sync_group)       # n_global = n_local * world everywhere (SyncBN, loss head)
                 self._bucketer = GradBucketer(self.arena, runtime.grad_group)
             self._bucketer.reset()
             runtime.grad_ready = self._bucketer.ready

@@ -86,8 +86,25 @@ class DeepLab(nn.Module):
         self.in_channels = in_channels
         self.n_classes = n_classes
         if pretrained:
-            raise ValueError('pretrained=True needs ./data/models/resnet101-5d3b4d8f.pth (resnet.py:149-158); '
-                             'load it with load_state_dict(strict=False) on .backbone instead')
+            self.load_pretrained_backbone()
+
+    PRETRAINED_PATH = './data/models/resnet101-5d3b4d8f.pth'       # config.py:188 `defaults.pretrained`
+
+    def load_pretrained_backbone(self, path=None):
+        """resnet.py:149-158 (`_load_pretrained_model`): read the torchvision ResNet-101 ImageNet state dict and copy every entry whose key
+        the backbone also has; entries it does not have (fc.*) are ignored, backbone tensors the file lacks keep their initialisation.
+        Like the reference, a missing file is an error (torch.load raises).  Only the ResNet backbone has a pretrained path (the
+        Xception branch, xception.py:247-283, points at a URL the reference never downloads)."""
+        import torch
+        if not isinstance(self.backbone, ResNet101):
+            raise ValueError('pretrained weights exist for the resnet backbone only')
+        path = path or self.PRETRAINED_PATH
+        pretrain = torch.load(path, map_location='cpu', weights_only=True)
+        own = self.backbone.state_dict()
+        picked = {k: v for k, v in pretrain.items() if k in own}
+        own.update(picked)
+        self.backbone.load_state_dict(own)
+        return sorted(picked)
 
     def forward(self, x):
         """x: normalised fp32 [B,3,H,W] (any layout), or the 4-channel NHWC pack made by ops.image_pack.

@@ -20,7 +20,8 @@ class SeparableConv2d(nn.Module):
         self.pointwise = Conv2d(cin, cout, 1, bn=True)         # every SeparableConv2d is followed by a BatchNorm (Block / bn3-5)
 
     def forward(self, x):
-        return self.pointwise(self.bn(self.conv1(x)))
+        # the inner BatchNorm feeds the pointwise conv only: it writes the conv's operand format (fp16 planes) directly
+        return self.pointwise(self.bn(self.conv1(x), out_planes=self.pointwise.takes_planes()))
 
 
 class Block(nn.Module):

@@ -24,13 +24,42 @@ class UNetConvBlock(nn.Module):
         return self.drop(x)
 
 
-class UNetUpBlock(nn.Module):
-    def __init__(self, cin, cout, padding, dropout):
+class UpConv2x2(nn.Module):
+    """nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2) (unet.py:132-133, up_mode='upconv'): every input pixel becomes a 2x2 output
+    block, y[b, o, 2i+r, 2j+s] = sum_c x[b, c, i, j] W[c, o, r, s] + bias[o].  That is the data gradient of a 2x2 / stride-2 conv with
+    the same weight tensor ([cin, cout, 2, 2] = that conv's [Cout, Cin, kh, kw]), so the forward runs pylc_conv2d_dgrad (one launch per
+    output parity class), the input gradient pylc_conv2d_fwd and the weight gradient pylc_conv2d_wgrad (ops.ConvTranspose2x2Fn).
+    state_dict keys as the reference's: up.weight [cin, cout, 2, 2], up.bias [cout]."""
+
+    def __init__(self, cin, cout):
         super().__init__()
-        self.up = Named(_1=Conv2d(cin, cout, 1, bias=True, init='torch'))
+        bound = 1.0 / (cout * 4) ** 0.5             # torch's ConvTranspose2d default init: fan_in = weight.size(1) * kh * kw
+        self.weight = nn.Parameter(torch.empty(cin, 2, 2, cout).uniform_(-bound, bound).permute(0, 3, 1, 2))     # KRSC memory
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self.cout = cout
+
+    def forward(self, x):
+        return ops.conv_transpose2x2(x, self.weight, self.bias)
+
+
+class UNetUpBlock(nn.Module):
+    def __init__(self, cin, cout, padding, dropout, up_mode='upsample'):
+        super().__init__()
+        self.up_mode = up_mode
+        if up_mode == 'upconv':
+            self.up = UpConv2x2(cin, cout)
+        else:
+            self.up = Named(_1=Conv2d(cin, cout, 1, bias=True, init='torch'))
         self.conv_block = UNetConvBlock(cin, cout, padding, dropout)
 
     def forward(self, x, bridge):
+        if self.up_mode == 'upconv':
+            # unet.py:145-152 with the transposed conv: its output and the centre crop of the bridge are concatenated (ops.cat_channels
+            # carries the ranges; the slice write of the 'upsample' path needs a conv that writes into a buffer, which dgrad does not)
+            up = self.up(x)
+            th, tw = up.shape[2:]
+            h0, w0 = (bridge.shape[2] - th) // 2, (bridge.shape[3] - tw) // 2
+            return self.conv_block(ops.cat_channels((up, ops.as_nhwc(bridge)[:, :, h0:h0 + th, w0:w0 + tw])))
         # unet.py:145-152: cat([up, center_crop(bridge)], 1).  The 1x1 conv writes `up` straight into the concat buffer, the
         # crop is copied behind it, and the crop's gradient is summed by the max-pool backward of the same skip tensor
         b, _, h, w = x.shape
@@ -44,8 +73,8 @@ class UNet(nn.Module):
     def __init__(self, in_channels=1, n_classes=2, depth=5, wf=6, padding=False, up_mode='upsample', dropout=None,
                  activ_func=None, normalizer=None):
         super().__init__()
-        if up_mode != 'upsample':
-            raise ValueError("only up_mode='upsample' (the reference default, config.py:231) is built")
+        if up_mode not in ('upsample', 'upconv'):
+            raise ValueError("up_mode must be 'upsample' (the reference default, config.py:231) or 'upconv' (unet.py:132-138)")
         self.depth = depth
         self.in_channels = in_channels
         prev = in_channels
@@ -55,7 +84,7 @@ class UNet(nn.Module):
             prev = 2 ** (wf + i)
         self.decoder = nn.ModuleList()
         for i in reversed(range(depth - 1)):
-            self.decoder.append(UNetUpBlock(prev, 2 ** (wf + i), padding, dropout))
+            self.decoder.append(UNetUpBlock(prev, 2 ** (wf + i), padding, dropout, up_mode))
             prev = 2 ** (wf + i)
         self.last = Conv2d(prev, n_classes, 1, bias=True, init='torch')
 

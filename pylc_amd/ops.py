@@ -485,7 +485,9 @@ class Conv2dFn(torch.autograd.Function):
             res_link.pending += 1
         cout, cin_w, r, s = w.shape
         b_, _, h_, w_ = x.shape
-        takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None
+        # (a conv with a bias keeps fp32 operands: its bias gradient is a column sum of dy, which wants fp32 -- only the U-Net's convs
+        # and the class heads carry one)
+        takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None and bias is None
         if takes and not is_planes(x) and convert:
             # (convert: training graphs only -- grad mode as seen by ops.conv2d; inference keeps fp32 operands and the kernels the
             # fused conv + BatchNorm epilogue path runs)
@@ -701,6 +703,83 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=N
     if fn is not None and getattr(fn, 'dy_pl_ok', False):
         y._pylc_dy_pl = True          # the BatchNorm that consumes y (its ONLY consumer, layers.conv_bn) may hand dy back as fp16 planes
     return y
+
+
+class ConvTranspose2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(cin, cout, 2, stride=2) on the conv kernels: forward = the data gradient of the 2x2 / stride-2 conv whose
+    weight is the same tensor ([cin, cout, 2, 2] read as [Cout', Cin', kh, kw]); backward: dx = that conv's forward on dy, dw = its
+    weight gradient (x in the role of dy).  Bias added / reduced by the BatchNorm row-slab kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        L.init()
+        x = as_nhwc(x)
+        b, cin, h, wd = x.shape
+        if tuple(w.shape[:1] + w.shape[2:]) != (cin, 2, 2) or not w.permute(0, 2, 3, 1).is_contiguous() or cin % 4 or w.shape[1] % 4:
+            raise L.PylcError('conv_transpose2x2: weight must be [Cin, Cout, 2, 2] with KRSC memory, channels multiples of 4')
+        cout = w.shape[1]
+        # the "forward conv" this is the dgrad of: input [B, cout, 2h, 2w] -> output [B, cin, h, w], 2x2 stride 2
+        y = empty_nhwc(b, cout, 2 * h, 2 * wd, x.device)
+        d = _conv_desc(y, cout, cin, 2, 2, 2, 0, 1, cout, pitch_of(x))
+        xa = wa = None
+        if ranges_needed():
+            xa, wa = amax_of(x), weight_amax(w)
+            d.dy_amax, d.w_amax = ptr(xa), ptr(wa)
+        wt = torch.empty((cout, 4, cin), device=x.device, dtype=torch.float32)
+        st = stream()
+        check(lib.pylc_weight_transpose(ptr(w), ptr(wt), cin, 4, cout, st))
+        check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(x), ptr(wt), ptr(y), 0, st))
+        if bias is not None:
+            one = torch.ones(cout, device=x.device)
+            m = b * 4 * h * wd
+            check(lib.pylc_bn_apply(ptr(y), cout, ptr(one), ptr(bias), None, 0, ptr(y), cout, m, cout, 0, None, st))       # y*1 + bias, in place
+        ctx.save_for_backward(x, w)
+        ctx.ranges = (xa, wa)
+        ctx.has_bias = bias is not None
+        ctx.b_param = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = as_nhwc(dy)
+        b, cin, h, wd = x.shape
+        cout = w.shape[1]
+        st = stream()
+        d = _conv_desc(dy, cout, cin, 2, 2, 2, 0, 1, pitch_of(dy), cin)
+        xa, wa = ctx.ranges
+        dya = None
+        if ranges_needed():
+            dya = amax_of(dy)
+            d.x_amax, d.w_amax, d.dy_amax = ptr(dya), ptr(wa), ptr(xa)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(b, cin, h, wd, x.device)
+            check(lib.pylc_conv2d_fwd(C.byref(d), ptr(dy), ptr(w), None, ptr(dx), st))
+        if ctx.needs_input_grad[1]:
+            d.y_pitch = pitch_of(x)
+            nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
+            ws = _ws(nbytes, x.device)
+            tgt = _grad_target(w)
+            dw = tgt if tgt is not None else torch.empty((cin, 2, 2, cout), device=x.device).permute(0, 3, 1, 2)
+            check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(dy), ptr(x), ptr(dw), None, ptr(ws), nbytes, st))
+            dw = _deliver_grad(w, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            m = dy.shape[0] * dy.shape[2] * dy.shape[3]
+            sums = torch.empty(2 * cout, device=x.device)
+            wsb = torch.empty(lib.pylc_bn_workspace_floats(m, cout), device=x.device)
+            check(lib.pylc_bn_stats(ptr(dy), m, cout, pitch_of(dy), ptr(sums), ptr(wsb), st))
+            tgt = _grad_target(ctx.b_param)
+            if tgt is not None:
+                tgt.copy_(sums[:cout])
+                db = _deliver_grad(ctx.b_param, tgt)
+            else:
+                db = sums[:cout].clone()
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, w, bias=None):
+    return ConvTranspose2x2Fn.apply(x, w, bias)
 
 
 def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False):
@@ -1241,18 +1320,17 @@ def global_avg_pool(x):
 # ----------------------------------------------------------------------------------------------
 # image ingest
 # ----------------------------------------------------------------------------------------------
-def image_pack(img, mean3, std3):
-    """Raw [B,1|3,H,W] 0..255 tiles -> normalised NHWC4 network input (Model.normalize_image + x3 stack)."""
+def image_pack(img, mean3, std3, denom=255.0):
+    """Raw [B,1|3,H,W] 0..255 tiles -> normalised NHWC4 network input (Model.normalize_image + x3 stack): ((x - mean) / std) / denom."""
     L.init()
     b, c, h, w = img.shape
     img = img.contiguous()
     out = empty_nhwc(b, 4, h, w, img.device)
     m = (C.c_float * 3)(*[float(v) for v in mean3])
     s = (C.c_float * 3)(*[float(v) for v in std3])
-    if img.dtype == torch.uint8:          # tiles as stored in the database: normalise straight from bytes
-        check(lib.pylc_image_pack_u8(ptr(img), b, c, h, w, m, s, ptr(out), stream()))
-    else:
-        check(lib.pylc_image_pack(ptr(img.float()), b, c, h, w, m, s, ptr(out), stream()))
+    u8 = img.dtype == torch.uint8          # tiles as stored in the database: normalise straight from bytes
+    src = img if u8 else img.float()
+    check(lib.pylc_image_pack_denom(ptr(src), int(u8), b, c, h, w, m, s, float(denom), ptr(out), stream()))
     return out
 
 

@@ -145,6 +145,33 @@ def broadcast_parameters(arena, group=None, src=0):
     arena.refresh_ranges()          # parameter ranges and prepared conv filters follow the new values
 
 
+def assert_equal_shards(local_batch, group):
+    """The SyncBN / loss-head exchanges take the global count as local count x world size (ops.BnActFn, ops.MultiLossFn): every rank
+    must hold the same number of tiles (a drop_last loader).  Checked once, when the data-parallel step is first set up."""
+    world = dist.get_world_size(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    mine = torch.tensor([int(local_batch)], dtype=torch.int64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    sizes = [int(t.item()) for t in every]
+    if len(set(sizes)) != 1:
+        raise RuntimeError('data-parallel ranks hold different batch sizes %s: SyncBN and the loss head need equal shards' % sizes)
+
+
+def init_single_rank_group():
+    """A one-rank RCCL process group in THIS process (bench.py: what the data-parallel code path -- SyncBN and loss collectives, stream
+    hops, bucketed all-reduce -- costs at world size 1)."""
+    if dist.is_initialized():
+        return
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29537')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.cuda.current_device()
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', dev))
+    runtime.sync_group = dist.group.WORLD
+    runtime.grad_group = dist.group.WORLD
+
+
 def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 

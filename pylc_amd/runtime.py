@@ -8,6 +8,11 @@ import os
 class _Runtime:
     def __init__(self):
         self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
+        # SyncBN on (default): every BatchNorm all-reduces [sum, sumsq, n] forward and [sum g, sum g xhat] backward, so N ranks compute
+        # exactly what one process computes at the global batch -- 2 collectives per BatchNorm layer per step, and they cannot be
+        # batched across layers (layer k+1's statistics depend on layer k's output).  PYLC_SYNC_BN=0: per-GPU statistics (what
+        # torch DDP does without SyncBatchNorm): only the loss statistics and the gradient buckets cross the fabric.
+        self.sync_bn = os.environ.get('PYLC_SYNC_BN', '1') != '0'
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)

@@ -1,0 +1,439 @@
+"""`torch.ops.pylc_hip.*`: the HIP kernels registered as PyTorch custom operators (torch.library.custom_op over the ctypes binding of
+libpylc_hip.so), each with its backward operator, an autograd formula and a fake (meta) implementation -- the operator-level boundary
+SURVEY.md section 8b asks for: `models/model.py` and the reference's modules can call `torch.ops.pylc_hip.conv2d(...)` wherever they
+call `F.conv2d` / `nn.BatchNorm2d` / `F.interpolate` / `MultiLoss.forward` today (call sites next to each operator below).
+
+The operators are the plain functional forms -- tensors in, fresh tensors out, no hidden state: they run the same kernels as
+pylc_amd.ops (whose autograd.Functions additionally carry the in-network fusions: gradient links, concat buffers, fp16-plane
+activations, flat-arena gradients) by driving those Functions' forward / backward with a stand-in context.  Importing this module
+registers them (pylc_amd/__init__.py does).
+
+    y   = torch.ops.pylc_hip.conv2d(x, w, None, 1, 1, 1)              # any layout in, NHWC-memory tensor out, differentiable
+    out = torch.ops.pylc_hip.batch_norm_act(y, g, b, rm, rv, None, True, True, 1e-5, 0.1)
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from . import lib as L
+
+
+class _Ctx:
+    """What ops.*Fn.forward / backward need from an autograd context."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = tuple(needs)
+        self._saved = ()
+
+    def save_for_backward(self, *tensors):
+        self._saved = tensors
+
+    @property
+    def saved_tensors(self):
+        return self._saved
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _or_empty(t, like):
+    return t if t is not None else like.new_empty(0)
+
+
+def _out_hw(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _fake_nhwc(like, b, c, h, w, pitch=None):
+    """Meta result with the strides the kernels produce: NHWC memory, channel pitch `pitch` (default c)."""
+    p = c if pitch is None else pitch
+    return like.new_empty_strided((b, c, h, w), (h * w * p, 1, w * p, p), dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# conv2d: nn.Conv2d at models/backbone/resnet.py:21-26,72,92; models/modules/aspp.py:18,64,67; models/decoder.py:27-38;
+# models/architectures/unet.py:78,112,116,137; models/backbone/xception.py:122,126 (groups = 1)
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::conv2d', mutates_args=())
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, padding: int, dilation: int) -> Tensor:
+    L.init()
+    ctx = _Ctx((False, False, False))
+    xa = wa = None
+    if ops.ranges_needed():
+        xa, wa = ops.amax_of(ops.as_nhwc(x)), ops.weight_amax(weight)
+    return ops.Conv2dFn.forward(ctx, x, weight, bias, stride, padding, dilation, False, xa, wa, None, None, False)
+
+
+@conv2d.register_fake
+def _(x, weight, bias, stride, padding, dilation):
+    b, _, h, w = x.shape
+    cout, _, r, s = weight.shape
+    return _fake_nhwc(x, b, cout, _out_hw(h, r, stride, padding, dilation), _out_hw(w, s, stride, padding, dilation), (cout + 3) & ~3)
+
+
+@torch.library.custom_op('pylc_hip::conv2d_backward', mutates_args=())
+def conv2d_backward(dy: Tensor, x: Tensor, weight: Tensor, stride: int, padding: int, dilation: int, has_bias: bool,
+                    need_dx: bool, need_dw: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    L.init()
+    ctx = _Ctx((need_dx, need_dw, has_bias))
+    x = ops.as_nhwc(x)
+    cout, cin_w, r, s = weight.shape
+    w_k = weight
+    if cin_w % 4 != 0:               # thin-input stem: the KRSC rows zero-padded to the 4-channel pack (as ops.Conv2dFn.forward)
+        w_k = torch.zeros((cout, r, s, x.shape[1]), device=weight.device, dtype=torch.float32)
+        w_k[..., :cin_w] = weight.detach().permute(0, 2, 3, 1)
+    ctx.save_for_backward(x, w_k)
+    ctx.geom = (stride, padding, dilation, cin_w, has_bias)
+    ctx.w_param, ctx.b_param = weight, (weight.new_empty(cout) if has_bias else None)
+    ctx.ranges = (ops.amax_of(x), ops.weight_amax(weight)) if ops.ranges_needed() else (None, None)
+    ctx.x_pl, ctx.dy_pl_ok, ctx.res_link = False, False, None
+    dx, dw, db = ops.Conv2dFn.backward(ctx, dy)[:3]
+    ops.sync_side_streams()          # the wgrad ran on the side stream: the returned tensors are consumed on this one
+    if dw is not None:
+        dw = dw.contiguous(memory_format=torch.channels_last) if dw.dim() == 4 else dw
+    return _or_empty(dx, dy), _or_empty(dw, dy), _or_empty(db, dy)
+
+
+@conv2d_backward.register_fake
+def _(dy, x, weight, stride, padding, dilation, has_bias, need_dx, need_dw):
+    return (torch.empty_like(x) if need_dx else dy.new_empty(0), torch.empty_like(weight) if need_dw else dy.new_empty(0),
+            dy.new_empty(weight.shape[0]) if has_bias else dy.new_empty(0))
+
+
+def _conv2d_setup(ctx, inputs, output):
+    x, weight, bias, stride, padding, dilation = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.cfg = (stride, padding, dilation, bias is not None)
+
+
+def _conv2d_bwd(ctx, dy):
+    x, weight = ctx.saved_tensors
+    stride, padding, dilation, has_bias = ctx.cfg
+    dx, dw, db = torch.ops.pylc_hip.conv2d_backward(dy, x, weight, stride, padding, dilation, has_bias, ctx.needs_input_grad[0],
+                                                    ctx.needs_input_grad[1])
+    return _none_if_empty(dx), _none_if_empty(dw), (_none_if_empty(db) if has_bias else None), None, None, None
+
+
+torch.library.register_autograd('pylc_hip::conv2d', _conv2d_bwd, setup_context=_conv2d_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# depthwise 3x3 with xception.py's fixed_padding folded in (models/backbone/xception.py:16-22,29-31)
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::dwconv3x3', mutates_args=())
+def dwconv3x3(x: Tensor, weight: Tensor, stride: int, dilation: int) -> Tensor:
+    return ops.DwConv3x3Fn.forward(_Ctx((False, False)), x, weight, stride, dilation)
+
+
+@dwconv3x3.register_fake
+def _(x, weight, stride, dilation):
+    b, c, h, w = x.shape
+    return _fake_nhwc(x, b, c, (h - 1) // stride + 1, (w - 1) // stride + 1)
+
+
+@torch.library.custom_op('pylc_hip::dwconv3x3_backward', mutates_args=())
+def dwconv3x3_backward(dy: Tensor, x: Tensor, weight: Tensor, stride: int, dilation: int) -> Tuple[Tensor, Tensor]:
+    ctx = _Ctx((True, True))
+    ctx.save_for_backward(ops.as_nhwc(x))
+    ctx.w_param, ctx.geom = weight, (stride, dilation)
+    dx, dw = ops.DwConv3x3Fn.backward(ctx, dy)[:2]
+    return dx, dw
+
+
+@dwconv3x3_backward.register_fake
+def _(dy, x, weight, stride, dilation):
+    return torch.empty_like(x), torch.empty_like(weight)
+
+
+def _dw_setup(ctx, inputs, output):
+    x, weight, stride, dilation = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.cfg = (stride, dilation)
+
+
+def _dw_bwd(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dw = torch.ops.pylc_hip.dwconv3x3_backward(dy, x, weight, *ctx.cfg)
+    return dx, dw, None, None
+
+
+torch.library.register_autograd('pylc_hip::dwconv3x3', _dw_bwd, setup_context=_dw_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BatchNorm2d (+ residual add, ReLU): torch.nn.BatchNorm2d selected at models/model.py:71-76, with the ReLU / `out += residual` that
+# follow it at resnet.py:36-51, aspp.py:28-31, decoder.py:42-44, xception.py:60-97.  Functional: returns (out, coefficients
+# [mean | invstd | scale | shift] for the backward operator, updated running_mean, updated running_var); bn_act_() below is the
+# nn.BatchNorm2d-style form that writes the running statistics back in place.
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::batch_norm_act', mutates_args=())
+def batch_norm_act(y: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, residual: Optional[Tensor],
+                   relu: bool, training: bool, eps: float, momentum: float) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    ctx = _Ctx((False,) * 6)
+    rm, rv = running_mean.clone(), running_var.clone()
+    out = ops.BnActFn.forward(ctx, y, gamma, beta, rm, rv, residual, relu, training, eps, momentum, None, False)
+    return out, ctx.saved_tensors[2], rm, rv
+
+
+@batch_norm_act.register_fake
+def _(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum):
+    return _fake_nhwc(y, *y.shape), y.new_empty(4 * y.shape[1]), torch.empty_like(running_mean), torch.empty_like(running_var)
+
+
+def bn_act_(y, gamma, beta, running_mean, running_var, residual=None, relu=False, training=True, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm2d semantics over the functional operator: running statistics updated in place (training mode)."""
+    out, _, rm, rv = torch.ops.pylc_hip.batch_norm_act(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum)
+    if training:
+        with torch.no_grad():
+            running_mean.copy_(rm)
+            running_var.copy_(rv)
+    return out
+
+
+@torch.library.custom_op('pylc_hip::batch_norm_act_backward', mutates_args=())
+def batch_norm_act_backward(dout: Tensor, y: Tensor, out: Tensor, coef: Tensor, gamma: Tensor, has_residual: bool, relu: bool,
+                            training: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    ctx = _Ctx((True, True, True, False, False, has_residual))
+    b, c, h, w = y.shape
+    y = ops.as_nhwc(y)
+    ctx.save_for_backward(y, ops.as_nhwc(out) if (relu and has_residual) else None, coef, None)
+    ctx.cfg = (relu, training, None, float(b * h * w), has_residual)
+    ctx.g_param, ctx.b_param = gamma, gamma
+    ctx.want_amax, ctx.out_pl, ctx.drop, ctx.dy_pl, ctx.res_link = False, False, (0.0, 0), False, None
+    res = ops.BnActFn.backward(ctx, dout)
+    dy, dgamma, dbeta, dres = res[0], res[1], res[2], res[5]
+    if dres is not None and dres.data_ptr() == dout.data_ptr():
+        dres = dres.clone()          # an operator output may not alias an input
+    return dy, dgamma, dbeta, _or_empty(dres, dout)
+
+
+@batch_norm_act_backward.register_fake
+def _(dout, y, out, coef, gamma, has_residual, relu, training):
+    return torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(gamma), (torch.empty_like(y) if has_residual else dout.new_empty(0))
+
+
+def _bn_setup(ctx, inputs, output):
+    y, gamma, beta, rm, rv, residual, relu, training, eps, momentum = inputs
+    out, coef = output[0], output[1]
+    ctx.save_for_backward(y, out, coef, gamma)
+    ctx.cfg = (residual is not None, relu, training)
+
+
+def _bn_bwd(ctx, dout, _dcoef, _drm, _drv):
+    y, out, coef, gamma = ctx.saved_tensors
+    has_res, relu, training = ctx.cfg
+    dy, dg, db, dres = torch.ops.pylc_hip.batch_norm_act_backward(dout, y, out, coef, gamma, has_res, relu, training)
+    return dy, dg, db, None, None, (_none_if_empty(dres) if has_res else None), None, None, None, None
+
+
+torch.library.register_autograd('pylc_hip::batch_norm_act', _bn_bwd, setup_context=_bn_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# pooling / resize / activation: nn.MaxPool2d resnet.py:76, F.max_pool2d unet.py:98; F.interpolate(bilinear, align_corners=True)
+# deeplab.py:38, decoder.py:46, aspp.py:79, unet.py:136; nn.AdaptiveAvgPool2d(1) aspp.py:63; nn.ReLU; nn.Dropout aspp.py:70 ...
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::relu', mutates_args=())
+def relu(x: Tensor) -> Tensor:
+    return ops.ReluFn.forward(_Ctx((True,)), x)
+
+
+@relu.register_fake
+def _(x):
+    return _fake_nhwc(x, *x.shape)
+
+
+@torch.library.custom_op('pylc_hip::relu_backward', mutates_args=())
+def relu_backward(dout: Tensor, out: Tensor) -> Tensor:
+    ctx = _Ctx((True,))
+    ctx.save_for_backward(ops.as_nhwc(out))
+    return ops.ReluFn.backward(ctx, dout)
+
+
+@relu_backward.register_fake
+def _(dout, out):
+    return torch.empty_like(out)
+
+
+torch.library.register_autograd('pylc_hip::relu', lambda ctx, d: torch.ops.pylc_hip.relu_backward(d, ctx.saved_tensors[0]),
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(output))
+
+
+@torch.library.custom_op('pylc_hip::max_pool2d', mutates_args=())
+def max_pool2d(x: Tensor, kernel: int, stride: int, padding: int) -> Tuple[Tensor, Tensor]:
+    ctx = _Ctx((True,))
+    y = ops.MaxPoolFn.forward(ctx, x, kernel, stride, padding, None)
+    return y, ctx.saved_tensors[0]
+
+
+@max_pool2d.register_fake
+def _(x, kernel, stride, padding):
+    b, c, h, w = x.shape
+    oh, ow = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    return _fake_nhwc(x, b, c, oh, ow), x.new_empty((b, oh, ow, c), dtype=torch.uint8)
+
+
+@torch.library.custom_op('pylc_hip::max_pool2d_backward', mutates_args=())
+def max_pool2d_backward(dy: Tensor, idx: Tensor, h: int, w: int, kernel: int, stride: int, padding: int) -> Tensor:
+    ctx = _Ctx((True,))
+    b, c, oh, ow = dy.shape
+    ctx.save_for_backward(idx)
+    ctx.cfg, ctx.link = (b, c, h, w, kernel, stride, padding, oh, ow), None
+    return ops.MaxPoolFn.backward(ctx, dy)[0]
+
+
+@max_pool2d_backward.register_fake
+def _(dy, idx, h, w, kernel, stride, padding):
+    return dy.new_empty((dy.shape[0], dy.shape[1], h, w))
+
+
+def _pool_setup(ctx, inputs, output):
+    x, kernel, stride, padding = inputs
+    ctx.save_for_backward(output[1])
+    ctx.cfg = (x.shape[2], x.shape[3], kernel, stride, padding)
+
+
+torch.library.register_autograd('pylc_hip::max_pool2d',
+                                lambda ctx, dy, _didx: (torch.ops.pylc_hip.max_pool2d_backward(dy, ctx.saved_tensors[0], *ctx.cfg), None, None, None),
+                                setup_context=_pool_setup)
+
+
+@torch.library.custom_op('pylc_hip::bilinear', mutates_args=())
+def bilinear(x: Tensor, out_h: int, out_w: int) -> Tensor:
+    return ops.BilinearFn.forward(_Ctx((True,)), x, out_h, out_w)
+
+
+@bilinear.register_fake
+def _(x, out_h, out_w):
+    return _fake_nhwc(x, x.shape[0], x.shape[1], out_h, out_w, (x.shape[1] + 3) & ~3)
+
+
+@torch.library.custom_op('pylc_hip::bilinear_backward', mutates_args=())
+def bilinear_backward(dy: Tensor, h: int, w: int) -> Tensor:
+    ctx = _Ctx((True,))
+    b, c, oh, ow = dy.shape
+    ctx.cfg = (b, c, h, w, oh, ow)
+    return ops.BilinearFn.backward(ctx, dy)[0]
+
+
+@bilinear_backward.register_fake
+def _(dy, h, w):
+    return dy.new_empty((dy.shape[0], dy.shape[1], h, w))
+
+
+torch.library.register_autograd('pylc_hip::bilinear',
+                                lambda ctx, dy: (torch.ops.pylc_hip.bilinear_backward(dy, *ctx.hw), None, None),
+                                setup_context=lambda ctx, inputs, output: setattr(ctx, 'hw', (inputs[0].shape[2], inputs[0].shape[3])))
+
+
+@torch.library.custom_op('pylc_hip::global_avg_pool', mutates_args=())
+def global_avg_pool(x: Tensor) -> Tensor:
+    return ops.GapFn.forward(_Ctx((True,)), x)
+
+
+@global_avg_pool.register_fake
+def _(x):
+    return _fake_nhwc(x, x.shape[0], x.shape[1], 1, 1)
+
+
+@torch.library.custom_op('pylc_hip::global_avg_pool_backward', mutates_args=())
+def global_avg_pool_backward(dy: Tensor, h: int, w: int) -> Tensor:
+    ctx = _Ctx((True,))
+    ctx.cfg = (dy.shape[0], dy.shape[1], h, w)
+    return ops.GapFn.backward(ctx, dy)
+
+
+@global_avg_pool_backward.register_fake
+def _(dy, h, w):
+    return dy.new_empty((dy.shape[0], dy.shape[1], h, w))
+
+
+torch.library.register_autograd('pylc_hip::global_avg_pool',
+                                lambda ctx, dy: torch.ops.pylc_hip.global_avg_pool_backward(dy, *ctx.hw),
+                                setup_context=lambda ctx, inputs, output: setattr(ctx, 'hw', (inputs[0].shape[2], inputs[0].shape[3])))
+
+
+@torch.library.custom_op('pylc_hip::dropout', mutates_args=())
+def dropout(x: Tensor, p: float, seed: int) -> Tensor:
+    return ops.DropoutFn.forward(_Ctx((True,)), x, p, seed)
+
+
+@dropout.register_fake
+def _(x, p, seed):
+    return _fake_nhwc(x, *x.shape)
+
+
+torch.library.register_autograd('pylc_hip::dropout',
+                                lambda ctx, dy: (torch.ops.pylc_hip.dropout(dy, *ctx.ps), None, None),       # the mask is a function of the seed
+                                setup_context=lambda ctx, inputs, output: setattr(ctx, 'ps', (inputs[1], inputs[2])))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# MultiLoss: CE + Dice + Focal in one pass (models/modules/loss.py:71-194).  Returns [total, ce, dice, focal]; total carries gradient.
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::multiloss', mutates_args=())
+def multiloss(logits: Tensor, target: Tensor, class_weights: Optional[Tensor], w_ce: float, w_dice: float, w_focal: float) -> Tuple[Tensor, Tensor]:
+    ctx = _Ctx((True,))
+    losses = ops.MultiLossFn.forward(ctx, logits, target, class_weights, w_ce, w_dice, w_focal, None)
+    return losses, ctx.saved_tensors[2]
+
+
+@multiloss.register_fake
+def _(logits, target, class_weights, w_ce, w_dice, w_focal):
+    return logits.new_empty(4), logits.new_empty(3 + 3 * logits.shape[1])
+
+
+@torch.library.custom_op('pylc_hip::multiloss_backward', mutates_args=())
+def multiloss_backward(dlosses: Tensor, logits: Tensor, target: Tensor, stats: Tensor, class_weights: Optional[Tensor], w_ce: float,
+                       w_dice: float, w_focal: float) -> Tensor:
+    ctx = _Ctx((True,))
+    b, c, h, w = logits.shape
+    ctx.save_for_backward(ops.as_nhwc(logits), target.contiguous(), stats, class_weights)
+    ctx.cfg = (float(b * h * w), w_ce, w_dice, w_focal, None)
+    return ops.MultiLossFn.backward(ctx, dlosses)[0]
+
+
+@multiloss_backward.register_fake
+def _(dlosses, logits, target, stats, class_weights, w_ce, w_dice, w_focal):
+    return torch.empty_like(logits)
+
+
+def _ml_setup(ctx, inputs, output):
+    logits, target, cw, w_ce, w_dice, w_focal = inputs
+    ctx.save_for_backward(logits, target, output[1], cw)
+    ctx.w = (w_ce, w_dice, w_focal)
+
+
+def _ml_bwd(ctx, dlosses, _dstats):
+    logits, target, stats, cw = ctx.saved_tensors
+    return torch.ops.pylc_hip.multiloss_backward(dlosses, logits, target, stats, cw, *ctx.w), None, None, None, None, None
+
+
+torch.library.register_autograd('pylc_hip::multiloss', _ml_bwd, setup_context=_ml_setup)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# input normalisation (Model.normalize_image, models/model.py:416-445, + the x3 channel stack :310-311) -> NHWC4 network input
+# ------------------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op('pylc_hip::image_pack', mutates_args=())
+def image_pack(img: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    return ops.image_pack(img, mean.tolist(), std.tolist())
+
+
+@image_pack.register_fake
+def _(img, mean, std):
+    return img.new_empty((img.shape[0], 4, img.shape[2], img.shape[3]), dtype=torch.float32)
+
+
+REGISTERED = ('conv2d', 'conv2d_backward', 'dwconv3x3', 'dwconv3x3_backward', 'batch_norm_act', 'batch_norm_act_backward', 'relu',
+              'relu_backward', 'max_pool2d', 'max_pool2d_backward', 'bilinear', 'bilinear_backward', 'global_avg_pool',
+              'global_avg_pool_backward', 'dropout', 'multiloss', 'multiloss_backward', 'image_pack')

@@ -98,6 +98,27 @@ fl = stats[2] / ng
 dice = (1 - (2 * stats[3:3 + C] + 1) / (stats[3 + C:3 + 2 * C] + stats[3 + 2 * C:] + 1)).mean()
 tot, oce, odice, ofl = oracle.multiloss(z, t)
 assert abs(ce - oce) < 1e-5 and abs(dice - odice) < 1e-5 and abs(fl - ofl) < 1e-5
+# --- 4. multi-GPU inference replicas (test.py:69-84 walks the tile batches of an image serially; here they are dealt round-robin
+#        over the ranks and the logit tiles are gathered to rank 0 in image order) -----------------------------------------------
+from pylc_amd import inference
+n_tiles, batch = 35, 8                       # a 4096x3072 image at tile 1024 / stride 512: 7 x 5 tiles, batches 8+8+8+8+3
+mine = inference.shard_batches(n_tiles, batch, rank, world)
+assert mine == ([(0, 8), (16, 8), (32, 3)] if rank == 0 else [(8, 8), (24, 8)])
+tile_of = lambda k: torch.full((4, 4, 12), float(k)) + torch.arange(12.0)          # a recognisable "logit tile"
+local = torch.stack([tile_of(k + j) for k, c in mine for j in range(c)])
+full = inference.gather_tiles(local, n_tiles, batch, runtime.sync_group)
+if rank == 0:
+    assert torch.equal(full, torch.stack([tile_of(k) for k in range(n_tiles)]))
+else:
+    assert full is None
+
+# --- 5. equal shards are asserted (n_global = n_local x world in SyncBN and the loss head) ------------------------------------------
+parallel.assert_equal_shards(4, runtime.sync_group)
+try:
+    parallel.assert_equal_shards(4 + rank, runtime.sync_group)
+    raise SystemExit('unequal shards were accepted')
+except RuntimeError as e:
+    assert 'equal shards' in str(e)
 parallel.barrier()
 if rank == 0:
     print('DIST_OK')

@@ -167,3 +167,58 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     best = str(tmp_path / 'best.pth')
     ck.save(m, best, best=True)
     assert sorted(ck.load_reference_file(best)) == ['meta', 'model', 'optim']
+
+
+def test_custom_ops_are_registered():
+    """torch.ops.pylc_hip.* exist with schemas and fake (meta) implementations (no GPU needed to trace through them)."""
+    import torch
+    import pylc_amd  # noqa: F401
+    from pylc_amd import torch_ops
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in torch_ops.REGISTERED:
+        assert hasattr(torch.ops.pylc_hip, name), name
+    with FakeTensorMode():
+        x, w = torch.empty(2, 64, 16, 20), torch.empty(128, 64, 3, 3)
+        y = torch.ops.pylc_hip.conv2d(x, w, None, 2, 1, 1)
+        assert tuple(y.shape) == (2, 128, 8, 10)
+        out = torch.ops.pylc_hip.batch_norm_act(y, torch.empty(128), torch.empty(128), torch.empty(128), torch.empty(128), None, True, True, 1e-5, 0.1)
+        assert tuple(out[0].shape) == (2, 128, 8, 10) and tuple(out[1].shape) == (512,)
+        assert tuple(torch.ops.pylc_hip.bilinear(y, 32, 40).shape) == (2, 128, 32, 40)
+        assert tuple(torch.ops.pylc_hip.max_pool2d(y, 3, 2, 1)[0].shape) == (2, 128, 4, 5)
+        losses, stats = torch.ops.pylc_hip.multiloss(torch.empty(2, 9, 8, 8), torch.empty(2, 8, 8, dtype=torch.int64), None, 0.5, 0.5, 0.5)
+        assert tuple(losses.shape) == (4,) and tuple(stats.shape) == (30,)
+
+
+def test_pretrained_backbone_load(tmp_path):
+    """DeepLab(pretrained=True) / load_pretrained_backbone (resnet.py:149-158): entries whose keys the backbone has are copied, others (fc.*)
+    ignored; a missing file raises like the reference's torch.load."""
+    import torch
+    from pylc_amd import DeepLab
+    net = DeepLab(backbone='resnet', n_classes=9)
+    own = net.backbone.state_dict()
+    fake = {'conv1.weight': torch.full_like(own['conv1.weight'], 0.25), 'layer1.0.bn1.running_var': torch.full_like(own['layer1.0.bn1.running_var'], 3.0),
+            'fc.weight': torch.zeros(1000, 2048), 'fc.bias': torch.zeros(1000)}
+    path = tmp_path / 'resnet101-5d3b4d8f.pth'
+    torch.save(fake, str(path))
+    picked = net.load_pretrained_backbone(str(path))
+    assert picked == ['conv1.weight', 'layer1.0.bn1.running_var']
+    sd = net.backbone.state_dict()
+    assert float(sd['conv1.weight'].min()) == 0.25 and float(sd['layer1.0.bn1.running_var'].max()) == 3.0
+    assert net.backbone.conv1.weight.permute(0, 2, 3, 1).is_contiguous()          # KRSC memory survives the load
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        DeepLab(backbone='resnet', n_classes=9, pretrained=True)                   # ./data/models/resnet101-5d3b4d8f.pth is not here
+    with pytest.raises(ValueError):
+        DeepLab(backbone='xception', n_classes=9).load_pretrained_backbone(str(path))
+
+
+def test_unet_upconv_state_dict_keys():
+    from pylc_amd import UNet
+    n = UNet(in_channels=3, n_classes=9, up_mode='upconv', dropout=0.5)
+    sd = n.state_dict()
+    assert tuple(sd['decoder.0.up.weight'].shape) == (1024, 512, 2, 2) and tuple(sd['decoder.0.up.bias'].shape) == (512,)      # nn.ConvTranspose2d(1024, 512, 2, 2)
+    assert 'decoder.0.up.1.weight' not in sd
+    assert 'decoder.0.up.1.weight' in UNet(in_channels=3, n_classes=9, up_mode='upsample', dropout=0.5).state_dict()
+    import pytest
+    with pytest.raises(ValueError):
+        UNet(in_channels=3, n_classes=9, up_mode='nearest')

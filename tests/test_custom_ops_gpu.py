@@ -1,0 +1,152 @@
+"""`torch.ops.pylc_hip.*` (pylc_amd/torch_ops.py) and the reference's own call pattern on the MI355X (-m gpu).
+
+1. every registered operator against the pylc_amd.ops path it wraps (same kernels: bit-identical forward, gradients equal), plus
+   torch.library.opcheck on the schema / fake / autograd registration of the main ones;
+2. the step models/model.py:300-328 runs, written the way the reference writes it -- normalised NCHW 3-channel input, `net(x)`,
+   `MultiLoss`, `torch.optim.AdamW(net.parameters())`, `clip_grad_norm_` -- with NO flat arena and no pylc_amd.Model, against the
+   reference's recorded losses (tests/golden/deeplab_resnet.json).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def nhwc(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+def test_custom_ops_match_the_ops_path(dev):
+    import pylc_amd  # noqa: F401  (registers the operators)
+    from pylc_amd import ops
+    P = torch.ops.pylc_hip
+    x = nhwc(rnd(1, 2, 64, 20, 24), dev).requires_grad_(True)
+    w = nhwc(rnd(2, 96, 64, 3, 3, scale=0.05), dev).requires_grad_(True)
+    b = rnd(3, 96).to(dev).requires_grad_(True)
+    dy = nhwc(rnd(4, 2, 96, 10, 12), dev)
+    # conv2d (stride 2, bias): forward bit-identical to ops.conv2d, gradients equal
+    y0 = ops.conv2d(x, w, b, 2, 1, 1)
+    y0.backward(dy)
+    ops.sync_side_streams()
+    g0 = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    y1 = P.conv2d(x, w, b, 2, 1, 1)
+    y1.backward(dy)
+    assert torch.equal(y0, y1)
+    for a, c in zip(g0, (x.grad, w.grad, b.grad)):
+        assert torch.equal(a, c)
+    # BatchNorm + residual + ReLU, training mode
+    yb = nhwc(rnd(5, 2, 96, 10, 12, scale=2.0), dev).requires_grad_(True)
+    res = nhwc(rnd(6, 2, 96, 10, 12), dev).requires_grad_(True)
+    ga, be = (1 + 0.1 * rnd(7, 96)).to(dev).requires_grad_(True), (0.1 * rnd(8, 96)).to(dev).requires_grad_(True)
+    rm0, rv0 = torch.zeros(96, device=dev), torch.ones(96, device=dev)
+    o0 = ops.bn_act(yb, ga, be, rm0, rv0, res, True, True)
+    o0.backward(dy)
+    gb0 = (yb.grad.clone(), ga.grad.clone(), be.grad.clone(), res.grad.clone())
+    yb.grad = ga.grad = be.grad = res.grad = None
+    rm1, rv1 = torch.zeros(96, device=dev), torch.ones(96, device=dev)
+    from pylc_amd.torch_ops import bn_act_
+    o1 = bn_act_(yb, ga, be, rm1, rv1, res, True, True)
+    o1.backward(dy)
+    assert torch.equal(o0, o1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    for a, c in zip(gb0, (yb.grad, ga.grad, be.grad, res.grad)):
+        assert torch.equal(a, c)
+    # pooling / resize / activation / dropout
+    t = nhwc(rnd(9, 2, 64, 17, 19), dev).requires_grad_(True)
+    for f0, f1 in ((lambda v: ops.maxpool(v, 3, 2, 1), lambda v: P.max_pool2d(v, 3, 2, 1)[0]),
+                   (lambda v: ops.bilinear(v, 40, 33), lambda v: P.bilinear(v, 40, 33)),
+                   (lambda v: ops.global_avg_pool(v), lambda v: P.global_avg_pool(v)),
+                   (lambda v: ops.relu(v), lambda v: P.relu(v)),
+                   (lambda v: ops.dropout(v, 0.3, 12345), lambda v: P.dropout(v, 0.3, 12345))):
+        a0 = f0(t)
+        go = torch.ones_like(a0) * 0.5
+        a0.backward(go)
+        gt = t.grad.clone()
+        t.grad = None
+        a1 = f1(t)
+        a1.backward(go)
+        assert torch.equal(a0, a1) and torch.equal(gt, t.grad)
+        t.grad = None
+    # depthwise 3x3
+    wd = rnd(10, 64, 1, 3, 3).to(dev).requires_grad_(True)
+    d0 = ops.dwconv3x3(t, wd, 2, 1)
+    d0.backward(torch.ones_like(d0))
+    gd = (t.grad.clone(), wd.grad.clone())
+    t.grad = wd.grad = None
+    d1 = P.dwconv3x3(t, wd, 2, 1)
+    d1.backward(torch.ones_like(d1))
+    assert torch.equal(d0, d1) and torch.equal(gd[0], t.grad) and torch.equal(gd[1], wd.grad)
+    # MultiLoss
+    z = nhwc(rnd(11, 2, 9, 16, 16, scale=2.0), dev)
+    z = ops.pack_nchw(z, 12)[:, :9].requires_grad_(True)
+    tgt = torch.from_numpy(np.random.RandomState(12).randint(0, 9, (2, 16, 16))).to(dev)
+    cw = torch.linspace(0.5, 1.5, 9, device=dev)
+    l0 = ops.multiloss(z, tgt, cw, 0.5, 0.5, 0.5)
+    l0[0].backward()
+    gz = z.grad.clone()
+    z.grad = None
+    l1 = P.multiloss(z, tgt, cw, 0.5, 0.5, 0.5)[0]
+    l1[0].backward()
+    assert torch.equal(l0, l1) and torch.equal(gz, z.grad)
+
+
+def test_opcheck(dev):
+    """Schema, fake-tensor (meta) implementation and autograd registration of the main operators."""
+    import pylc_amd  # noqa: F401
+    from torch.library import opcheck
+    x = nhwc(rnd(1, 2, 32, 12, 12), dev).requires_grad_(True)
+    w = nhwc(rnd(2, 64, 32, 3, 3, scale=0.05), dev).requires_grad_(True)
+    tests = ('test_schema', 'test_faketensor', 'test_autograd_registration')
+    opcheck(torch.ops.pylc_hip.conv2d.default, (x, w, None, 1, 1, 1), test_utils=tests)
+    y = nhwc(rnd(3, 2, 64, 12, 12), dev).requires_grad_(True)
+    g, b = torch.ones(64, device=dev, requires_grad=True), torch.zeros(64, device=dev, requires_grad=True)
+    opcheck(torch.ops.pylc_hip.batch_norm_act.default, (y, g, b, torch.zeros(64, device=dev), torch.ones(64, device=dev), None, True, True, 1e-5, 0.1),
+            test_utils=tests)
+    opcheck(torch.ops.pylc_hip.bilinear.default, (y, 24, 24), test_utils=tests)
+    opcheck(torch.ops.pylc_hip.max_pool2d.default, (y, 3, 2, 1), test_utils=tests)
+
+
+def test_reference_call_pattern_without_arena(dev):
+    """models/model.py:300-328, literally: normalise on the host, NCHW 3-channel fp32 input, net(x), MultiLoss, zero_grad, backward,
+    clip_grad_norm_(0.5), torch.optim.AdamW(net.parameters()).step() -- two steps, losses against the reference's recording."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import DeepLab, runtime
+    from pylc_amd.loss import MultiLoss
+    from tests import _data as D
+    from tests.test_nets_gpu import load_golden, LOSS_TOL
+    meta_g, _ = load_golden('deeplab_resnet')
+    c = meta_g['config']
+    runtime.dropout_enabled = False
+    cfg = ostep.StepConfig(c['arch'], c['backbone'], c['n_classes'], c['ch'], dropout=False)
+    x = D.tiles(c['tile_seed'], c['b'], c['ch'], c['hw'], c['hw'])                       # raw 0..255 fp32 [B,3,H,W], as db/buffer.py:62 hands them over
+    y = D.blob_masks(c['mask_seed'], c['b'], c['hw'], c['hw'], c['n_classes'], cell=c['mask_cell'])
+    w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec(c['arch'], c['backbone'], c['n_classes'], 3), salt=c['weight_salt']), cfg, x.clone())
+    net = DeepLab(activ_func=None, normalizer=None, backbone='resnet', n_classes=c['n_classes'], in_channels=3, pretrained=False).to(dev)
+    net.load_state_dict(w)
+    crit = MultiLoss(loss_weights={'weighted': False, 'weights': [float(v) for v in D.class_weights(c['n_classes'])], 'ce': 0.5, 'dice': 0.5,
+                                   'focal': 0.5},
+                     schema={'n_classes': c['n_classes'], 'class_codes': None, 'class_labels': None}).to(dev)
+    optim = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=5e-5)                  # model.py:240-245
+    assert not any(hasattr(p, '_pylc_grad') for p in net.parameters())                       # no flat arena anywhere
+    px_mean, px_std = torch.tensor([132.47, 144.47, 149.45]), torch.tensor([24.85, 22.04, 18.77])
+    net.train()
+    for it in range(2):
+        xn = ((x - px_mean[None, :, None, None]) / px_std[None, :, None, None]) / 255       # Model.normalize_image, model.py:444-445
+        xn, yd = xn.to(dev), y.to(dev)                                                       # model.py:301-303
+        y_hat = net(xn)                                                                      # model.py:314
+        assert tuple(y_hat.shape) == (c['b'], c['n_classes'], c['hw'], c['hw'])
+        loss = crit(y_hat, yd)                                                               # model.py:317
+        got = (crit.ce.item(), crit.dsc.item(), crit.fl.item())                              # model.py:319
+        optim.zero_grad()                                                                    # model.py:322
+        loss.backward()                                                                      # model.py:323
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 0.5)                                # model.py:326
+        optim.step()                                                                         # model.py:328
+        ref = meta_g['train_steps'][it]
+        print('step %d: (%.6f %.6f %.6f) reference (%.6f %.6f %.6f)' % (it, *got, ref['ce'], ref['dice'], ref['focal']))
+        assert abs(got[0] - ref['ce']) < LOSS_TOL and abs(got[1] - ref['dice']) < LOSS_TOL and abs(got[2] - ref['focal']) < LOSS_TOL

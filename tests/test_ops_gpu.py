@@ -634,3 +634,75 @@ def test_unet_skip_connection_fusion(dev):
     ref = torch.zeros_like(skip)
     ref[:, :, o:o + th, o:o + th] = g_cat[:, c:]
     assert rel_err(leaf2.grad, ref) < 1e-7
+
+
+@pytest.mark.parametrize('cin,cout,b,h,w', [(128, 64, 2, 12, 10), (64, 64, 1, 7, 9)])
+def test_conv_transpose2x2(dev, cin, cout, b, h, w):
+    """U-Net up_mode='upconv' (unet.py:132-133): nn.ConvTranspose2d(k=2, s=2) as the dgrad / fwd / wgrad of a 2x2 stride-2 conv."""
+    from pylc_amd import ops
+    x = rnd(31, b, cin, h, w)
+    wt = rnd(32, cin, cout, 2, 2, scale=0.1)
+    bias = rnd(33, cout, scale=0.1)
+    xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, br, stride=2)
+    do = rnd(34, *ref.shape)
+    ref.backward(do.double())
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = to_dev_nhwc(wt, dev).requires_grad_(True)
+    bd = bias.to(dev).requires_grad_(True)
+    y = ops.conv_transpose2x2(xd, wd, bd)
+    y.backward(to_dev_nhwc(do, dev))
+    ops.sync_side_streams()
+    assert tuple(y.shape) == (b, cout, 2 * h, 2 * w)
+    assert rel_err(y, ref) < 3e-6
+    assert rel_err(xd.grad, xr.grad) < 3e-6 and rel_err(wd.grad, wr.grad) < 3e-6 and rel_err(bd.grad, br.grad) < 3e-6
+
+
+def test_unet_upconv_mode_matches_torch(dev):
+    """The whole U-Net with up_mode='upconv' against a plain torch restatement of unet.py built from the same state dict (forward, fp64)."""
+    from pylc_amd import UNet, runtime
+    runtime.dropout_enabled = False
+    torch.manual_seed(5)
+    net = UNet(in_channels=3, n_classes=9, up_mode='upconv', dropout=0.5).to(dev).eval()
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    x = rnd(41, 1, 3, 188 + 16, 188 + 16)
+
+    def block(t, p):
+        for i in ('0', '3'):
+            t = F.conv2d(t, sd[p + '.block.%s.weight' % i], sd[p + '.block.%s.bias' % i])
+            j = str(int(i) + 1)
+            t = F.relu(F.batch_norm(t, sd[p + '.block.%s.running_mean' % j], sd[p + '.block.%s.running_var' % j], sd[p + '.block.%s.weight' % j],
+                                    sd[p + '.block.%s.bias' % j], False, 0.1, 1e-5))
+        return t
+    t, skips = x.double(), []
+    for i in range(5):
+        t = block(t, 'encoder.%d' % i)
+        if i != 4:
+            skips.append(t)
+            t = F.max_pool2d(t, 2)
+    for i in range(4):
+        up = F.conv_transpose2d(t, sd['decoder.%d.up.weight' % i], sd['decoder.%d.up.bias' % i], stride=2)
+        br = skips[-i - 1]
+        dy, dx = (br.shape[2] - up.shape[2]) // 2, (br.shape[3] - up.shape[3]) // 2
+        t = block(torch.cat([up, br[:, :, dy:dy + up.shape[2], dx:dx + up.shape[3]]], 1), 'decoder.%d.conv_block' % i)
+    ref = F.conv2d(t, sd['last.weight'], sd['last.bias'])
+    with torch.no_grad():
+        got = net(x.to(dev))
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert rel_err(got, ref) < 2e-5
+
+
+def test_image_pack_grayscale_default_branch(dev):
+    """Model.normalize_image(default=True) on a 1-channel image omits the division by 255 (models/model.py:428-430): reproduced."""
+    from pylc_amd.model import Model, Meta
+    m = Model(Meta(ch=1, backbone='xception', n_classes=11), dev)
+    x = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (2, 1, 16, 20)).astype(np.float32))
+    got = m.pack_input(x, default=True)
+    want = (x.numpy().astype('float32') - m.meta.px_grayscale_mean) / m.meta.px_grayscale_std          # the reference's expression
+    for c in range(3):
+        assert np.abs(got[:, c].cpu().numpy() - want[:, 0]).max() <= 1e-6 * np.abs(want).max()
+    assert float(got[:, 3].abs().max()) == 0.0
+    x8 = x.to(torch.uint8)
+    assert torch.equal(m.pack_input(x8, default=True), got)
+    ref255 = ((x.numpy() - np.mean(np.asarray(m.meta.px_mean, np.float32))) / np.mean(np.asarray(m.meta.px_std, np.float32))) / 255
+    assert np.abs(m.pack_input(x)[:, 0].cpu().numpy() - ref255[:, 0]).max() <= 1e-6 * np.abs(ref255).max()
