@@ -298,6 +298,9 @@ int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int dx_pitch, in
                       int OH, int OW, void* stream);
 int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream);
+/* accumulate != 0: dx += the pooled gradient (dx holds the gradient parts of the tensor's other consumers: aspp.py:76-80, where the
+ * encoder output feeds four atrous branches and this pooling branch) */
+int pylc_gap_bwd_acc(const float* dy, float* dx, int B, int HW, int C, int accumulate, void* stream);
 
 /* Image ingest: Model.normalize_image models/model.py:416-445 + the 1->3 channel stack model.py:310-311
  * + NCHW->NHWC, zero-padded to 4 channels.  img is [B][Cimg][H][W] raw 0..255 floats (Cimg = 1 or 3);

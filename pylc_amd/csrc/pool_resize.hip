@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ 
     }
 }
 
+template <bool ACC>
 __global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int HW, int C) {
     const int CV = C / 4;
     const long long total = (long long)B * HW * CV;
@@ -211,7 +212,9 @@ __global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
         const int b = (int)(i / ((long long)HW * CV));
-        st4(dx + 4 * i, ld4(dy + (size_t)b * C + 4 * cv) * inv);
+        f32x4 v = ld4(dy + (size_t)b * C + 4 * cv) * inv;
+        if (ACC) v = v + ld4(dx + 4 * i);       // dx already holds the other consumers' part of the gradient (ops.ResidualLink)
+        st4(dx + 4 * i, v);
     }
 }
 
@@ -354,11 +357,19 @@ extern "C" int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void
     return PYLC_OK;
 }
 
-extern "C" int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream) {
+extern "C" int pylc_gap_bwd_acc(const float* dy, float* dx, int B, int HW, int C, int accumulate, void* stream) {
     PYLC_REQUIRE(dy && dx && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "gap_bwd: bad arguments");
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((long long)B * HW * (C / 4))), dim3(256), 0, as_stream(stream), dy, dx, B, HW, C);
+    const dim3 grid(grid_for((long long)B * HW * (C / 4)));
+    if (accumulate)
+        hipLaunchKernelGGL(gap_bwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), dy, dx, B, HW, C);
+    else
+        hipLaunchKernelGGL(gap_bwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), dy, dx, B, HW, C);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
+}
+
+extern "C" int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream) {
+    return pylc_gap_bwd_acc(dy, dx, B, HW, C, 0, stream);
 }
 
 extern "C" int pylc_image_pack_denom(const void* img, int is_u8, int B, int Cimg, int H, int W, const float* mean3, const float* std3,

@@ -106,6 +106,7 @@ SIGNATURES = {
     'pylc_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pylc_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'pylc_gap_bwd_acc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'pylc_image_pack': (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     'pylc_image_pack_tiles': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     'pylc_stitch_argmax': (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),

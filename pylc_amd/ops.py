@@ -473,6 +473,23 @@ def grad_link(x):
     return link
 
 
+def _padded_stem_filter(w, cin):
+    """The thin-input stem filter ([Cout, 3, k, k]) zero-padded to the 4-channel input pack, KRSC.  Built once per optimiser step, not per
+    forward: cached on the parameter, keyed by its version counter and -- the flat-arena optimisers update parameters through raw
+    pointers, which does not bump it -- the arena's generation."""
+    arena = getattr(w, '_pylc_arena', None)
+    arena = arena() if arena is not None else None
+    key = (w._version, arena.generation if arena is not None else -1, cin)
+    cache = getattr(w, '_pylc_w4', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    cout, cin_w, r, s = w.shape
+    w_k = torch.zeros((cout, r, s, cin), device=w.device, dtype=torch.float32)
+    w_k[..., :cin_w] = w.detach().permute(0, 2, 3, 1)
+    w._pylc_w4 = (key, w_k)
+    return w_k
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
@@ -512,8 +529,7 @@ class Conv2dFn(torch.autograd.Function):
             # thin-input stem (Cin=3): zero-pad the KRSC rows to 4 channels; x must already be the 4-channel pack
             if cin != _r4(cin_w):
                 raise L.PylcError('conv expects the %d-channel packed input for a %d-channel filter' % (_r4(cin_w), cin_w))
-            w_k = torch.zeros((cout, r, s, cin), device=w.device, dtype=torch.float32)
-            w_k[..., :cin_w] = w.detach().permute(0, 2, 3, 1)
+            w_k = _padded_stem_filter(w, cin)
         elif cin != cin_w:
             raise L.PylcError('conv: input has %d channels, filter expects %d' % (cin, cin_w))
         elif not (w.permute(0, 2, 3, 1).is_contiguous()):
@@ -898,7 +914,7 @@ class BnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre_sums=None,
-                want_amax=False, res_link=None, out_planes=False, drop=None, dy_planes=False):
+                want_amax=False, res_link=None, out_planes=False, drop=None, dy_planes=False, into=None):
         L.init()
         ctx.set_materialize_grads(False)
         ctx.res_link = res_link
@@ -950,7 +966,15 @@ class BnActFn(torch.autograd.Function):
         else:
             check(lib.pylc_bn_eval_coeffs_full(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
                                                ptr(scale), ptr(shift), ptr(mean), ptr(invstd), st))
-        out = empty_nhwc(b, c, h, w, dev)
+        op_ = c
+        if into is not None:               # write into channels [c0, c0 + c) of a caller-owned concat buffer: into = ([buffer], c0)
+            buf, c0 = into[0][0], into[1]
+            op_ = pitch_of(buf)
+            if out_planes or tuple(buf.shape[2:]) != (h, w) or buf.shape[0] != b or c0 % 4 or c0 + c > buf.shape[1]:
+                raise L.PylcError('bn_act into=: slice [%d, %d) does not fit the %s buffer' % (c0, c0 + c, tuple(buf.shape)))
+            out = buf[:, c0:c0 + c]
+        else:
+            out = empty_nhwc(b, c, h, w, dev)
         amax = amax_slot(dev) if (want_amax and not out_planes) else None
         if out_planes or res_pl is not None or drop_p > 0:
             ex = _bn_extra(drop_p=drop_p, drop_seed=drop_seed)
@@ -959,10 +983,10 @@ class BnActFn(torch.autograd.Function):
             if res_pl is not None:
                 ex.res_planes, ex.res_plane_stride, ex.res_amax = ptr(res_pl), m * c, ptr(res_amax)
             check(lib.pylc_bn_apply_ex(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else (c if res_pl is not None else 0),
-                                       None if out_planes else ptr(out), c, m, c, int(relu), ptr(amax), C.byref(ex), st))
+                                       None if out_planes else ptr(out), op_, m, c, int(relu), ptr(amax), C.byref(ex), st))
         else:
             check(lib.pylc_bn_apply(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else 0,
-                                    ptr(out), c, m, c, int(relu), ptr(amax), st))
+                                    ptr(out), op_, m, c, int(relu), ptr(amax), st))
         # ReLU mask in backward: without a residual it is recomputed from y (y*scale + shift > 0, the forward's own
         # expression), so `out` is neither kept alive for it nor read again
         ctx.save_for_backward(y, out if (relu and residual is not None) else None, coef, bound)
@@ -983,7 +1007,7 @@ class BnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         if dout is None:
-            return (None,) * 18
+            return (None,) * 19
         y, out, coef, out_bound = ctx.saved_tensors
         relu, training, group, n_global, has_res = ctx.cfg
         gamma, beta = ctx.g_param, ctx.b_param
@@ -1078,11 +1102,11 @@ class BnActFn(torch.autograd.Function):
         if g_out is not None and link is not None and link.armed and link.buf is None and tuple(g_out.shape) == tuple(y.shape):
             link.buf = g_out         # the first conv's dgrad accumulates into it and returns it as x's whole gradient
             g_out = None
-        return (dy, dgamma, dbeta, None, None, g_out) + (None,) * 12
+        return (dy, dgamma, dbeta, None, None, g_out) + (None,) * 13
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
-           group=None, clamp_eps=False, res_link=None, out_planes=False, drop=None):
+           group=None, clamp_eps=False, res_link=None, out_planes=False, drop=None, into=None):
     pre = getattr(y, '_pylc_sums', None) if training else None
     dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and not os.environ.get('PYLC_NO_PLANES_DY')
     out_planes = bool(out_planes) and ranges_needed() and not _runtime.no_planes
@@ -1090,14 +1114,14 @@ def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, 
         drop = None
     if ranges_needed():
         out, tagv = BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
-                                  True, res_link, out_planes, drop, dy_pl)
-        if is_planes_candidate(out_planes, training, y):
+                                  True, res_link, out_planes and into is None, drop, dy_pl, into)
+        if is_planes_candidate(out_planes and into is None, training, y):
             mark_planes(out, tagv)
         else:
             tag_amax(out, tagv)
         return out
     return BnActFn.apply(y, gamma, beta, running_mean, running_var, residual, relu, training, eps, momentum, group, clamp_eps, pre,
-                         False, res_link, False, drop, False)
+                         False, res_link, False, drop, False, into)
 
 
 def is_planes_candidate(out_planes, training, y):
@@ -1255,11 +1279,49 @@ def crop_concat(up, bridge, holder, link=None):
     return CropConcatFn.apply(up, bridge, holder, link)
 
 
+class ConcatSlicesFn(torch.autograd.Function):
+    """torch.cat(parts, 1) (aspp.py:80, decoder.py:47) without the copy: every part was WRITTEN into its channel slice of one NHWC
+    buffer by the kernel that produced it (bn_act / bilinear `into=`); the "concat" is the buffer.  Backward: each part's gradient is a
+    channel-slice view of the buffer's gradient."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        c0 = 0
+        offs = []
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + 4 * c0 or tuple(p.shape[2:]) != tuple(buf.shape[2:]) or pitch_of(p) != pitch_of(buf):
+                raise L.PylcError('concat_slices: part at channel %d is not that slice of the buffer' % c0)
+            offs.append((c0, p.shape[1]))
+            c0 += p.shape[1]
+        if c0 != buf.shape[1]:
+            raise L.PylcError('concat_slices: the parts cover %d of %d channels' % (c0, buf.shape[1]))
+        ctx.offs = offs
+        return buf
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = as_nhwc(dy)
+        return (None,) + tuple(dy[:, c0:c0 + c] for c0, c in ctx.offs)
+
+
+def concat_slices(holder, parts):
+    out = ConcatSlicesFn.apply(holder, *parts)
+    if ranges_needed():
+        tags = [getattr(t, '_pylc_amax', None) for t in parts]
+        if all(tg is not None and tg[1] == t._version for tg, t in zip(tags, parts)):
+            a = tags[0][0]
+            for tg in tags[1:]:
+                a = torch.maximum(a, tg[0])
+            tag_amax(out, a)
+    return out
+
+
 class BilinearFn(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=True) to an explicit output size."""
 
     @staticmethod
-    def forward(ctx, x, oh, ow):
+    def forward(ctx, x, oh, ow, into=None):
         L.init()
         x = as_nhwc(x)
         b, c, h, w = x.shape
@@ -1267,8 +1329,14 @@ class BilinearFn(torch.autograd.Function):
         cc = _r4(c)
         if cc > cp:
             raise L.PylcError('bilinear: channel count %d needs a pitch >= %d' % (c, cc))
-        y = empty_nhwc(b, c, oh, ow, x.device, cc)
-        check(lib.pylc_bilinear_fwd(ptr(x), cp, ptr(y), cc, b, h, w, cc, oh, ow, stream()))
+        if into is not None:               # channels [c0, c0 + c) of a concat buffer: into = ([buffer], c0)
+            buf, c0 = into[0][0], into[1]
+            if tuple(buf.shape[2:]) != (oh, ow) or buf.shape[0] != b or c0 % 4 or c % 4 or c0 + c > buf.shape[1]:
+                raise L.PylcError('bilinear into=: slice [%d, %d) does not fit the %s buffer' % (c0, c0 + c, tuple(buf.shape)))
+            y, yp = buf[:, c0:c0 + c], pitch_of(buf)
+        else:
+            y, yp = empty_nhwc(b, c, oh, ow, x.device, cc), cc
+        check(lib.pylc_bilinear_fwd(ptr(x), cp, ptr(y), yp, b, h, w, cc, oh, ow, stream()))
         ctx.cfg = (b, c, h, w, oh, ow)
         return y
 
@@ -1283,17 +1351,17 @@ class BilinearFn(torch.autograd.Function):
             dy = t
         dx = empty_nhwc(b, c, h, w, dy.device, cc)
         check(lib.pylc_bilinear_bwd(ptr(dy), pitch_of(dy), ptr(dx), cc, b, h, w, cc, oh, ow, stream()))
-        return dx, None, None
+        return dx, None, None, None
 
 
-def bilinear(x, oh, ow):
-    y = BilinearFn.apply(x, oh, ow)
+def bilinear(x, oh, ow, into=None):
+    y = BilinearFn.apply(x, oh, ow, into)
     return inherit_amax(y, x) if ranges_needed() else y       # interpolation weights are a convex combination
 
 
 class GapFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, res_link=None):
         L.init()
         x = as_nhwc(x)
         if pitch_of(x) != x.shape[1]:
@@ -1302,19 +1370,30 @@ class GapFn(torch.autograd.Function):
         y = empty_nhwc(b, c, 1, 1, x.device)
         check(lib.pylc_gap_fwd(ptr(x), ptr(y), b, h * w, c, stream()))
         ctx.cfg = (b, c, h, w)
+        ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
+        if ctx.res_link is not None:
+            res_link.pending += 1           # one more backward node that adds its part of x's gradient into the shared buffer
         return y
 
     @staticmethod
     def backward(ctx, dy):
         b, c, h, w = ctx.cfg
         dy = dy.reshape(b, c).contiguous()
-        dx = empty_nhwc(b, c, h, w, dy.device)
-        check(lib.pylc_gap_bwd(ptr(dy), ptr(dx), b, h * w, c, stream()))
-        return dx
+        link = ctx.res_link
+        sink = link.buf if link is not None else None
+        dx = sink if sink is not None else empty_nhwc(b, c, h, w, dy.device)
+        check(lib.pylc_gap_bwd_acc(ptr(dy), ptr(dx), b, h * w, c, 1 if sink is not None else 0, stream()))
+        if link is not None:
+            link.pending -= 1
+            if link.pending > 0:            # the convs that read x follow: their dgrads accumulate into the same buffer
+                link.buf, dx = dx, None
+            else:
+                link.buf = None
+        return dx, None
 
 
-def global_avg_pool(x):
-    return GapFn.apply(x)
+def global_avg_pool(x, res_link=None):
+    return GapFn.apply(x, res_link)
 
 
 # ----------------------------------------------------------------------------------------------

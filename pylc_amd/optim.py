@@ -74,6 +74,7 @@ class FlatArena:
                                   self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
         self._index = {id(p): i for i, p in enumerate(params)}
         self._delivered = set()          # parameters whose gradient a backward kernel wrote since the last zero_grad()
+        self.generation = 0              # bumped whenever parameter VALUES may have changed (refresh_ranges): derived buffers key on it
         me = weakref.ref(self)           # no module -> arena strong reference: a dropped model frees its memory by refcount
         module.register_load_state_dict_post_hook(lambda *_: me() is not None and me().refresh_ranges())
         self.refresh_ranges()
@@ -81,6 +82,7 @@ class FlatArena:
     def refresh_ranges(self):
         """Recompute every parameter's max magnitude and rebuild the prepared filter planes from it.  Call after anything
         that changes parameter values (the optimiser steps here do; Model refreshes at the start of each step as well)."""
+        self.generation += 1
         if self.p.is_cuda:
             L.init()
             check(lib.pylc_amax_segments(ptr(self.p), ptr(self._segments), len(self.params), ptr(self.amax), stream()))

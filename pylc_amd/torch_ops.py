@@ -349,7 +349,8 @@ def _(x):
 def global_avg_pool_backward(dy: Tensor, h: int, w: int) -> Tensor:
     ctx = _Ctx((True,))
     ctx.cfg = (dy.shape[0], dy.shape[1], h, w)
-    return ops.GapFn.backward(ctx, dy)
+    ctx.res_link = None
+    return ops.GapFn.backward(ctx, dy)[0]
 
 
 @global_avg_pool_backward.register_fake

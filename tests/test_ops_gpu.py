@@ -706,3 +706,47 @@ def test_image_pack_grayscale_default_branch(dev):
     assert torch.equal(m.pack_input(x8, default=True), got)
     ref255 = ((x.numpy() - np.mean(np.asarray(m.meta.px_mean, np.float32))) / np.mean(np.asarray(m.meta.px_std, np.float32))) / 255
     assert np.abs(m.pack_input(x)[:, 0].cpu().numpy() - ref255[:, 0]).max() <= 1e-6 * np.abs(ref255).max()
+
+
+def test_concat_by_slice_equals_cat(dev):
+    """aspp.py:80 / decoder.py:47: BatchNorm passes and the interpolation write their channel ranges of one buffer (`into=`) and
+    ops.concat_slices() hands the buffer on -- values, range tag and every gradient equal to producing the parts and torch.cat."""
+    from pylc_amd import ops, runtime
+    prev = runtime.dropout_enabled
+    runtime.dropout_enabled = True
+    b, h, w = 2, 12, 20
+    ya, yb = rnd(1, b, 64, h, w, scale=2.0), rnd(2, b, 48, h, w) + 0.3
+    g = rnd(3, b, 32, 5, 7)
+    ga, be = 1 + 0.1 * rnd(4, 64), 0.1 * rnd(5, 64)
+    gb, bb = 1 + 0.1 * rnd(6, 48), 0.1 * rnd(7, 48)
+    do = rnd(8, b, 144, h, w).to(dev).contiguous(memory_format=torch.channels_last)
+    got = {}
+    for mode in ('cat', 'slices'):
+        cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+        leaves = [cl(ya), ga.to(dev), be.to(dev), cl(yb), gb.to(dev), bb.to(dev), cl(g)]
+        for t in leaves:
+            t.requires_grad_(True)
+        stats = [torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.zeros(48, device=dev), torch.ones(48, device=dev)]
+        if mode == 'cat':
+            parts = [ops.bn_act(leaves[0], leaves[1], leaves[2], stats[0], stats[1], None, True, True),
+                     ops.bilinear(leaves[6], h, w),
+                     ops.bn_act(leaves[3], leaves[4], leaves[5], stats[2], stats[3], None, True, True, drop=(0.5, 77))]
+            out = ops.cat_channels(parts)
+        else:
+            buf = [ops.empty_nhwc(b, 144, h, w, dev)]
+            parts = [ops.bn_act(leaves[0], leaves[1], leaves[2], stats[0], stats[1], None, True, True, into=(buf, 0)),
+                     ops.bilinear(leaves[6], h, w, into=(buf, 64)),
+                     ops.bn_act(leaves[3], leaves[4], leaves[5], stats[2], stats[3], None, True, True, drop=(0.5, 77), into=(buf, 96))]
+            out = ops.concat_slices(buf, parts)
+            assert out.data_ptr() == buf[0].data_ptr()
+        tag = ops.amax_of(out).clone() if ops.ranges_needed() else None
+        (out * 1.0).backward(do)
+        torch.cuda.synchronize()
+        got[mode] = [out.detach().clone(), tag] + [t.grad.clone() for t in leaves] + [s.clone() for s in stats]
+    runtime.dropout_enabled = prev
+    for i, (a, c) in enumerate(zip(got['cat'], got['slices'])):
+        if a is not None:
+            assert torch.equal(a, c), i
+    with pytest.raises(Exception):
+        buf = [ops.empty_nhwc(b, 144, h, w, dev)]
+        ops.concat_slices(buf, [ops.bilinear(g.to(dev).contiguous(memory_format=torch.channels_last), h, w, into=(buf, 0))])        # does not cover the buffer
