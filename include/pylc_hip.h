@@ -241,14 +241,19 @@ typedef struct PylcBnExtra {
     unsigned int* g_amax;
 } PylcBnExtra;
 /* pylc_bn_finalize / _from_partial that also max-accumulate into *bound_out (zero-initialised) an upper bound of
- * |act(BN(y)) (+ residual)| * bound_mul:  max_c (|gamma_c| sqrt(n - 1) + |beta_c|) + *bound_extra (the residual's range, may be NULL). */
+ * |act(BN(y)) (+ residual)| * bound_mul:  max_c (|gamma_c| sqrt(n - 1) + |beta_c|) + *bound_extra (the residual's range, may be NULL).
+ * y (may be NULL) / y_pitch / M == n: the tensor the sums were taken over.  With it, a channel whose mean^2 exceeds 64 var -- where
+ * sumsq/n - mean^2 from fp32 sums no longer carries the variance -- is re-measured in a second pass as sum((y - mean)^2), so the result
+ * follows torch.nn.BatchNorm2d's two-pass / Welford statistics (what the reference's non-SyncBN layers run) at any mean / sigma ratio.
+ * Pass NULL for all-reduced sums: the vendored SyncBN itself exchanges [sum, sumsq] in fp32 (sync_batchnorm/batchnorm.py:78-103). */
 int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                         int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                        float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream);
+                        float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out,
+                        const float* y, int y_pitch, long long M, void* stream);
 int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
                                      float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                      float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
-                                     float bound_mul, unsigned int* bound_out, void* stream);
+                                     float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M, void* stream);
 int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
                      float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, const PylcBnExtra* ex,
                      void* stream);

@@ -188,16 +188,70 @@ __device__ __forceinline__ void bn_commit_bound(float gamma, float beta, double 
     atomicMax(bound_out, __float_as_uint(b));
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
-                                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                   float* shift, const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
-    const double mu = (double)sums[c] / n;
-    double var = (double)sums[C + c] / n - mu * mu;
+// Where the statistics' second moment cannot carry the variance: sum(x^2)/n - mean^2 computed from fp32 partial sums loses
+// (mean/sigma)^2 * 2^-24 of relative accuracy, i.e. everything once |mean| ~ 10^3 sigma -- torch.nn.BatchNorm2d (two-pass on the CPU,
+// Welford on the GPU; what the reference runs outside SyncBN) does not.  A channel with mean^2 > kRefineRatio * var is therefore
+// re-measured here in a second pass over its column of y: sum(y - mean) and sum((y - mean)^2), differences exact in fp32 (Sterbenz),
+// sums in fp64.  Costs nothing for well-conditioned channels (all of them in the networks of this package); the pass itself is a
+// strided column read by the 32 row lanes of the finalize block.
+constexpr double kRefineRatio = 64.0;
+
+struct RefineSrc {
+    const float* y;       // NULL: no refinement (SyncBN: the reference's own exchange is [sum, sumsq] in fp32, batchnorm.py:78-103)
+    int pitch;
+    long long M;
+};
+
+// Tail of both finalize kernels: 8 channels (tx) x 32 row lanes (ty) per block; the ty == 0 lanes arrive with the channel's sum and
+// sum of squares.
+__device__ __forceinline__ void bn_finalize_tail(double sum, double sumsq, double (*red)[32][9], int tx, int ty, int c, double n, int C,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd,
+                                                 float* scale, float* shift, const unsigned* bound_extra, float bound_mul,
+                                                 unsigned* bound_out, RefineSrc src) {
+    __shared__ float ref_mu[8];
+    __shared__ int ref_need[8];
+    double mu = sum / n;
+    double var = sumsq / n - mu * mu;
     if (var < 0.0) var = 0.0;
+    if (src.y != nullptr) {                  // kernel-uniform
+        if (ty == 0) {
+            ref_need[tx] = (c < C && mu * mu > kRefineRatio * var) ? 1 : 0;
+            ref_mu[tx] = (float)mu;
+        }
+        __syncthreads();
+        const int need = ref_need[tx];
+        if (__syncthreads_or(need)) {        // block-uniform
+            double a0 = 0.0, a1 = 0.0;
+            const float mf = ref_mu[tx];
+            if (need) {
+                const float* col = src.y + c;
+                long long r = ty;
+                for (; r + 7 * 32 < src.M; r += 8 * 32) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = col[(r + u * 32) * src.pitch];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const float d = v[u] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
+                }
+                for (; r < src.M; r += 32) { const float d = col[r * src.pitch] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
+            }
+            __syncthreads();                 // `red` still holds the caller's first-stage values until every lane has read them
+            red[0][ty][tx] = a0;
+            red[1][ty][tx] = a1;
+            __syncthreads();
+            if (ty == 0 && need) {
+                double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) { d0 += red[0][k][tx]; d1 += red[1][k][tx]; }
+                mu = (double)mf + d0 / n;
+                var = (d1 - d0 * d0 / n) / n;
+                if (var < 0.0) var = 0.0;
+            }
+        }
+    }
+    if (ty != 0 || c >= C) return;
+    if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
     // torch.nn.BatchNorm2d: 1/sqrt(var + eps); vendored SyncBN (batchnorm.py:125): clamp(var, eps)^-1/2
     const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
     const float mu_f = (float)mu, is_f = (float)is;
@@ -213,13 +267,27 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, double n, int
     }
 }
 
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
+                                                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                                          float* shift, const unsigned* bound_extra, float bound_mul, unsigned* bound_out,
+                                                          RefineSrc src) {
+    __shared__ double red[2][32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx;
+    const bool mine = ty == 0 && c < C;
+    bn_finalize_tail(mine ? (double)sums[c] : 0.0, mine ? (double)sums[C + c] : 0.0, red, tx, ty, c, n, C, gamma, beta, eps, momentum, clamp_eps,
+                     running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out, src);
+}
+
 // bn_finalize fed directly by the conv epilogue's per-tile partials: the fp64 column combine (column_sum_kernel's
 // arithmetic, 8 channels x 32 row lanes per block, fixed order) and the coefficient math in one launch.
 __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* __restrict__ partial, int nrows, double n, int C,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                   float momentum, int clamp_eps, float* running_mean, float* running_var,
                                                                   float* mean, float* invstd, float* scale, float* shift,
-                                                                  const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
+                                                                  const unsigned* bound_extra, float bound_mul, unsigned* bound_out,
+                                                                  RefineSrc src) {
     __shared__ double red[2][32][9];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + tx;
@@ -244,27 +312,14 @@ __global__ __launch_bounds__(256) void bn_finalize_partial_kernel(const float* _
     red[0][ty][tx] = a0;
     red[1][ty][tx] = a1;
     __syncthreads();
-    if (ty != 0 || c >= C) return;
-    if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
     double s0 = 0.0, s1 = 0.0;
+    if (ty == 0) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { s0 += red[0][k][tx]; s1 += red[1][k][tx]; }
-    const double sum = (double)(float)s0, sumsq = (double)(float)s1;      // the two-launch path rounds the sums to fp32 in between
-    const double mu = sum / n;
-    double var = sumsq / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
-    const float mu_f = (float)mu, is_f = (float)is;
-    mean[c] = mu_f;
-    invstd[c] = is_f;
-    const float sc = gamma[c] * is_f;
-    scale[c] = sc;
-    shift[c] = beta[c] - mu_f * sc;
-    if (running_mean != nullptr) {
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu_f;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        for (int k = 0; k < 32; ++k) { s0 += red[0][k][tx]; s1 += red[1][k][tx]; }
     }
+    // the two-launch path rounds the sums to fp32 in between
+    bn_finalize_tail((double)(float)s0, (double)(float)s1, red, tx, ty, c, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var,
+                     mean, invstd, scale, shift, bound_extra, bound_mul, bound_out, src);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* rm, const float* rv, const float* gamma, const float* beta, float eps,
@@ -558,11 +613,14 @@ extern "C" int pylc_bn_stats_from_partial(const float* partial, int n_rows, int 
 
 extern "C" int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                                    int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                   float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream) {
+                                   float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out,
+                                   const float* y, int y_pitch, long long M, void* stream) {
     PYLC_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be set or both NULL");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums, n, C, gamma, beta, eps, momentum,
-                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
+    PYLC_REQUIRE(y == nullptr || (y_pitch >= C && M > 0 && (double)M == n), "bn_finalize: the refinement source must be the n rows the sums cover");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), sums, n, C, gamma, beta, eps, momentum,
+                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out,
+                       RefineSrc{y, y_pitch, M});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -571,18 +629,22 @@ extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float*
                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                 float* shift, void* stream) {
     return pylc_bn_finalize_ex(sums, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift,
-                               nullptr, 1.f, nullptr, stream);
+                               nullptr, 1.f, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
                                                 float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                                 float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
-                                                float bound_mul, unsigned int* bound_out, void* stream) {
+                                                float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M,
+                                                void* stream) {
     PYLC_REQUIRE(partial && n_rows > 0 && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0,
                  "bn_finalize_from_partial: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_from_partial: running stats must both be set or both NULL");
+    PYLC_REQUIRE(y == nullptr || (y_pitch >= C && M > 0 && (double)M == n),
+                 "bn_finalize_from_partial: the refinement source must be the n rows the partials cover");
     hipLaunchKernelGGL(bn_finalize_partial_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, n, C, gamma, beta, eps,
-                       momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
+                       momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out,
+                       RefineSrc{y, y_pitch, M});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -591,7 +653,7 @@ extern "C" int pylc_bn_finalize_from_partial(const float* partial, int n_rows, d
                                              float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
     return pylc_bn_finalize_from_partial_ex(partial, n_rows, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean,
-                                            invstd, scale, shift, nullptr, 1.f, nullptr, stream);
+                                            invstd, scale, shift, nullptr, 1.f, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,

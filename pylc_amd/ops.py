@@ -948,7 +948,7 @@ class BnActFn(torch.autograd.Function):
                 # statistics came out of the conv epilogue as per-tile partials: combine + coefficients in one launch
                 check(lib.pylc_bn_finalize_from_partial_ex(ptr(partial), partial.shape[0], n_global, c, ptr(gamma), ptr(beta), eps, momentum,
                                                            int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
-                                                           ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound), st))
+                                                           ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound), ptr(y), yp, m, st))
             else:
                 sums = torch.empty(2 * c + 1, device=dev)                 # [sum | sumsq | count slot for SyncBN]
                 if partial is not None:
@@ -962,7 +962,7 @@ class BnActFn(torch.autograd.Function):
                     n_global = float(m) * dist.get_world_size(group)      # equal shards (checked by parallel.init_from_env / DataParallel setup)
                 check(lib.pylc_bn_finalize_ex(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
                                               ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                              ptr(res_amax), mul, ptr(bound), st))
+                                              ptr(res_amax), mul, ptr(bound), None if group is not None else ptr(y), yp, m, st))
         else:
             check(lib.pylc_bn_eval_coeffs_full(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
                                                ptr(scale), ptr(shift), ptr(mean), ptr(invstd), st))

@@ -13,6 +13,7 @@ BN running stats), and (4) writes small fixtures holding OUTPUTS only -- inputs 
 are regenerated from seeds by tests/_data.py and oracle.formula_state.
 
     python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py --only-grads deeplab_resnet deeplab_xception unet     # the elementwise-gradient fixtures only
 """
 import json
 import os
@@ -178,6 +179,13 @@ def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
             print('  step 0  worst relative grad diff = %.3g' % worst)
             assert worst < 2e-3
             meta['grad_digest_step0'] = tensor_digests(gref.items())
+            # elementwise gradients of six tensors spread over the depth of the network (four conv filters, two BatchNorm vectors, each
+            # at most 40k elements): a permutation or a sign error inside a tensor leaves the digests above unchanged, these not
+            convs = [k for k, g in gref.items() if k not in zero_keys and g.dim() == 4 and g.numel() <= 40000]
+            vecs = [k for k, g in gref.items() if k not in zero_keys and g.dim() == 1 and g.numel() >= 32]
+            picked = [convs[round(i * (len(convs) - 1) / 3)] for i in range(4)] + [vecs[len(vecs) // 5], vecs[-3]]
+            grad_fix = {'g::' + k: gref[k].detach().numpy().astype(np.float32).copy() for k in picked}
+            grad_meta = {k: {'absmax': float(gref[k].abs().max()), 'oracle_maxdiff': float((gref[k] - sd[k].grad).abs().max())} for k in picked}
             new_sd = ref.net.state_dict()
             pw, pk = 0.0, None
             for k, v in new_sd.items():
@@ -206,6 +214,8 @@ def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
             for k, g in gref.items():
                 g1 = sd1[k].grad          # already clipped in place by clip_grad_norm_
                 grad_cond[k] = float((g1 - g).norm() / (g.norm() + 1e-3 * gmax))
+                if k in grad_meta:
+                    grad_meta[k]['cond_maxdiff'] = float((g1 - g).abs().max())       # reference-vs-reference noise, elementwise
     torch.set_num_threads(8)
     meta['conditioning_train'] = cond_steps
     meta['grad_conditioning_step0'] = grad_cond
@@ -214,6 +224,12 @@ def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
     meta['config'] = {'arch': arch, 'backbone': backbone, 'b': b, 'ch': ch, 'hw': hw, 'n_classes': n_classes,
                       'tile_seed': 100, 'mask_seed': 101, 'mask_cell': 8, 'weight_salt': 1,
                       'torch': torch.__version__}
+    np.savez_compressed(os.path.join(out_dir, tag + '_grads.npz'), **grad_fix)
+    with open(os.path.join(out_dir, tag + '_grads.json'), 'w') as f:
+        json.dump(grad_meta, f)
+    print('  elementwise gradient fixtures: %s' % {k: (v['absmax'], v['oracle_maxdiff'], v['cond_maxdiff']) for k, v in grad_meta.items()})
+    if ONLY_GRADS:
+        return
     np.savez_compressed(os.path.join(out_dir, tag + '.npz'), **fix)
     with open(os.path.join(out_dir, tag + '.json'), 'w') as f:
         json.dump(meta, f)
@@ -335,9 +351,16 @@ def golden_driver(out_dir):
                               'train_seeds': [700, 701, 702], 'valid_seeds': [800, 801]}}, fh)
 
 
+ONLY_GRADS = False
+
+
 def main():
+    global ONLY_GRADS
     torch.set_num_threads(8)
     enter_reference()
+    if '--only-grads' in sys.argv:          # write <net>_grads.npz|json only, leave the other fixtures as they are
+        ONLY_GRADS = True
+        sys.argv.remove('--only-grads')
     which = sys.argv[1:] or ['multiloss', 'stitch', 'driver', 'deeplab_resnet', 'deeplab_xception', 'unet']
     if 'stitch' in which:
         golden_stitch(HERE)

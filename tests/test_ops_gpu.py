@@ -750,3 +750,89 @@ def test_concat_by_slice_equals_cat(dev):
     with pytest.raises(Exception):
         buf = [ops.empty_nhwc(b, 144, h, w, dev)]
         ops.concat_slices(buf, [ops.bilinear(g.to(dev).contiguous(memory_format=torch.channels_last), h, w, into=(buf, 0))])        # does not cover the buffer
+
+
+@pytest.mark.parametrize('path', ['standalone', 'conv_fused'])
+def test_bn_train_mean_1e3_sigma(dev, path):
+    """|mean| / sigma ~ 10^3 per channel: sum(x^2)/n - mean^2 from fp32 sums carries no variance bits there; the finalize kernels
+    re-measure such channels in a second pass (bn.hip: kRefineRatio), as torch.nn.BatchNorm2d's two-pass / Welford statistics do.
+    Both statistics sources: the standalone reduction over y, and the per-tile partials of the conv epilogue."""
+    from pylc_amd import ops
+    c, b, hw = 64, 4, 24
+    if path == 'standalone':
+        y = (1000.0 + rnd(71, b, c, hw, hw)) * (1 + torch.arange(c).float().view(1, c, 1, 1) / c)       # mean 1000..2000, sigma 1..2
+        y[:, 5] = rnd(72, b, hw, hw) * 3.0 + 0.25                                                           # one well-conditioned channel
+        yd = to_dev_nhwc(y, dev).requires_grad_(True)
+        y_ref = y.double()
+    else:
+        # conv outputs with a large common mode: positive inputs x positive filters (mean ~ 64 * 9 * 1.0 = 576, sigma ~ 0.3)
+        x = 1.0 + 0.01 * rnd(73, b, 64, hw, hw)
+        wt = 1.0 + 0.01 * rnd(74, c, 64, 3, 3)
+        conv_out = ops.conv2d(to_dev_nhwc(x, dev), to_dev_nhwc(wt, dev), None, 1, 1, 1, want_stats=True)
+        assert getattr(conv_out, '_pylc_sums', None) is not None
+        y_ref = conv_out.detach().double().cpu()
+        ratio = (y_ref.mean((0, 2, 3)).abs() / y_ref.std((0, 2, 3))).min().item()
+        assert ratio > 300, ratio
+        yd = conv_out.detach().requires_grad_(True)
+        yd._pylc_sums = conv_out._pylc_sums
+    g, be = 1 + 0.1 * rnd(75, c), 0.1 * rnd(76, c)
+    yr, gr, ber = y_ref.clone().requires_grad_(True), g.double().requires_grad_(True), be.double().requires_grad_(True)
+    rmr, rvr = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    o = F.relu(F.batch_norm(yr, rmr, rvr, gr, ber, True, 0.1, 1e-5))
+    do = rnd(77, *o.shape)
+    o.backward(do.double())
+    gd, bed = g.to(dev).requires_grad_(True), be.to(dev).requires_grad_(True)
+    rmd, rvd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    od = ops.bn_act(yd, gd, bed, rmd, rvd, None, True, True)
+    od.backward(to_dev_nhwc(do, dev))
+    # y itself is fp32: (y - mean) carries |mean| 2^-24 ~ 1e-4 sigma of input rounding, which bounds what any fp32 BatchNorm can return
+    assert rel_err(od, o) < 3e-4, rel_err(od, o)
+    assert rel_err(rvd, rvr) < 1e-4, rel_err(rvd, rvr)                  # the variance itself: no cancellation left
+    assert rel_err(rmd, rmr) < 1e-6
+    assert rel_err(yd.grad, yr.grad) < 2e-3 and rel_err(gd.grad, gr.grad) < 5e-4 and rel_err(bed.grad, ber.grad) < 1e-5
+    # torch's own fp32 BatchNorm on the device, for scale: ours must not be worse than 4x its error
+    yt = yd.detach().clone().requires_grad_(True)
+    ot = F.relu(F.batch_norm(yt, torch.zeros(c, device=dev), torch.ones(c, device=dev), g.to(dev), be.to(dev), True, 0.1, 1e-5))
+    assert rel_err(od, o) <= 4 * rel_err(ot, o) + 1e-5, (rel_err(od, o), rel_err(ot, o))
+
+
+def test_range_tags_go_stale_with_the_tensor(dev):
+    """An operand range tag (ops.tag_amax) is trusted only while the tensor's version counter is the one it was attached at: an
+    in-place change after tagging -- autograd's gradient accumulation does that -- must send amax_of() back to a read pass, and the
+    tag must not travel on through inherit_amax / cat_channels.  A too-small range would overflow the fp16 pieces (inf/NaN), so the
+    conv on the modified tensor is checked against fp64 as well."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib, check
+    prev = lib.pylc_get_conv_precision()
+    check(lib.pylc_set_conv_precision(2))
+    try:
+        bits = lambda t: float(t.view(torch.float32).item())
+        a = to_dev_nhwc(rnd(81, 2, 32, 12, 12), dev)
+        b = to_dev_nhwc(rnd(82, 2, 32, 12, 12) * 0.5, dev)
+        passes0 = ops.amax_passes[0]
+        ra = bits(ops.amax_of(a))
+        assert abs(ra - a.abs().max().item()) == 0 and ops.amax_passes[0] == passes0 + 1
+        assert bits(ops.amax_of(a)) == ra and ops.amax_passes[0] == passes0 + 1           # fresh tag: reused, no pass
+        ops.amax_of(b)
+        cat = ops.cat_channels([a, b])
+        assert bits(ops.amax_of(cat)) == ra and ops.amax_passes[0] == passes0 + 2         # max of the parts' tags, no pass
+        up = ops.bilinear(a, 24, 24)
+        assert getattr(up, '_pylc_amax', None) is not None and bits(ops.amax_of(up)) == ra
+        # in-place change: 1000x larger values, version bumped
+        a.mul_(1000.0)
+        assert bits(ops.amax_of(a)) == a.abs().max().item() and ops.amax_passes[0] == passes0 + 3   # stale tag ignored: a read pass
+        a2 = to_dev_nhwc(rnd(83, 2, 32, 12, 12), dev)
+        ops.amax_of(a2)
+        a2.add_(500.0)
+        cat2 = ops.cat_channels([a2, b])                                                  # one part stale: the result carries no tag
+        assert getattr(cat2, '_pylc_amax', None) is None
+        assert bits(ops.amax_of(cat2)) == cat2.abs().max().item()
+        up2 = ops.bilinear(a2, 24, 24)                                                    # stale source: nothing inherited
+        assert getattr(up2, '_pylc_amax', None) is None
+        # and the conv that consumes the modified tensor is right (a stale range of ~4 against values of ~4000 would saturate fp16)
+        wt = rnd(84, 64, 32, 3, 3, scale=0.05)
+        y = ops.conv2d(a, to_dev_nhwc(wt, dev), None, 1, 1, 1)
+        ref = F.conv2d(a.double().cpu(), wt.double(), None, 1, 1, 1)
+        assert bool(torch.isfinite(y).all()) and rel_err(y, ref) < 3e-6
+    finally:
+        check(lib.pylc_set_conv_precision(prev))
