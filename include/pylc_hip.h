@@ -254,6 +254,14 @@ int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n,
                                      float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                      float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
                                      float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M, void* stream);
+/* SyncBN in two stages around ONE all-reduce (sync_batchnorm/batchnorm.py:48-125 exchanges [sum, ssum, size] per layer): stage 1 turns
+ * this rank's fp32 sums over its n rows into fp64 moments [sum y | sum y^2 | n] (2C + 1 doubles), re-measuring ill-conditioned channels
+ * from y as pylc_bn_finalize_ex does; the caller all-reduces the buffer (SUM); stage 2 derives the coefficients from the global moments
+ * over n = the summed count.  With one rank the result equals pylc_bn_finalize_ex bit for bit. */
+int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, double* moments, void* stream);
+int pylc_bn_finalize_moments(const double* moments, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
+                             int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                             float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream);
 int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
                      float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, const PylcBnExtra* ex,
                      void* stream);

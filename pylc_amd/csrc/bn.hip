@@ -202,56 +202,64 @@ struct RefineSrc {
     long long M;
 };
 
-// Tail of both finalize kernels: 8 channels (tx) x 32 row lanes (ty) per block; the ty == 0 lanes arrive with the channel's sum and
-// sum of squares.
-__device__ __forceinline__ void bn_finalize_tail(double sum, double sumsq, double (*red)[32][9], int tx, int ty, int c, double n, int C,
-                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd,
-                                                 float* scale, float* shift, const unsigned* bound_extra, float bound_mul,
-                                                 unsigned* bound_out, RefineSrc src) {
+// First half of a finalize (all 256 threads of the block: 8 channels (tx) x 32 row lanes (ty); the ty == 0 lanes arrive with the
+// channel's fp32-rounded sum and sum of squares): the channel's LOCAL moments (S1, S2) = (sum y, sum y^2) in fp64 -- the sums as they
+// are for a well-conditioned channel, rebuilt from the second pass for a refined one (sum y^2 = sum d^2 + 2 m sum d + n m^2 with
+// d = y - m: no cancellation left in fp64).  Result valid in the ty == 0 lanes.
+__device__ __forceinline__ void bn_local_moments(double sum, double sumsq, double (*red)[32][9], int tx, int ty, int c, double n, int C,
+                                                 RefineSrc src, double& S1, double& S2) {
     __shared__ float ref_mu[8];
     __shared__ int ref_need[8];
-    double mu = sum / n;
-    double var = sumsq / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    if (src.y != nullptr) {                  // kernel-uniform
-        if (ty == 0) {
-            ref_need[tx] = (c < C && mu * mu > kRefineRatio * var) ? 1 : 0;
-            ref_mu[tx] = (float)mu;
-        }
-        __syncthreads();
-        const int need = ref_need[tx];
-        if (__syncthreads_or(need)) {        // block-uniform
-            double a0 = 0.0, a1 = 0.0;
-            const float mf = ref_mu[tx];
-            if (need) {
-                const float* col = src.y + c;
-                long long r = ty;
-                for (; r + 7 * 32 < src.M; r += 8 * 32) {
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = col[(r + u * 32) * src.pitch];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { const float d = v[u] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
-                }
-                for (; r < src.M; r += 32) { const float d = col[r * src.pitch] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
-            }
-            __syncthreads();                 // `red` still holds the caller's first-stage values until every lane has read them
-            red[0][ty][tx] = a0;
-            red[1][ty][tx] = a1;
-            __syncthreads();
-            if (ty == 0 && need) {
-                double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) { d0 += red[0][k][tx]; d1 += red[1][k][tx]; }
-                mu = (double)mf + d0 / n;
-                var = (d1 - d0 * d0 / n) / n;
-                if (var < 0.0) var = 0.0;
-            }
-        }
+    S1 = sum;
+    S2 = sumsq;
+    if (src.y == nullptr) return;            // kernel-uniform
+    if (ty == 0) {
+        const double mu = sum / n;
+        double var = sumsq / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        ref_need[tx] = (c < C && mu * mu > kRefineRatio * var) ? 1 : 0;
+        ref_mu[tx] = (float)mu;
     }
-    if (ty != 0 || c >= C) return;
+    __syncthreads();
+    const int need = ref_need[tx];
+    if (!__syncthreads_or(need)) return;     // block-uniform
+    double a0 = 0.0, a1 = 0.0;
+    const float mf = ref_mu[tx];
+    if (need) {
+        const float* col = src.y + c;
+        long long r = ty;
+        for (; r + 7 * 32 < src.M; r += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(r + u * 32) * src.pitch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float d = v[u] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
+        }
+        for (; r < src.M; r += 32) { const float d = col[r * src.pitch] - mf; a0 += (double)d; a1 += (double)d * (double)d; }
+    }
+    __syncthreads();                         // `red` may still hold the caller's first-stage values until every lane has read them
+    red[0][ty][tx] = a0;
+    red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && need) {
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { d0 += red[0][k][tx]; d1 += red[1][k][tx]; }
+        const double m = (double)mf;
+        S1 = n * m + d0;
+        S2 = d1 + 2.0 * m * d0 + n * m * m;
+    }
+}
+
+// Second half: one thread per channel, from the (local, or all-reduced) moments over n values.
+__device__ __forceinline__ void bn_coeffs_from_moments(double S1, double S2, int c, double n, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
+                                                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                                       float* shift, const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
     if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
+    const double mu = S1 / n;
+    double var = S2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
     // torch.nn.BatchNorm2d: 1/sqrt(var + eps); vendored SyncBN (batchnorm.py:125): clamp(var, eps)^-1/2
     const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
     const float mu_f = (float)mu, is_f = (float)is;
@@ -267,6 +275,18 @@ __device__ __forceinline__ void bn_finalize_tail(double sum, double sumsq, doubl
     }
 }
 
+__device__ __forceinline__ void bn_finalize_tail(double sum, double sumsq, double (*red)[32][9], int tx, int ty, int c, double n, int C,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd,
+                                                 float* scale, float* shift, const unsigned* bound_extra, float bound_mul,
+                                                 unsigned* bound_out, RefineSrc src) {
+    double S1, S2;
+    bn_local_moments(sum, sumsq, red, tx, ty, c, n, C, src, S1, S2);
+    if (ty != 0 || c >= C) return;
+    bn_coeffs_from_moments(S1, S2, c, n, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift,
+                           bound_extra, bound_mul, bound_out);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
                                                           float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
@@ -278,6 +298,34 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const bool mine = ty == 0 && c < C;
     bn_finalize_tail(mine ? (double)sums[c] : 0.0, mine ? (double)sums[C + c] : 0.0, red, tx, ty, c, n, C, gamma, beta, eps, momentum, clamp_eps,
                      running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out, src);
+}
+
+// SyncBN, stage 1: this rank's moments in fp64 ([S1 | S2 | count], the buffer ONE all-reduce sums over the ranks), refined like the
+// single-GPU statistics.  Stage 2 (bn_finalize_moments_kernel) is the second half of bn_finalize_kernel, so a one-rank group computes
+// bit for bit what the group-less path does.
+__global__ __launch_bounds__(256) void bn_local_moments_kernel(const float* __restrict__ sums, double n, int C, RefineSrc src,
+                                                               double* __restrict__ moments) {
+    __shared__ double red[2][32][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx;
+    const bool mine = ty == 0 && c < C;
+    double S1, S2;
+    bn_local_moments(mine ? (double)sums[c] : 0.0, mine ? (double)sums[C + c] : 0.0, red, tx, ty, c, n, C, src, S1, S2);
+    if (mine) {
+        moments[c] = S1;
+        moments[C + c] = S2;
+        if (c == 0) moments[2 * C] = n;
+    }
+}
+
+__global__ void bn_finalize_moments_kernel(const double* __restrict__ moments, double n, int C, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float eps, float momentum, int clamp_eps, float* running_mean,
+                                           float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                           const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    bn_coeffs_from_moments(moments[c], moments[C + c], c, n, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd,
+                           scale, shift, bound_extra, bound_mul, bound_out);
 }
 
 // bn_finalize fed directly by the conv epilogue's per-tile partials: the fp64 column combine (column_sum_kernel's
@@ -654,6 +702,27 @@ extern "C" int pylc_bn_finalize_from_partial(const float* partial, int n_rows, d
                                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
     return pylc_bn_finalize_from_partial_ex(partial, n_rows, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean,
                                             invstd, scale, shift, nullptr, 1.f, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, double* moments,
+                                     void* stream) {
+    PYLC_REQUIRE(sums && moments && C > 0 && n > 0, "bn_local_moments: bad arguments");
+    PYLC_REQUIRE(y == nullptr || (y_pitch >= C && M > 0 && (double)M == n), "bn_local_moments: the refinement source must be the n rows the sums cover");
+    hipLaunchKernelGGL(bn_local_moments_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), sums, n, C, RefineSrc{y, y_pitch, M}, moments);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_bn_finalize_moments(const double* moments, double n, int C, const float* gamma, const float* beta, float eps,
+                                        float momentum, int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd,
+                                        float* scale, float* shift, const unsigned int* bound_extra, float bound_mul,
+                                        unsigned int* bound_out, void* stream) {
+    PYLC_REQUIRE(moments && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize_moments: bad arguments");
+    PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_moments: running stats must both be set or both NULL");
+    hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), moments, n, C, gamma, beta, eps, momentum,
+                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
 }
 
 extern "C" int pylc_bn_eval_coeffs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C, float* scale,

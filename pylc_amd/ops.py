@@ -950,19 +950,25 @@ class BnActFn(torch.autograd.Function):
                                                            int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
                                                            ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound), ptr(y), yp, m, st))
             else:
-                sums = torch.empty(2 * c + 1, device=dev)                 # [sum | sumsq | count slot for SyncBN]
+                sums = torch.empty(2 * c, device=dev)                     # [sum | sumsq]
                 if partial is not None:
                     check(lib.pylc_bn_stats_from_partial(ptr(partial), partial.shape[0], c, ptr(sums), st))
                 else:
                     ws = torch.empty(lib.pylc_bn_workspace_floats(m, c), device=dev)
                     check(lib.pylc_bn_stats(ptr(y), m, c, yp, ptr(sums), ptr(ws), st))
                 if group is not None:
-                    sums[2 * c] = float(m)
-                    _runtime.sync_all_reduce(sums, group)
+                    # SyncBN: this rank's moments in fp64 [sum | sumsq | count], ONE all-reduce, coefficients from the global moments
+                    moments = torch.empty(2 * c + 1, device=dev, dtype=torch.float64)
+                    check(lib.pylc_bn_local_moments(ptr(sums), float(m), c, ptr(y), yp, m, ptr(moments), st))
+                    _runtime.sync_all_reduce(moments, group)
                     n_global = float(m) * dist.get_world_size(group)      # equal shards (checked by parallel.init_from_env / DataParallel setup)
-                check(lib.pylc_bn_finalize_ex(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
-                                              ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                              ptr(res_amax), mul, ptr(bound), None if group is not None else ptr(y), yp, m, st))
+                    check(lib.pylc_bn_finalize_moments(ptr(moments), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
+                                                       ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                                       ptr(res_amax), mul, ptr(bound), st))
+                else:
+                    check(lib.pylc_bn_finalize_ex(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
+                                                  ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                                  ptr(res_amax), mul, ptr(bound), ptr(y), yp, m, st))
         else:
             check(lib.pylc_bn_eval_coeffs_full(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
                                                ptr(scale), ptr(shift), ptr(mean), ptr(invstd), st))

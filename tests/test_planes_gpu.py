@@ -187,3 +187,42 @@ def test_bottleneck_block_planes_vs_fp32(dev, f16x3):
     assert ops.plane_conversions[0] >= 0
     for name, a, b in zip(('y', 'dx', 'param grads'), res['fp32'], res['planes']):
         assert rel(b, a) < 3e-5, (name, rel(b, a))
+
+
+@pytest.fixture
+def fp16_single(dev):
+    from pylc_amd.lib import lib, check
+    from pylc_amd import runtime, ops
+    prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
+    check(lib.pylc_set_conv_precision(3))
+    ops.PLANES_MIN_PIXELS = 0
+    yield
+    ops.PLANES_MIN_PIXELS = prev_min
+    check(lib.pylc_set_conv_precision(prev))
+    runtime.no_planes = False
+
+
+@pytest.mark.parametrize('case', PLANES_CONV_CASES)
+def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
+    """Precision mode 3: the same kernels with ONE fp16 plane per operand (NTERMS = 1) -- y, dx, dw against fp64 on the operands as given:
+    each operand carries a relative rounding of 2^-12, a sum of K products sqrt(2) 2^-12 of its typical term, so errors relative to the
+    largest output stay below 1e-3 at every K of these cases (measured 1e-4..4e-4)."""
+    from pylc_amd import ops, layers, optim
+    cin, cout, k, st, pad, dil, B, H, W = case
+    torch.manual_seed(3)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil).to(dev)
+    arena = optim.FlatArena(conv)
+    assert ops.nplanes() == 1
+    x = nhwc(rnd(5, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    y = conv(x)
+    dy = nhwc(rnd(6, *y.shape), dev)
+    y.backward(dy)
+    ops.sync_side_streams()
+    torch.cuda.synchronize()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wr = conv.weight.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, st, pad, dil)
+    yr.backward(dy.double().cpu())
+    e = (rel(y.detach(), yr.detach()), rel(x.grad, xr.grad), rel(conv.weight.grad.detach(), wr.grad))
+    print('mode 3 %s: y %.2e dx %.2e dw %.2e' % (case, *e))
+    assert max(e) < 1e-3, e
