@@ -109,6 +109,8 @@ struct GatherGemmArgs {
     int nterms;                   // conv_pl.hip: 3 = f16x3 (both planes of both operands), 1 = plain fp16 (plane 0 only)
     int tile_bm;                  // conv_pl.hip (set by launch_gg_pl): pixel rows per tile = rows per statistics partial
     int ident;                    // conv_pl.hip (set by launch_gg_pl): 1x1 / stride 1 / no padding -- input pixel == output pixel
+    int stagger, stagger_blocks;  // conv_pl.hip (set by launch_gg_pl): start delay (units of 2048 cycles) of the SECOND block of each CU among
+                                  // the first `stagger_blocks` blocks of the grid (128-row tiles, several rounds of blocks)
     int dbg_flags;           // tools/pp_stamps.py: 16 = finer stamps inside the store segment (STAMPS build only)
     unsigned long long* dbg; // debug builds of the ping-pong kernel: per-segment clock stamps of block 0 (else null)
     float* stats;           // optional [tiles_m][2][N_store]: per-M-tile column sums / sums of squares of the stored values (BatchNorm)

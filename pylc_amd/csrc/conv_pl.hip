@@ -197,6 +197,18 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: LDS-DMA destinations live in M0
     const int wave_m = wave >> 1, wave_n = wave & 1;
+    if constexpr (BM == 128) {
+        // All tiles of a launch cost the same, so the two blocks of a CU run in lockstep: both in their main loops (two waves per SIMD
+        // competing for the matrix pipe), then both in their epilogues (the whole chip storing at once: on the short reductions of
+        // the 1x1 convs the stores of a round are an HBM-rate burst as long as the main loop, during which no MFMA issues).  Delaying
+        // the SECOND block of each CU (the one whose LDS allocation does not start at 0) by about half a tile, once, in the first
+        // round, puts one block's epilogue and prologue under the other's main loop for the rest of the launch.
+        if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks) {
+            const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);     // HW_REG_LDS_ALLOC.LDS_BASE
+            if (lds_base != 0)
+                for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);                 // 32 x 64 cycles
+        }
+    }
     const int lrow = lane >> 2;                                         // loader: 4 lanes per 64-byte row, 16 rows per DMA instruction
     const int lc = (lane & 3) ^ (((lane >> 4) & 1) << 1);               // logical chunk this lane fetches for its LDS position
     const bool ident = a.ident != 0;
@@ -399,6 +411,11 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             issue(0);
             if (S > 1) issue(1);
             int sc = 0, sn = 2;                                  // stage of the tile being computed / of the tile being requested
+            // The waves of a block pass the barrier together, and a wave whose DMA issue waits for room in the CU's (saturated) load
+            // queue issues no MFMAs: in lockstep the step costs DMA time PLUS MFMA time.  So the two waves of every SIMD (w, w + 4)
+            // take opposite orders -- the first requests tile s+2 and then computes tile s, the second computes and then requests:
+            // while one waits on the queue its partner owns the matrix pipe.  (Debug flag 32768: all waves request first.)
+            const bool late = wave >= NW / 2 && !(a.dbg_flags & 32768);
             for (int s = 0; s < S; ++s) {
                 PL_STAMP();
                 if (s + 1 < S) {
@@ -410,10 +427,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 PL_STAMP();
-                if (s + 2 < S && !(STAMPS && (a.dbg_flags & 64))) issue(sn);
+                if (!late && s + 2 < S && !(STAMPS && (a.dbg_flags & 64))) issue(sn);
                 __builtin_amdgcn_sched_barrier(0);
                 PL_STAMP();
                 if (!(STAMPS && (a.dbg_flags & 128))) compute(sc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (late && s + 2 < S && !(STAMPS && (a.dbg_flags & 64))) issue(sn);
                 __builtin_amdgcn_sched_barrier(0);
                 sc = sc == 2 ? 0 : sc + 1;
                 sn = sn == 2 ? 0 : sn + 1;
@@ -630,6 +649,9 @@ template __global__ void gg_pl_kernel<3, 256, true>(const GatherGemmArgs);
 
 // geometry / size conditions on top of: A operand given as planes, prepared filter planes present
 
+int g_stagger = -1;        // < 0: the launch heuristic; >= 0: forced start delay in 2048-cycle units (pylc_debug_stagger)
+extern "C" int pylc_debug_stagger(int units) { g_stagger = units; return PYLC_OK; }
+
 // geometry / size conditions on top of: A operand given as planes, prepared filter planes present
 bool takes_pl(const GatherGemmArgs& a) {
     const bool aligned = a.y_pitch % 4 == 0 && a.N_store % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
@@ -681,6 +703,14 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     const long long n_tiles = (long long)cdiv(a.M, bm) * a.tiles_n;
     PYLC_REQUIRE(n_tiles > 0 && n_tiles < (1ll << 31), "conv grid out of range");
     a.n_tiles = (int)n_tiles;
+    a.stagger = 0;
+    a.stagger_blocks = 2 * kNumCU;
+    if (!big && n_tiles >= 3 * kNumCU) {             // at least two rounds of blocks: the one-off delay pays back
+        // half a tile of this launch: ~1200 cycles per K-step of a block that shares its SIMDs + half the epilogue / prologue
+        const long long cycles = (ksteps * 1200 + 8000) / 2;
+        a.stagger = (int)(cycles / 2048);
+        if (g_stagger >= 0) a.stagger = g_stagger;   // A/B knob (pylc_debug_stagger)
+    }
     if (a.nterms == 1) {
         if (big) launch_pl<1, 256>(a, (unsigned)n_tiles, st); else launch_pl<1, 128>(a, (unsigned)n_tiles, st);
     } else {

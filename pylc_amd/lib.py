@@ -60,6 +60,7 @@ SIGNATURES = {
     'pylc_get_conv_precision': (_I, []),
     'pylc_debug_set_big_tile': (_I, [_I]),
     'pylc_debug_pp_flags': (_I, [_I]),
+    'pylc_debug_stagger': (_I, [_I]),
     'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),

@@ -1,0 +1,57 @@
+"""A/B of the start stagger of conv_pl.hip's 128-row kernel (second block of each CU delayed by about half a tile in the first round):
+per-shape time with no delay, the launch heuristic and a sweep, plus bit-identity.   usage: python tools/pl_stagger_ab.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pylc_amd import ops, layers, optim
+from pylc_amd.lib import lib
+
+dev = torch.device('cuda:0')
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+SHAPES = [  # B, H, Cin, Cout, k, stride, pad, dil
+    (32, 32, 256, 1024, 1, 1, 0, 1),
+    (32, 32, 1024, 256, 1, 1, 0, 1),
+    (32, 64, 128, 512, 1, 1, 0, 1),
+    (32, 64, 512, 128, 1, 1, 0, 1),
+    (32, 128, 64, 256, 1, 1, 0, 1),
+    (32, 128, 256, 64, 1, 1, 0, 1),
+    (32, 32, 512, 2048, 1, 1, 0, 1),
+    (32, 32, 2048, 512, 1, 1, 0, 1),
+    (32, 64, 128, 128, 3, 1, 1, 1),
+    (32, 32, 256, 256, 3, 1, 1, 1),
+]
+
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+for (B, H, cin, cout, k, st, pad, dil) in SHAPES:
+    torch.manual_seed(1)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil, bn=True).to(dev)
+    arena = optim.FlatArena(conv)
+    x = ops.empty_nhwc(B, cin, H, H, dev)
+    x.copy_(torch.randn(B, cin, H, H, device=dev) * 3)
+    xp = ops.to_planes(x)
+    fl = 2.0 * B * (H // st) ** 2 * cout * k * k * cin
+    lib.pylc_debug_pp_flags(1024 | 2048 | 16384)          # the 128-row planes kernel
+    res = []
+    ref = None
+    with torch.no_grad():
+        for units in (0, -1, 0, 1, 2, 3, 4, 6, 8, 12, 16, 24):
+            lib.pylc_debug_stagger(units)
+            y = ops.conv2d(xp, conv.weight, None, st, pad, dil, want_stats=True)
+            if ref is None:
+                ref = y.clone()
+            assert torch.equal(y, ref)
+            t = timeit(lambda: ops.conv2d(xp, conv.weight, None, st, pad, dil, want_stats=True))
+            res.append('%s:%.0f' % ('auto' if units < 0 else units, 1e3 * t))
+    print('%-34s' % str((B, H, cin, cout, k, st, pad, dil)), 'us by delay ', ' '.join(res), flush=True)
+lib.pylc_debug_stagger(-1)
+lib.pylc_debug_pp_flags(0)
