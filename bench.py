@@ -56,21 +56,42 @@ def synth(rank, b, ch, hw, n_cls, dev):
     return x, y
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources: ties a committed PMC profile to the build it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'pylc_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'pylc_amd', 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact).
-    PMC collection needs the profiler, so it cannot be measured live here; None if no profile is committed."""
+    """HBM bytes per launch of `kernel` ('a<..,*> + b<..>': every instantiation with one of those prefixes) from the committed
+    rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950
+    correction, WRITE_SIZE exact).  PMC collection needs the profiler, so it cannot be measured live here: the value comes with its
+    provenance -- the profile file, the kernel-source fingerprint it was taken on and whether that is THIS build's.  (None, None) if no
+    profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if not files:
-        return None
-    want = ''.join(kernel.split()).split('*')[0]          # 'name<a,b,*>' matches every instantiation with that prefix
+        return None, None
+    prof = json.load(open(files[-1]))
+    wants = [''.join(k.split()).split('*')[0] for k in kernel.split('+')]
     tot_bytes = tot_n = 0.0
-    for name, v in json.load(open(files[-1])).items():
-        if want in ''.join(name.split()):
+    for name, v in prof.items():
+        if name.startswith('_'):
+            continue
+        flat = ''.join(name.split())
+        if any(w in flat for w in wants):
             tot_bytes += v['hbm_bytes_per_launch'] * v['launches']
             tot_n += v['launches']
-    return tot_bytes / tot_n if tot_n else None
+    meta = prof.get('_meta', {})
+    src = {'file': os.path.relpath(files[-1], ROOT), 'measured_on_csrc_sha256': meta.get('csrc_sha256'),
+           'this_build_csrc_sha256': csrc_fingerprint(), 'launches_in_profile': int(tot_n)}
+    src['same_build'] = src['measured_on_csrc_sha256'] == src['this_build_csrc_sha256']
+    return (tot_bytes / tot_n if tot_n else None), src
 
 
 def cpu_baseline(hw, n_cls, budget_s=25.0):
@@ -238,7 +259,7 @@ def main():
     }
     if timer is not None:
         out['roofline'] = timer.roofline(PEAK_BF16_MFMA_TFLOPS)
-        out['roofline']['traffic'] = pmc_traffic(out['roofline']['kernel'])
+        out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic(out['roofline']['kernel'])
     if world == 1 and not args.no_cpu_baseline and args.config == 'c3':
         out['cpu_baseline'] = cpu_baseline(args.tile, args.classes)
     print(json.dumps(out), flush=True)

@@ -133,7 +133,8 @@ int pylc_conv2d_fwd_bnact(const PylcConvDesc* d, const float* x, const float* w_
                           unsigned int* amax_out, void* stream);
 /* pylc_conv2d_fwd that additionally emits per-M-tile partial column sums of y for the BatchNorm that follows (saves a full read
  * of y): stats_partial has pylc_conv2d_fwd_stats_floats(d) floats, laid out [rows][2][roundup4(Cout)] = (sum | sum of
- * squares); *stats_rows receives the number of rows written.  Combine with pylc_bn_stats_from_partial. */
+ * squares) of (y - bias) -- taken BEFORE the bias is added, so that a bias much larger than the spread does not cost the variance its
+ * digits; pass the bias as `stat_shift` to the finalize.  *stats_rows receives the number of rows written. */
 size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d);
 int pylc_conv2d_fwd_stats(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
                           float* y, float* stats_partial, int* stats_rows, void* stream);
@@ -245,23 +246,29 @@ typedef struct PylcBnExtra {
  * y (may be NULL) / y_pitch / M == n: the tensor the sums were taken over.  With it, a channel whose mean^2 exceeds 64 var -- where
  * sumsq/n - mean^2 from fp32 sums no longer carries the variance -- is re-measured in a second pass as sum((y - mean)^2), so the result
  * follows torch.nn.BatchNorm2d's two-pass / Welford statistics (what the reference's non-SyncBN layers run) at any mean / sigma ratio.
- * Pass NULL for all-reduced sums: the vendored SyncBN itself exchanges [sum, sumsq] in fp32 (sync_batchnorm/batchnorm.py:78-103). */
+ * stat_shift (may be NULL): per-channel K when the sums are of (y - K) and (y - K)^2 -- the conv epilogues take their statistics before
+ * the bias is added (a bias that dwarfs the spread, U-Net's first layer, is the common ill-conditioned case and costs nothing this
+ * way); the mean returned is K + sum / n.  For all-reduced statistics use pylc_bn_local_moments / pylc_bn_finalize_moments. */
 int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                         int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                         float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out,
-                        const float* y, int y_pitch, long long M, void* stream);
+                        const float* y, int y_pitch, long long M, const float* stat_shift, void* stream);
 int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
                                      float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                      float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
-                                     float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M, void* stream);
+                                     float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M,
+                                     const float* stat_shift, void* stream);
 /* SyncBN in two stages around ONE all-reduce (sync_batchnorm/batchnorm.py:48-125 exchanges [sum, ssum, size] per layer): stage 1 turns
  * this rank's fp32 sums over its n rows into fp64 moments [sum y | sum y^2 | n] (2C + 1 doubles), re-measuring ill-conditioned channels
  * from y as pylc_bn_finalize_ex does; the caller all-reduces the buffer (SUM); stage 2 derives the coefficients from the global moments
- * over n = the summed count.  With one rank the result equals pylc_bn_finalize_ex bit for bit. */
-int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, double* moments, void* stream);
+ * over n = the summed count.  With one rank the result equals pylc_bn_finalize_ex bit for bit.  stat_shift: as pylc_bn_finalize_ex (the
+ * same K on every rank: a conv bias is a replicated parameter). */
+int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, const float* stat_shift,
+                          double* moments, void* stream);
 int pylc_bn_finalize_moments(const double* moments, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                              int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                             float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out, void* stream);
+                             float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out,
+                             const float* stat_shift, void* stream);
 int pylc_bn_apply_ex(const float* y, int y_pitch, const float* scale, const float* shift, const float* residual, int res_pitch,
                      float* out, int out_pitch, long long M, int C, int relu, unsigned int* amax_out, const PylcBnExtra* ex,
                      void* stream);

@@ -195,11 +195,13 @@ __device__ __forceinline__ void bn_commit_bound(float gamma, float beta, double 
 // sums in fp64.  Costs nothing for well-conditioned channels (all of them in the networks of this package); the pass itself is a
 // strided column read by the 32 row lanes of the finalize block.
 constexpr double kRefineRatio = 64.0;
+constexpr double kRefineFloor = 1e-5;    // the BatchNorm eps of every layer of this path: a variance far below it does not need its digits
 
 struct RefineSrc {
-    const float* y;       // NULL: no refinement (SyncBN: the reference's own exchange is [sum, sumsq] in fp32, batchnorm.py:78-103)
+    const float* y;       // NULL: no second pass
     int pitch;
     long long M;
+    const float* shift;   // NULL, or per-channel K: the sums are of (y - K) and (y - K)^2 (a conv's statistics are taken before its bias)
 };
 
 // First half of a finalize (all 256 threads of the block: 8 channels (tx) x 32 row lanes (ty); the ty == 0 lanes arrive with the
@@ -213,12 +215,14 @@ __device__ __forceinline__ void bn_local_moments(double sum, double sumsq, doubl
     S1 = sum;
     S2 = sumsq;
     if (src.y == nullptr) return;            // kernel-uniform
+    const double K = (src.shift != nullptr && c < C) ? (double)src.shift[c] : 0.0;
     if (ty == 0) {
-        const double mu = sum / n;
+        const double mu = sum / n;           // mean of (y - K)
         double var = sumsq / n - mu * mu;
         if (var < 0.0) var = 0.0;
-        ref_need[tx] = (c < C && mu * mu > kRefineRatio * var) ? 1 : 0;
-        ref_mu[tx] = (float)mu;
+        // the rounding of sum(x^2) is ~2^-22 mu^2: re-measure where that is more than 2^-16 of what the coefficient depends on
+        ref_need[tx] = (c < C && mu * mu > kRefineRatio * (var + kRefineFloor)) ? 1 : 0;
+        ref_mu[tx] = (float)(K + mu);
     }
     __syncthreads();
     const int need = ref_need[tx];
@@ -245,21 +249,22 @@ __device__ __forceinline__ void bn_local_moments(double sum, double sumsq, doubl
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) { d0 += red[0][k][tx]; d1 += red[1][k][tx]; }
-        const double m = (double)mf;
+        const double m = (double)mf - K;     // back to moments of (y - K)
         S1 = n * m + d0;
         S2 = d1 + 2.0 * m * d0 + n * m * m;
     }
 }
 
 // Second half: one thread per channel, from the (local, or all-reduced) moments over n values.
-__device__ __forceinline__ void bn_coeffs_from_moments(double S1, double S2, int c, double n, const float* __restrict__ gamma,
+__device__ __forceinline__ void bn_coeffs_from_moments(double S1, double S2, double K, int c, double n, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float momentum, int clamp_eps,
                                                        float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                                        float* shift, const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
     if (bound_out != nullptr) bn_commit_bound(gamma[c], beta[c], n, bound_extra, bound_mul, bound_out);
-    const double mu = S1 / n;
-    double var = S2 / n - mu * mu;
+    const double mk = S1 / n;                // moments of (y - K)
+    double var = S2 / n - mk * mk;
     if (var < 0.0) var = 0.0;
+    const double mu = K + mk;
     // torch.nn.BatchNorm2d: 1/sqrt(var + eps); vendored SyncBN (batchnorm.py:125): clamp(var, eps)^-1/2
     const double is = clamp_eps ? 1.0 / sqrt(var > (double)eps ? var : (double)eps) : 1.0 / sqrt(var + (double)eps);
     const float mu_f = (float)mu, is_f = (float)is;
@@ -283,8 +288,8 @@ __device__ __forceinline__ void bn_finalize_tail(double sum, double sumsq, doubl
     double S1, S2;
     bn_local_moments(sum, sumsq, red, tx, ty, c, n, C, src, S1, S2);
     if (ty != 0 || c >= C) return;
-    bn_coeffs_from_moments(S1, S2, c, n, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift,
-                           bound_extra, bound_mul, bound_out);
+    bn_coeffs_from_moments(S1, S2, src.shift != nullptr ? (double)src.shift[c] : 0.0, c, n, gamma, beta, eps, momentum, clamp_eps, running_mean,
+                           running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, double n, int C, const float* __restrict__ gamma,
@@ -321,11 +326,11 @@ __global__ __launch_bounds__(256) void bn_local_moments_kernel(const float* __re
 __global__ void bn_finalize_moments_kernel(const double* __restrict__ moments, double n, int C, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, float eps, float momentum, int clamp_eps, float* running_mean,
                                            float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                                           const unsigned* bound_extra, float bound_mul, unsigned* bound_out) {
+                                           const unsigned* bound_extra, float bound_mul, unsigned* bound_out, const float* stat_shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    bn_coeffs_from_moments(moments[c], moments[C + c], c, n, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd,
-                           scale, shift, bound_extra, bound_mul, bound_out);
+    bn_coeffs_from_moments(moments[c], moments[C + c], stat_shift != nullptr ? (double)stat_shift[c] : 0.0, c, n, gamma, beta, eps, momentum,
+                           clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
 }
 
 // bn_finalize fed directly by the conv epilogue's per-tile partials: the fp64 column combine (column_sum_kernel's
@@ -662,13 +667,13 @@ extern "C" int pylc_bn_stats_from_partial(const float* partial, int n_rows, int 
 extern "C" int pylc_bn_finalize_ex(const float* sums, double n, int C, const float* gamma, const float* beta, float eps, float momentum,
                                    int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                    float* shift, const unsigned int* bound_extra, float bound_mul, unsigned int* bound_out,
-                                   const float* y, int y_pitch, long long M, void* stream) {
+                                   const float* y, int y_pitch, long long M, const float* stat_shift, void* stream) {
     PYLC_REQUIRE(sums && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must both be set or both NULL");
     PYLC_REQUIRE(y == nullptr || (y_pitch >= C && M > 0 && (double)M == n), "bn_finalize: the refinement source must be the n rows the sums cover");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), sums, n, C, gamma, beta, eps, momentum,
                        clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out,
-                       RefineSrc{y, y_pitch, M});
+                       RefineSrc{y, y_pitch, M, stat_shift});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -677,14 +682,14 @@ extern "C" int pylc_bn_finalize(const float* sums, double n, int C, const float*
                                 int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                 float* shift, void* stream) {
     return pylc_bn_finalize_ex(sums, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift,
-                               nullptr, 1.f, nullptr, nullptr, 0, 0, stream);
+                               nullptr, 1.f, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows, double n, int C, const float* gamma, const float* beta,
                                                 float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                                 float* mean, float* invstd, float* scale, float* shift, const unsigned int* bound_extra,
                                                 float bound_mul, unsigned int* bound_out, const float* y, int y_pitch, long long M,
-                                                void* stream) {
+                                                const float* stat_shift, void* stream) {
     PYLC_REQUIRE(partial && n_rows > 0 && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0,
                  "bn_finalize_from_partial: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_from_partial: running stats must both be set or both NULL");
@@ -692,7 +697,7 @@ extern "C" int pylc_bn_finalize_from_partial_ex(const float* partial, int n_rows
                  "bn_finalize_from_partial: the refinement source must be the n rows the partials cover");
     hipLaunchKernelGGL(bn_finalize_partial_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), partial, n_rows, n, C, gamma, beta, eps,
                        momentum, clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out,
-                       RefineSrc{y, y_pitch, M});
+                       RefineSrc{y, y_pitch, M, stat_shift});
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -701,14 +706,15 @@ extern "C" int pylc_bn_finalize_from_partial(const float* partial, int n_rows, d
                                              float eps, float momentum, int clamp_eps, float* running_mean, float* running_var,
                                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
     return pylc_bn_finalize_from_partial_ex(partial, n_rows, n, C, gamma, beta, eps, momentum, clamp_eps, running_mean, running_var, mean,
-                                            invstd, scale, shift, nullptr, 1.f, nullptr, nullptr, 0, 0, stream);
+                                            invstd, scale, shift, nullptr, 1.f, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
-extern "C" int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, double* moments,
-                                     void* stream) {
+extern "C" int pylc_bn_local_moments(const float* sums, double n, int C, const float* y, int y_pitch, long long M, const float* stat_shift,
+                                     double* moments, void* stream) {
     PYLC_REQUIRE(sums && moments && C > 0 && n > 0, "bn_local_moments: bad arguments");
     PYLC_REQUIRE(y == nullptr || (y_pitch >= C && M > 0 && (double)M == n), "bn_local_moments: the refinement source must be the n rows the sums cover");
-    hipLaunchKernelGGL(bn_local_moments_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), sums, n, C, RefineSrc{y, y_pitch, M}, moments);
+    hipLaunchKernelGGL(bn_local_moments_kernel, dim3(cdiv(C, 8)), dim3(256), 0, as_stream(stream), sums, n, C, RefineSrc{y, y_pitch, M, stat_shift},
+                       moments);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
@@ -716,11 +722,11 @@ extern "C" int pylc_bn_local_moments(const float* sums, double n, int C, const f
 extern "C" int pylc_bn_finalize_moments(const double* moments, double n, int C, const float* gamma, const float* beta, float eps,
                                         float momentum, int clamp_eps, float* running_mean, float* running_var, float* mean, float* invstd,
                                         float* scale, float* shift, const unsigned int* bound_extra, float bound_mul,
-                                        unsigned int* bound_out, void* stream) {
+                                        unsigned int* bound_out, const float* stat_shift, void* stream) {
     PYLC_REQUIRE(moments && gamma && beta && mean && invstd && scale && shift && C > 0 && n > 0, "bn_finalize_moments: bad arguments");
     PYLC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_moments: running stats must both be set or both NULL");
     hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), moments, n, C, gamma, beta, eps, momentum,
-                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out);
+                       clamp_eps, running_mean, running_var, mean, invstd, scale, shift, bound_extra, bound_mul, bound_out, stat_shift);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

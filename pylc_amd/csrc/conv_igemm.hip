@@ -363,10 +363,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gather_gemm_ker
                 if (extra != nullptr) val += prev[r];
                 if (a.ep_relu) val = fmaxf(val, 0.f);
                 vals[r] = val;
-                const float cv = (nok && offs[r] >= 0) ? val : 0.f;  // rows / channels outside the tensor do not count
+                const bool counted = nok && offs[r] >= 0;            // rows / channels outside the tensor do not count
+                // statistics are taken of (stored value - bias): a conv whose bias dwarfs its spread (U-Net's first layer on the
+                // 1/255-scaled input: |mean| / sigma ~ 20) would otherwise lose its variance in sum(y^2)/n - mean^2; the finalize adds
+                // the bias back to the mean (pylc_bn_finalize*_ex `shift`).  bv == 0 leaves every bit as it was.
+                const float cv = counted ? val - bv : 0.f;
                 cs += cv;
                 css += cv * cv;
-                ep_max = fmaxf(ep_max, fabsf(cv));
+                ep_max = fmaxf(ep_max, counted ? fabsf(val) : 0.f);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -901,10 +905,10 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                     if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
                     if (EP && a.ep_relu) val = fmaxf(val, 0.f);
                     acc[i][j][r] = val;
-                    const float cv = stored ? val : 0.f;                 // rows / channels outside the tensor do not count
-                    cs[r] += cv;
+                    const float cv = stored ? val - bv[j][r] : 0.f;      // rows / channels outside the tensor do not count; statistics of
+                    cs[r] += cv;                                         // (value - bias), see gather_gemm_kernel's epilogue
                     css[r] += cv * cv;
-                    if (EP) ep_max = fmaxf(ep_max, fabsf(cv));
+                    if (EP) ep_max = fmaxf(ep_max, stored ? fabsf(val) : 0.f);
                 }
             }
             if (do_stats) {                                         // the 16 lanes of a DPP row hold the 16 pixel rows of one channel quad
@@ -992,8 +996,8 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
                     if (extra != nullptr) val += prev[r];
                     if (EP && a.ep_relu) val = fmaxf(val, 0.f);
                     a.y[offs[r] + n] = val;
-                    cs += val;
-                    css += val * val;
+                    cs += val - bv;                                  // statistics of (value - bias), see gather_gemm_kernel's epilogue
+                    css += (val - bv) * (val - bv);
                     if (EP) ep_max = fmaxf(ep_max, fabsf(val));
                 }
             }

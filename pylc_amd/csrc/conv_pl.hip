@@ -107,7 +107,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                     float val = acc[i][j][r] + bv[j][r];
                     if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
                     acc[i][j][r] = val;
-                    const float cv = stored ? val : 0.f;
+                    const float cv = stored ? val - bv[j][r] : 0.f;      // statistics of (value - bias): conv_igemm.hip's epilogue
                     cs[r] += cv;
                     css[r] += cv * cv;
                 }

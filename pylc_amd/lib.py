@@ -87,10 +87,10 @@ SIGNATURES = {
     'pylc_bn_eval_coeffs': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     'pylc_bn_eval_coeffs_full': (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P]),
     'pylc_bn_finalize_from_partial': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'pylc_bn_finalize_ex': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _LL, _P]),
-    'pylc_bn_local_moments': (_I, [_P, _D, _I, _P, _I, _LL, _P, _P]),
-    'pylc_bn_finalize_moments': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
-    'pylc_bn_finalize_from_partial_ex': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _LL, _P]),
+    'pylc_bn_finalize_ex': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _LL, _P, _P]),
+    'pylc_bn_local_moments': (_I, [_P, _D, _I, _P, _I, _LL, _P, _P, _P]),
+    'pylc_bn_finalize_moments': (_I, [_P, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    'pylc_bn_finalize_from_partial_ex': (_I, [_P, _I, _D, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _LL, _P, _P]),
     'pylc_bn_apply_ex': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _LL, _I, _I, _P, C.POINTER(BnExtra), _P]),
     'pylc_bn_bwd_reduce_ex': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P, _D, C.POINTER(BnExtra), _P, _P]),
     'pylc_bn_bwd_bound': (_I, [_P, _P, _P, _D, _I, _P, _P, _P]),

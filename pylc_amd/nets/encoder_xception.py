@@ -56,8 +56,11 @@ class Block(nn.Module):
                 self.rep.add_module(str(i), item)
                 self.plan.append(('bn' if isinstance(item, BatchNorm2d) else 'sep', str(i)))
 
-    def forward(self, inp):
-        if self.start_with_relu:
+    def forward(self, inp, input_relud=False, relu_out=False):
+        """input_relud: the caller already applied this block's leading ReLU (fused into the pass that produced `inp`: because of the
+        aliasing quirk below nothing ever reads the un-rectified tensor).  relu_out: apply the NEXT block's leading ReLU (or the
+        explicit one of xception.py:200 / :222) in this block's last pass."""
+        if self.start_with_relu and not input_relud:
             inp = ops.relu(inp)                   # aliasing quirk: both branches see relu(inp)
         if self.skip is not None:
             skip = self.skipbn(self.skip(inp))
@@ -72,7 +75,7 @@ class Block(nn.Module):
                 x = getattr(self.rep, name)(x)
             elif kind == 'bn':
                 if i == n - 1:          # the branch ends in a BatchNorm: `rep(inp) + skip` (xception.py:97) is its apply pass
-                    return getattr(self.rep, name)(x, residual=skip, relu=False)      # (y*scale + shift) + skip: the same two fp32 operations
+                    return getattr(self.rep, name)(x, residual=skip, relu=relu_out)   # (y*scale + shift) + skip: the same two fp32 operations
                 fuse = self.plan[i + 1][0] == 'relu'                   # BN followed by the shared ReLU -> one pass
                 x = getattr(self.rep, name)(x, relu=fuse)
                 if fuse:
@@ -80,7 +83,7 @@ class Block(nn.Module):
             else:
                 x = ops.relu(x)
             i += 1
-        return x + skip
+        return ops.relu(x + skip) if relu_out else x + skip
 
 
 class AlignedXception(nn.Module):
@@ -112,11 +115,12 @@ class AlignedXception(nn.Module):
     def forward(self, x4):
         x = self.bn1(self.conv1(x4), relu=True)
         x = self.bn2(self.conv2(x), relu=True)
-        low = ops.relu(self.block1(x))            # xception.py:199-202
-        x = self.block3(self.block2(low))
-        for i in range(4, 21):
-            x = getattr(self, 'block%d' % i)(x)
-        x = ops.relu(x)
+        # every block output is read through a ReLU only (xception.py:200 explicitly; blocks 3..20 through the in-place ReLU that
+        # leads their `rep` and aliases the skip input, :53-97; the exit flow's :222), so the ReLU runs in the producing BatchNorm pass
+        low = self.block1(x, relu_out=True)       # xception.py:199-202
+        x = self.block2(low, relu_out=True)
+        for i in range(3, 21):
+            x = getattr(self, 'block%d' % i)(x, input_relud=True, relu_out=True)
         x = self.bn3(self.conv3(x), relu=True)
         x = self.bn4(self.conv4(x), relu=True)
         x = self.bn5(self.conv5(x), relu=True)

@@ -182,8 +182,9 @@ class KernelTimer:
         self.mode = lib.pylc_get_conv_precision()
         self.planes = self.mode >= 2 and not _runtime.no_planes
         # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
-        # activations travel as planes; '*' = both instantiations (rocprof lists them as two rows)
-        self.KERNEL = ('gg_pl_kernel<%d,*>' % (3 if self.mode == 2 else 1) if self.planes else
+        # activations travel as planes; '*' = both tile heights (rocprof lists them as two rows) and the 3x3 halo variant: one kernel
+        # family (conv_pl.hip), the same loop body, dispatched by shape
+        self.KERNEL = ('gg_pl_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 2) if self.planes else
                        'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
                        'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
 
@@ -713,6 +714,8 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1, want_stats=False, res_link=N
     if want_stats:
         y, sums = Conv2dFn.apply(x, w, bias, stride, pad, dil, True, xa, wa, res_link, out, torch.is_grad_enabled())
         y._pylc_sums = sums
+        if bias is not None:
+            sums._pylc_shift = bias.detach()      # the epilogue takes the statistics of (y - bias): the finalize adds it back to the mean
     else:
         y = Conv2dFn.apply(x, w, bias, stride, pad, dil, False, xa, wa, res_link, out, torch.is_grad_enabled())
     fn = y.grad_fn
@@ -944,11 +947,13 @@ class BnActFn(torch.autograd.Function):
         mul = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         if training:
             partial = pre_sums if (pre_sums is not None and pre_sums.dim() == 2 and pre_sums.shape[1] == 2 * c) else None
+            kshift = getattr(partial, '_pylc_shift', None) if partial is not None else None
             if partial is not None and group is None:
                 # statistics came out of the conv epilogue as per-tile partials: combine + coefficients in one launch
                 check(lib.pylc_bn_finalize_from_partial_ex(ptr(partial), partial.shape[0], n_global, c, ptr(gamma), ptr(beta), eps, momentum,
                                                            int(clamp_eps), ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd),
-                                                           ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound), ptr(y), yp, m, st))
+                                                           ptr(scale), ptr(shift), ptr(res_amax), mul, ptr(bound),
+                                                           ptr(y) if _runtime.bn_refine else None, yp, m, ptr(kshift), st))
             else:
                 sums = torch.empty(2 * c, device=dev)                     # [sum | sumsq]
                 if partial is not None:
@@ -959,16 +964,17 @@ class BnActFn(torch.autograd.Function):
                 if group is not None:
                     # SyncBN: this rank's moments in fp64 [sum | sumsq | count], ONE all-reduce, coefficients from the global moments
                     moments = torch.empty(2 * c + 1, device=dev, dtype=torch.float64)
-                    check(lib.pylc_bn_local_moments(ptr(sums), float(m), c, ptr(y), yp, m, ptr(moments), st))
+                    check(lib.pylc_bn_local_moments(ptr(sums), float(m), c, ptr(y) if _runtime.bn_refine else None, yp, m, ptr(kshift),
+                                                    ptr(moments), st))
                     _runtime.sync_all_reduce(moments, group)
                     n_global = float(m) * dist.get_world_size(group)      # equal shards (checked by parallel.init_from_env / DataParallel setup)
                     check(lib.pylc_bn_finalize_moments(ptr(moments), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
                                                        ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                                       ptr(res_amax), mul, ptr(bound), st))
+                                                       ptr(res_amax), mul, ptr(bound), ptr(kshift), st))
                 else:
                     check(lib.pylc_bn_finalize_ex(ptr(sums), n_global, c, ptr(gamma), ptr(beta), eps, momentum, int(clamp_eps),
                                                   ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                                  ptr(res_amax), mul, ptr(bound), ptr(y), yp, m, st))
+                                                  ptr(res_amax), mul, ptr(bound), ptr(y) if _runtime.bn_refine else None, yp, m, ptr(kshift), st))
         else:
             check(lib.pylc_bn_eval_coeffs_full(ptr(running_mean), ptr(running_var), ptr(gamma), ptr(beta), eps, c,
                                                ptr(scale), ptr(shift), ptr(mean), ptr(invstd), st))

@@ -13,6 +13,9 @@ class _Runtime:
         # batched across layers (layer k+1's statistics depend on layer k's output).  PYLC_SYNC_BN=0: per-GPU statistics (what
         # torch DDP does without SyncBatchNorm): only the loss statistics and the gradient buckets cross the fabric.
         self.sync_bn = os.environ.get('PYLC_SYNC_BN', '1') != '0'
+        # BatchNorm statistics: re-measure ill-conditioned channels (mean^2 >> var) in a second pass (bn.hip kRefineRatio); PYLC_BN_REFINE=0
+        # keeps the plain sum / sum-of-squares variance (A/B knob)
+        self.bn_refine = os.environ.get('PYLC_BN_REFINE', '1') != '0'
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)

@@ -752,7 +752,7 @@ def test_concat_by_slice_equals_cat(dev):
         ops.concat_slices(buf, [ops.bilinear(g.to(dev).contiguous(memory_format=torch.channels_last), h, w, into=(buf, 0))])        # does not cover the buffer
 
 
-@pytest.mark.parametrize('path', ['standalone', 'conv_fused'])
+@pytest.mark.parametrize('path', ['standalone', 'conv_fused', 'conv_bias'])
 def test_bn_train_mean_1e3_sigma(dev, path):
     """|mean| / sigma ~ 10^3 per channel: sum(x^2)/n - mean^2 from fp32 sums carries no variance bits there; the finalize kernels
     re-measure such channels in a second pass (bn.hip: kRefineRatio), as torch.nn.BatchNorm2d's two-pass / Welford statistics do.
@@ -764,6 +764,19 @@ def test_bn_train_mean_1e3_sigma(dev, path):
         y[:, 5] = rnd(72, b, hw, hw) * 3.0 + 0.25                                                           # one well-conditioned channel
         yd = to_dev_nhwc(y, dev).requires_grad_(True)
         y_ref = y.double()
+    elif path == 'conv_bias':
+        # the common case (U-Net's first layer on the 1/255-scaled input): a bias that dwarfs the spread.  The conv epilogue takes its
+        # statistics of (y - bias), so this costs no second pass
+        x = 0.01 * rnd(78, b, 64, hw, hw)
+        wt = 0.05 * rnd(79, c, 64, 3, 3)
+        bias = (5.0 + rnd(80, c).abs()).to(dev)
+        conv_out = ops.conv2d(to_dev_nhwc(x, dev), to_dev_nhwc(wt, dev), bias, 1, 0, 1, want_stats=True)
+        assert getattr(conv_out._pylc_sums, '_pylc_shift', None) is not None
+        y_ref = conv_out.detach().double().cpu()
+        ratio = (y_ref.mean((0, 2, 3)).abs() / y_ref.std((0, 2, 3))).min().item()
+        assert ratio > 300, ratio
+        yd = conv_out.detach().requires_grad_(True)
+        yd._pylc_sums = conv_out._pylc_sums
     else:
         # conv outputs with a large common mode: positive inputs x positive filters (mean ~ 64 * 9 * 1.0 = 576, sigma ~ 0.3); no padding,
         # so that every output sums all 576 products

@@ -6,7 +6,7 @@ tag=${1:-final}
 out=gpurun_out/$tag
 mkdir -p $out
 if [ -z "$SKIP_TESTS" ]; then
-    timeout -k 10 700 python -m pytest tests -m gpu -x -q > $out/gputests.log 2>&1
+    timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/gputests.log 2>&1
     rc=$?
     echo "pytest exit $rc" >> $out/gputests.log
     tail -4 $out/gputests.log
@@ -16,6 +16,12 @@ timeout -k 10 300 python tools/net_bench.py 2> $out/other_configs.err | grep -v 
 cat $out/other_configs.txt
 timeout -k 10 300 python bench.py > $out/bench_n1.json 2> $out/bench.err || exit $?
 tail -c 400 $out/bench_n1.json; echo
+for c in c2 c4 c5; do
+    timeout -k 10 300 python bench.py --config $c --no-cpu-baseline --no-dp-overhead > $out/bench_$c.json 2> $out/bench_$c.err || exit $?
+    head -c 300 $out/bench_$c.json; echo
+done
+timeout -k 10 200 python tools/pl_dephase_ab.py 20 2> /dev/null | grep -v amdgpu.ids > $out/conv_pl_shapes.txt
+timeout -k 10 200 python tools/aten_ops_in_step.py 2> /dev/null | grep -v amdgpu.ids > $out/aten_ops_in_step.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/rocprof.err || exit $?
 find $out/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv

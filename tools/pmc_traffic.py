@@ -19,5 +19,10 @@ for k, v in acc.items():
                     'fetch_bytes_per_launch': 2.0 * 1024 * v['fetch_kb'] / max(v['n_fetch'], 1),
                     'write_bytes_per_launch': 1024 * v['write_kb'] / max(v['n_write'], 1)}
     res[k[:120]]['hbm_bytes_per_launch'] = res[k[:120]]['fetch_bytes_per_launch'] + res[k[:120]]['write_bytes_per_launch']
-top = dict(sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12])
+top = dict(sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:16])
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+top['_meta'] = {'csrc_sha256': bench.csrc_fingerprint(), 'command': 'bench.py --steps 2 --warmup 1 (PYLC_NO_SIDE_STREAM=1), two rocprofv3 --pmc passes',
+                'corrections': 'FETCH_SIZE x2 (gfx950), WRITE_SIZE exact; KB -> bytes'}
 print(json.dumps(top, indent=1))
