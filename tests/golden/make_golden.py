@@ -184,8 +184,17 @@ def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
             convs = [k for k, g in gref.items() if k not in zero_keys and g.dim() == 4 and g.numel() <= 40000]
             vecs = [k for k, g in gref.items() if k not in zero_keys and g.dim() == 1 and g.numel() >= 32]
             picked = [convs[round(i * (len(convs) - 1) / 3)] for i in range(4)] + [vecs[len(vecs) // 5], vecs[-3]]
-            grad_fix = {'g::' + k: gref[k].detach().numpy().astype(np.float32).copy() for k in picked}
-            grad_meta = {k: {'absmax': float(gref[k].abs().max()), 'oracle_maxdiff': float((gref[k] - sd[k].grad).abs().max())} for k in picked}
+            # plus named tensors from the middle and the far end of the network; of the large ones the first `rows` filters only
+            named = {'deeplab_resnet': [('backbone.layer3.22.conv2.weight', 8), ('aspp.aspp4.atrous_conv.weight', 2), ('backbone.layer3.22.bn3.weight', 0)],
+                     'deeplab_xception': [('backbone.block12.rep.4.conv1.weight', 0), ('backbone.block12.rep.4.pointwise.weight', 8),
+                                          ('aspp.aspp4.atrous_conv.weight', 2)],
+                     'unet': [('encoder.3.block.3.weight', 4), ('decoder.0.conv_block.block.0.weight', 2)]}[tag]
+            rows = {k: 0 for k in picked}
+            rows.update({k: r for k, r in named if k not in zero_keys})
+            cut = lambda k, t: t[:rows[k]] if rows[k] else t
+            grad_fix = {'g::' + k: cut(k, gref[k]).detach().numpy().astype(np.float32).copy() for k in rows}
+            grad_meta = {k: {'absmax': float(cut(k, gref[k]).abs().max()), 'rows': rows[k],
+                             'oracle_maxdiff': float((cut(k, gref[k]) - cut(k, sd[k].grad)).abs().max())} for k in rows}
             new_sd = ref.net.state_dict()
             pw, pk = 0.0, None
             for k, v in new_sd.items():
@@ -215,7 +224,7 @@ def golden_net(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
                 g1 = sd1[k].grad          # already clipped in place by clip_grad_norm_
                 grad_cond[k] = float((g1 - g).norm() / (g.norm() + 1e-3 * gmax))
                 if k in grad_meta:
-                    grad_meta[k]['cond_maxdiff'] = float((g1 - g).abs().max())       # reference-vs-reference noise, elementwise
+                    grad_meta[k]['cond_maxdiff'] = float((cut(k, g1) - cut(k, g)).abs().max())       # reference-vs-reference noise, elementwise
     torch.set_num_threads(8)
     meta['conditioning_train'] = cond_steps
     meta['grad_conditioning_step0'] = grad_cond

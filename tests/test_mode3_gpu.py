@@ -59,7 +59,7 @@ def test_mode3_train_step_against_the_fp32_reference(dev, mode3):
     assert abs(got[0] - ref['ce']) < 2e-2 and abs(got[1] - ref['dice']) < 2e-2 and abs(got[2] - ref['focal']) < 2e-2
     gnorm, coef = model.optim.norm.cpu().tolist()
     print('mode 3 pre-clip gradient norm %.4f reference %.4f' % (gnorm, ref['grad_norm_preclip']))
-    # this 96x96 fixture amplifies rounding-level conv differences ~1e5-fold into its early-layer gradients (DESIGN.md section 7: 2^-22
+    # this 96x96 fixture amplifies rounding-level conv differences ~1e5-fold into its early-layer gradients (DESIGN.md section 3: 2^-22
     # operand differences already move the norm by 0.4 %), so 2^-11 operands land within tens of per cent, not per mille
     assert abs(gnorm - ref['grad_norm_preclip']) < 0.25 * ref['grad_norm_preclip']
     gmeta = json.load(open(os.path.join(HERE, 'deeplab_xception_grads.json')))
@@ -67,7 +67,8 @@ def test_mode3_train_step_against_the_fp32_reference(dev, mode3):
     params = dict(model.net.named_parameters())
     for k in gmeta:
         r = torch.from_numpy(garr['g::' + k]).double().flatten()
-        g = (params[k].grad.double() * coef).cpu().flatten()
+        g = (params[k].grad.double() * coef).cpu()
+        g = (g[:gmeta[k]['rows']] if gmeta[k].get('rows') else g).flatten()
         cos = float((g * r).sum() / (g.norm() * r.norm()))
         print('  grad %-44s cos %.5f  |g|/|ref| %.4f' % (k, cos, float(g.norm() / r.norm())))
         assert cos > 0.85 and abs(float(g.norm() / r.norm()) - 1) < 0.3, (k, cos)

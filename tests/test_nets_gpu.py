@@ -104,7 +104,7 @@ def test_train_steps_match_reference(dev, tag):
             print('%s worst grad-l2 rel diff %.3g' % (tag, worst))
             # elementwise against the reference's own gradients of six tensors (tests/golden/<net>_grads.*, make_golden.py): bounded by
             # the fixture's reference-vs-reference noise (the same algorithm on 1 vs 8 CPU threads; at least 2 % of the tensor's largest
-            # gradient -- the 96x96 fixtures amplify last-bit conv differences by ~1e5, DESIGN.md section 7), never looser than 5 % -- a
+            # gradient -- the 96x96 fixtures amplify last-bit conv differences by ~1e5, DESIGN.md section 3), never looser than 5 % -- a
             # transposed filter, a permuted channel or a sign error differs by ~100 %
             gmeta = json.load(open(os.path.join(HERE, tag + '_grads.json')))
             garr = np.load(os.path.join(HERE, tag + '_grads.npz'))
@@ -112,6 +112,8 @@ def test_train_steps_match_reference(dev, tag):
             for k, m in gmeta.items():
                 ref_g = torch.from_numpy(garr['g::' + k]).double()
                 got_g = (params[k].grad.double() * coef).cpu()
+                if m.get('rows'):
+                    got_g = got_g[:m['rows']]                   # of the large tensors the fixture holds the first filters
                 assert got_g.shape == ref_g.shape
                 err = (got_g - ref_g).abs().max().item()
                 cos = float((got_g * ref_g).sum() / (got_g.norm() * ref_g.norm()))
