@@ -164,6 +164,9 @@ typedef struct PylcDwDesc {
 } PylcDwDesc;
 int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const float* w, float* y, void* stream);
 int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream);
+/* accumulate != 0: dx += the data gradient (dx holds the part of the tensor's other consumers: the block input of xception.py:88-97
+ * feeds both the first depthwise conv of `rep` and the skip path) */
+int pylc_dwconv3x3_dgrad_acc(const PylcDwDesc* d, const float* dy, const float* w_c9, float* dx, int accumulate, void* stream);
 size_t pylc_dwconv3x3_wgrad_workspace(const PylcDwDesc* d);
 int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const float* dy, float* dw,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -316,6 +319,12 @@ int pylc_bilinear_fwd(const float* x, int x_pitch, float* y, int y_pitch, int B,
                       int OH, int OW, void* stream);
 int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C,
                       int OH, int OW, void* stream);
+/* The same gradient applied one axis at a time (along W into `workspace` [B, OH, W, C], pylc_bilinear_bwd_workspace bytes, then along
+ * H): ~2 x (2 OW / W + 3) candidate taps per element instead of their product -- the form to use for up-sampling factors >= 2
+ * (deeplab.py:38 logits x4, decoder.py:46 x4).  Same weights; the two-stage summation order differs from pylc_bilinear_bwd's. */
+size_t pylc_bilinear_bwd_workspace(int B, int W, int C, int OH);
+int pylc_bilinear_bwd_separable(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C,
+                                int OH, int OW, float* workspace, void* stream);
 int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int pylc_gap_bwd(const float* dy, float* dx, int B, int HW, int C, void* stream);
 /* accumulate != 0: dx += the pooled gradient (dx holds the gradient parts of the tensor's other consumers: aspp.py:76-80, where the

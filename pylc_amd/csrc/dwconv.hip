@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 
 // dx[b,h,w,c] = sum_{r,s} dy[b, (h + dil - r*dil)/stride, (w + dil - s*dil)/stride, c] * k[c][r][s]   (where divisible)
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, DwGeom d,
-                                                       Slab g) {
+                                                       Slab g, int accumulate) {
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     if (ty >= g.RL) return;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
                     acc += k[kr * 3 + ks] * ld4(dy + ((size_t)(b * d.OH + oh) * d.OW + ow) * d.y_pitch + 4 * cv);
                 }
             }
+            if (accumulate) acc += ld4(dx + r * d.x_pitch + 4 * cv);      // dx holds the other consumers' part of the gradient (ops.ResidualLink)
             st4(dx + r * d.x_pitch + 4 * cv, acc);
         }
     }
@@ -154,7 +155,7 @@ __device__ __forceinline__ void dw_load_col(f32x4 (&c)[4], const float* const (&
 // MODE 2: partial[block][9][C] = sum over this block's pixels of dy (x) window(x) (in = x, aux = dy, out = partial)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 2 : 3, 8))) void dw_strip_kernel(const float* __restrict__ in, const float* __restrict__ aux, float* __restrict__ out,
-                                                       DwGeom d, DwStrip s, int cols, int RL, int CV) {
+                                                       DwGeom d, DwStrip s, int cols, int RL, int CV, int accumulate) {
     __shared__ f32x4 red[MODE == 2 ? 256 : 1];
     const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
     const int in_pitch = MODE == 1 ? d.y_pitch : d.x_pitch;
@@ -214,6 +215,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 a1 += k[kr * 3 + 0] * (MODE == 0 ? L[j + 1] : R[j + 1]);                                                  \
                 a1 += k[kr * 3 + 1] * M[j + 1];                                                                           \
                 a1 += k[kr * 3 + 2] * (MODE == 0 ? R[j + 1] : L[j + 1]);                                                  \
+            }                                                                                                             \
+            if (MODE == 1 && accumulate) {          /* dx += : the other consumers' part of the gradient is already there */  \
+                a0 += ld4(out + o0 + (size_t)ww * out_pitch);                                                             \
+                if (two) a1 += ld4(out + o1 + (size_t)ww * out_pitch);                                                    \
             }                                                                                                             \
             st4(out + o0 + (size_t)ww * out_pitch, a0);                                                                   \
             if (two) st4(out + o1 + (size_t)ww * out_pitch, a1);                                                          \
@@ -306,7 +311,7 @@ extern "C" int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const flo
     if (dw_fast(d)) {
         const DwStrip s = make_strips(d, g.cols, g.RL);
         hipLaunchKernelGGL((dw_strip_kernel<0>), dim3(cdiv(s.n_strips, s.strips_per_block)), dim3(256), 0, as_stream(stream), x, w, y, geom(d), s,
-                           g.cols, g.RL, g.CV);
+                           g.cols, g.RL, g.CV, 0);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }
@@ -315,20 +320,24 @@ extern "C" int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const flo
     return PYLC_OK;
 }
 
-extern "C" int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream) {
+extern "C" int pylc_dwconv3x3_dgrad_acc(const PylcDwDesc* d, const float* dy, const float* w, float* dx, int accumulate, void* stream) {
     if (int rc = check_dw(d)) return rc;
     PYLC_REQUIRE(dy && w && dx, "dwconv_dgrad: null pointer");
     const Slab g = make_slab((long long)d->B * d->H * d->W, d->C);
     if (dw_fast(d)) {
         const DwStrip s = make_strips(d, g.cols, g.RL);
         hipLaunchKernelGGL((dw_strip_kernel<1>), dim3(cdiv(s.n_strips, s.strips_per_block)), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), s,
-                           g.cols, g.RL, g.CV);
+                           g.cols, g.RL, g.CV, accumulate);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }
-    hipLaunchKernelGGL(dw_dgrad_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), g);
+    hipLaunchKernelGGL(dw_dgrad_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), dy, w, dx, geom(d), g, accumulate);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
+}
+
+extern "C" int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream) {
+    return pylc_dwconv3x3_dgrad_acc(d, dy, w, dx, 0, stream);
 }
 
 extern "C" size_t pylc_dwconv3x3_wgrad_workspace(const PylcDwDesc* d) {
@@ -349,7 +358,7 @@ extern "C" int pylc_dwconv3x3_wgrad(const PylcDwDesc* d, const float* x, const f
         const DwStrip s = make_strips(d, g.cols, g.RL);
         nslab = cdiv(s.n_strips, s.strips_per_block);          // <= kDefaultSlabs by construction
         hipLaunchKernelGGL((dw_strip_kernel<2>), dim3(nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), s, g.cols, g.RL,
-                           g.CV);
+                           g.CV, 0);
     } else {
         hipLaunchKernelGGL(dw_wgrad_kernel, dim3(g.nslab), dim3(256), 0, st, x, dy, static_cast<float*>(workspace), geom(d), g);
     }

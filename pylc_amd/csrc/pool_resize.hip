@@ -186,6 +186,39 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int dy_pitch, 
     }
 }
 
+// Separable form of the same gradient: the interpolation matrix is Wh (x) Ww, so its transpose can be applied one axis at a time --
+// dy [B,OH,OW,C] -> tmp [B,OH,W,C] (along W), tmp -> dx [B,H,W,C] (along H).  Per element ~(2/scale + 3) candidates per pass instead of
+// their product in one (100 -> 2 x 10 for the 4x up-sampling of the logits), and the second pass reads the OW/W times smaller tmp.
+// AXIS 0: reduce along the last spatial axis (n_out = OW -> n_in = W), rows = B*OH.  AXIS 1: along H (n_out = OH -> n_in = H) of a
+// [B, OH, W, C] tensor, rows = B.
+template <int AXIS>
+__global__ void bilinear_bwd_axis_kernel(const float* __restrict__ src, int src_pitch, float* __restrict__ dst, int dst_pitch, int rows, int n_in,
+                                         int n_out, int inner, int C, float scale) {
+    const int CV = C / 4;
+    // AXIS 0: index = ((row * n_in + i) * CV + cv), inner == 1.   AXIS 1: index = (((row * n_in + i) * inner + w) * CV + cv), inner == W
+    const long long total = (long long)rows * n_in * inner * CV;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        long long t = idx / CV;
+        const int w = (int)(t % inner); t /= inner;
+        const int i = (int)(t % n_in);
+        const int row = (int)(t / n_in);
+        int lo, hi;
+        cand_range(i, scale, n_out, lo, hi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* base = src + ((size_t)row * n_out * inner + w) * src_pitch + 4 * cv;
+        for (int o = lo; o <= hi; ++o) {
+            const Lerp l = lerp_of(o, scale, n_in);
+            if (l.i0 != i && l.i1 != i) continue;
+            float wt = 0.f;
+            if (l.i0 == i) wt += l.w0;
+            if (l.i1 == i) wt += l.w1;          // i1 == i0 at the border: both weights land on the same pixel
+            acc += wt * ld4(base + (size_t)o * inner * src_pitch);
+        }
+        st4(dst + (((size_t)row * n_in + i) * inner + w) * dst_pitch + 4 * cv, acc);
+    }
+}
+
 // ---- global average pool -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C) {
     __shared__ f32x4 red[256];
@@ -346,6 +379,22 @@ extern "C" int pylc_bilinear_bwd(const float* dy, int dy_pitch, float* dx, int d
     const long long total = (long long)B * H * W * (C / 4);
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_pitch, dx, dx_pitch, B, H, W, C, OH, OW,
                        ac_scale(H, OH), ac_scale(W, OW));
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" size_t pylc_bilinear_bwd_workspace(int B, int W, int C, int OH) { return (size_t)B * OH * W * C * sizeof(float); }
+
+extern "C" int pylc_bilinear_bwd_separable(const float* dy, int dy_pitch, float* dx, int dx_pitch, int B, int H, int W, int C, int OH, int OW,
+                                           float* workspace, void* stream) {
+    PYLC_REQUIRE(dy && dx && workspace && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "bilinear_bwd_separable: bad arguments");
+    PYLC_REQUIRE(dy_pitch >= C && dx_pitch >= C && dy_pitch % 4 == 0 && dx_pitch % 4 == 0, "bilinear_bwd_separable: bad pitch");
+    const long long t0 = (long long)B * OH * W * (C / 4), t1 = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(bilinear_bwd_axis_kernel<0>, dim3(grid_for(t0)), dim3(256), 0, as_stream(stream), dy, dy_pitch, workspace, C, B * OH, W, OW, 1, C,
+                       ac_scale(W, OW));
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bilinear_bwd_axis_kernel<1>, dim3(grid_for(t1)), dim3(256), 0, as_stream(stream), workspace, C, dx, dx_pitch, B, H, OH, W, C,
+                       ac_scale(H, OH));
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

@@ -52,8 +52,8 @@ class DepthwiseConv3x3(nn.Module):
         self.c, self.stride, self.dilation = c, stride, dilation
         self.weight = nn.Parameter(torch.empty(c, 1, 3, 3).normal_(0, math.sqrt(2.0 / (9 * c))))
 
-    def forward(self, x):
-        return ops.dwconv3x3(x, self.weight, self.stride, self.dilation)
+    def forward(self, x, res_link=None):
+        return ops.dwconv3x3(x, self.weight, self.stride, self.dilation, res_link)
 
 
 class BatchNorm2d(nn.Module):

@@ -78,6 +78,7 @@ SIGNATURES = {
     'pylc_weight_transpose': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_dwconv3x3_fwd': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
     'pylc_dwconv3x3_dgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
+    'pylc_dwconv3x3_dgrad_acc': (_I, [C.POINTER(DwDesc), _P, _P, _P, _I, _P]),
     'pylc_dwconv3x3_wgrad_workspace': (_SZ, [C.POINTER(DwDesc)]),
     'pylc_dwconv3x3_wgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _SZ, _P]),
     'pylc_bn_workspace_floats': (_SZ, [_LL, _I]),
@@ -107,6 +108,8 @@ SIGNATURES = {
     'pylc_crop_copy': (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     'pylc_bilinear_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pylc_bilinear_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pylc_bilinear_bwd_workspace': (C.c_size_t, [_I, _I, _I, _I]),
+    'pylc_bilinear_bwd_separable': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'pylc_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_gap_bwd_acc': (_I, [_P, _P, _I, _I, _I, _I, _P]),

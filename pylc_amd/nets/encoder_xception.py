@@ -19,9 +19,9 @@ class SeparableConv2d(nn.Module):
         self.bn = BatchNorm2d(cin)
         self.pointwise = Conv2d(cin, cout, 1, bn=True)         # every SeparableConv2d is followed by a BatchNorm (Block / bn3-5)
 
-    def forward(self, x):
+    def forward(self, x, link=None):
         # the inner BatchNorm feeds the pointwise conv only: it writes the conv's operand format (fp16 planes) directly
-        return self.pointwise(self.bn(self.conv1(x), out_planes=self.pointwise.takes_planes()))
+        return self.pointwise(self.bn(self.conv1(x, res_link=link), out_planes=self.pointwise.takes_planes()))
 
 
 class Block(nn.Module):
@@ -62,20 +62,26 @@ class Block(nn.Module):
         explicit one of xception.py:200 / :222) in this block's last pass."""
         if self.start_with_relu and not input_relud:
             inp = ops.relu(inp)                   # aliasing quirk: both branches see relu(inp)
+        # `inp` has two consumers -- the first depthwise conv of `rep` and the skip path (the 1x1 skip conv, or the residual input of the
+        # last BatchNorm): their gradients meet in one buffer instead of an autograd add pass (ops.ResidualLink)
+        link = ops.grad_link(inp)
         if self.skip is not None:
-            skip = self.skipbn(self.skip(inp))
+            skip = self.skipbn(self.skip(inp, res_link=link))
         else:
             skip = inp
         x = inp
         n = len(self.plan)
         i = 1 if self.start_with_relu else 0
+        first_sep = True
         while i < n:
             kind, name = self.plan[i]
             if kind == 'sep':
-                x = getattr(self.rep, name)(x)
+                x = getattr(self.rep, name)(x, link if first_sep else None)
+                first_sep = False
             elif kind == 'bn':
                 if i == n - 1:          # the branch ends in a BatchNorm: `rep(inp) + skip` (xception.py:97) is its apply pass
-                    return getattr(self.rep, name)(x, residual=skip, relu=relu_out)   # (y*scale + shift) + skip: the same two fp32 operations
+                    return getattr(self.rep, name)(x, residual=skip, relu=relu_out,   # (y*scale + shift) + skip: the same two fp32 operations
+                                                   res_link=link if self.skip is None else None)
                 fuse = self.plan[i + 1][0] == 'relu'                   # BN followed by the shared ReLU -> one pass
                 x = getattr(self.rep, name)(x, relu=fuse)
                 if fuse:

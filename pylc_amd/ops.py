@@ -853,12 +853,15 @@ def _dw_desc(x, stride, dil, xp, yp):
 
 class DwConv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, dil):
+    def forward(ctx, x, w, stride, dil, res_link=None):
         L.init()
         x = as_nhwc(x)
         b, c, h, wd = x.shape
         if tuple(w.shape) != (c, 1, 3, 3) or not w.is_contiguous():
             raise L.PylcError('depthwise weight must be contiguous [C,1,3,3]')
+        ctx.res_link = res_link if (res_link is not None and ctx.needs_input_grad[0]) else None
+        if ctx.res_link is not None:
+            res_link.pending += 1           # one more backward node that adds its part of x's gradient into the shared buffer
         d = _dw_desc(x, stride, dil, pitch_of(x), c)
         y = empty_nhwc(b, c, d.OH, d.OW, x.device)
         check(lib.pylc_dwconv3x3_fwd(C.byref(d), ptr(x), ptr(w), ptr(y), stream()))
@@ -876,10 +879,20 @@ class DwConv3x3Fn(torch.autograd.Function):
         d = _dw_desc(x, stride, dil, pitch_of(x), pitch_of(dy))
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = empty_nhwc(*x.shape, device=x.device)
+            link = ctx.res_link
+            sink = link.buf if link is not None else None
+            if sink is not None and (tuple(sink.shape) != tuple(x.shape) or pitch_of(sink) != x.shape[1]):
+                raise L.PylcError('depthwise dgrad: the parked gradient does not have the shape of the input')
+            dx = sink if sink is not None else empty_nhwc(*x.shape, device=x.device)
             d.x_pitch = x.shape[1]
-            check(lib.pylc_dwconv3x3_dgrad(C.byref(d), ptr(dy), ptr(w), ptr(dx), st))
+            check(lib.pylc_dwconv3x3_dgrad_acc(C.byref(d), ptr(dy), ptr(w), ptr(dx), 1 if sink is not None else 0, st))
             d.x_pitch = pitch_of(x)
+            if link is not None:
+                link.pending -= 1
+                if link.pending > 0:        # other consumers of x follow: they accumulate into the same buffer
+                    link.buf, dx = dx, None
+                else:
+                    link.buf = None
         if ctx.needs_input_grad[1]:
             nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
             ws = _ws(nbytes, x.device)
@@ -887,11 +900,11 @@ class DwConv3x3Fn(torch.autograd.Function):
             dw = tgt if tgt is not None else torch.empty_like(w)
             check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, st))
             dw = _deliver_grad(w, dw)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def dwconv3x3(x, w, stride=1, dil=1):
-    return DwConv3x3Fn.apply(x, w, stride, dil)
+def dwconv3x3(x, w, stride=1, dil=1, res_link=None):
+    return DwConv3x3Fn.apply(x, w, stride, dil, res_link)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1362,7 +1375,11 @@ class BilinearFn(torch.autograd.Function):
             t.copy_(dy)
             dy = t
         dx = empty_nhwc(b, c, h, w, dy.device, cc)
-        check(lib.pylc_bilinear_bwd(ptr(dy), pitch_of(dy), ptr(dx), cc, b, h, w, cc, oh, ow, stream()))
+        if oh >= 2 * h and ow >= 2 * w:      # up-sampling: one axis at a time (10 + 10 instead of 100 candidate taps per element at x4)
+            tmp = torch.empty(lib.pylc_bilinear_bwd_workspace(b, w, cc, oh) // 4, device=dy.device, dtype=torch.float32)
+            check(lib.pylc_bilinear_bwd_separable(ptr(dy), pitch_of(dy), ptr(dx), cc, b, h, w, cc, oh, ow, ptr(tmp), stream()))
+        else:
+            check(lib.pylc_bilinear_bwd(ptr(dy), pitch_of(dy), ptr(dx), cc, b, h, w, cc, oh, ow, stream()))
         return dx, None, None, None
 
 

@@ -145,6 +145,7 @@ def dwconv3x3_backward(dy: Tensor, x: Tensor, weight: Tensor, stride: int, dilat
     ctx = _Ctx((True, True))
     ctx.save_for_backward(ops.as_nhwc(x))
     ctx.w_param, ctx.geom = weight, (stride, dilation)
+    ctx.res_link = None
     dx, dw = ops.DwConv3x3Fn.backward(ctx, dy)[:2]
     return dx, dw
 

@@ -277,7 +277,8 @@ def test_maxpool(dev, k, s, p, hw, c):
 
 
 @pytest.mark.parametrize('c,h,w,oh,ow', [(256, 8, 8, 32, 32), (12, 16, 16, 64, 64), (256, 1, 1, 8, 8), (64, 12, 12, 24, 24),
-                                         (9, 10, 12, 40, 48), (128, 7, 5, 14, 10)])
+                                         (9, 10, 12, 40, 48), (128, 7, 5, 14, 10),          # up-sampling: the separable backward
+                                         (32, 16, 16, 24, 40), (16, 20, 20, 10, 30)])       # below x2 / down-sampling: the one-pass backward
 def test_bilinear(dev, c, h, w, oh, ow):
     from pylc_amd import ops
     x = rnd(25, 2, c, h, w)
@@ -854,3 +855,49 @@ def test_range_tags_go_stale_with_the_tensor(dev):
         assert bool(torch.isfinite(y).all()) and rel_err(y, ref) < 3e-6
     finally:
         check(lib.pylc_set_conv_precision(prev))
+
+
+def test_depthwise_gradient_link(dev):
+    """xception.py:88-97: a block input feeds the first depthwise conv of `rep` AND the skip path; with ops.grad_link the two gradients meet
+    in one buffer (the depthwise dgrad accumulates: pylc_dwconv3x3_dgrad_acc) -- equal to autograd's sum, for the strip kernel (stride 1)
+    and the generic one (stride 2), with an identity skip through a BatchNorm residual and with a 1x1 skip conv."""
+    from pylc_amd import ops
+    for stride, hw in ((1, 24), (2, 25)):
+        x0 = rnd(91, 2, 64, hw, hw)
+        wd0 = rnd(92, 64, 1, 3, 3)
+        ws0 = rnd(93, 64, 64, 1, 1, scale=0.1)
+        g0, b0 = 1 + 0.1 * rnd(94, 64), 0.1 * rnd(95, 64)
+        res = {}
+        for mode in ('autograd', 'link'):
+            x = to_dev_nhwc(x0, dev).requires_grad_(True)
+            wd = wd0.to(dev).requires_grad_(True)
+            ws = to_dev_nhwc(ws0, dev).requires_grad_(True)
+            g, be = g0.to(dev).requires_grad_(True), b0.to(dev).requires_grad_(True)
+            link = ops.grad_link(x) if mode == 'link' else None
+            y = ops.dwconv3x3(x, wd, stride, 1, link)
+            skip = ops.conv2d(x, ws, None, stride, 0, 1, res_link=link)
+            out = ops.bn_act(y, g, be, torch.zeros(64, device=dev), torch.ones(64, device=dev), skip, True, True)
+            out.backward(to_dev_nhwc(rnd(96, *out.shape), dev))
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().clone(), x.grad.clone(), wd.grad.clone(), ws.grad.clone())
+            if link is not None:
+                assert link.pending == 0 and link.buf is None
+        for a, c in zip(res['autograd'], res['link']):
+            assert rel_err(c, a) < 1e-6
+    # identity skip: the BatchNorm's residual gradient is parked, the depthwise dgrad adds to it
+    x0 = rnd(97, 2, 32, 20, 20)
+    wd0 = rnd(98, 32, 1, 3, 3)
+    res = {}
+    for mode in ('autograd', 'link'):
+        x = to_dev_nhwc(x0, dev).requires_grad_(True)
+        wd = wd0.to(dev).requires_grad_(True)
+        g, be = torch.ones(32, device=dev, requires_grad=True), torch.zeros(32, device=dev, requires_grad=True)
+        link = ops.grad_link(x) if mode == 'link' else None
+        y = ops.dwconv3x3(x, wd, 1, 1, link)
+        out = ops.bn_act(y, g, be, torch.zeros(32, device=dev), torch.ones(32, device=dev), x, True, True, res_link=link)
+        out.backward(to_dev_nhwc(rnd(99, *out.shape), dev))
+        torch.cuda.synchronize()
+        res[mode] = (out.detach().clone(), x.grad.clone(), wd.grad.clone())
+    for a, c in zip(res['autograd'], res['link']):
+        assert rel_err(c, a) < 1e-6
