@@ -163,6 +163,11 @@ typedef struct PylcDwDesc {
     int x_pitch, y_pitch;
 } PylcDwDesc;
 int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const float* w, float* y, void* stream);
+/* pylc_dwconv3x3_fwd that also emits per-block (sum | sum of squares) of y for the BatchNorm that follows the depthwise conv
+ * (xception.py:34-39): stats_partial [rows][2][C] with rows = pylc_dwconv3x3_fwd_stats_rows(d) (0: this shape has no fused form --
+ * stride 2 / dilated -- use pylc_bn_stats); feed to pylc_bn_finalize_from_partial(_ex). */
+int pylc_dwconv3x3_fwd_stats_rows(const PylcDwDesc* d);
+int pylc_dwconv3x3_fwd_stats(const PylcDwDesc* d, const float* x, const float* w_c9, float* y, float* stats_partial, void* stream);
 int pylc_dwconv3x3_dgrad(const PylcDwDesc* d, const float* dy, const float* w, float* dx, void* stream);
 /* accumulate != 0: dx += the data gradient (dx holds the part of the tensor's other consumers: the block input of xception.py:88-97
  * feeds both the first depthwise conv of `rep` and the skip path) */

@@ -153,10 +153,12 @@ __device__ __forceinline__ void dw_load_col(f32x4 (&c)[4], const float* const (&
 
 // MODE 0: y = dw(x) (in = x, aux = filter, out = y); MODE 1: dx = dw^T(dy) (in = dy, aux = filter, out = dx);
 // MODE 2: partial[block][9][C] = sum over this block's pixels of dy (x) window(x) (in = x, aux = dy, out = partial)
-template <int MODE>
+// STATS (MODE 0): additionally stats[block][2C] = per-block (sum | sum of squares) of the outputs this block wrote, for the BatchNorm that
+// follows every depthwise conv (xception.py:34-39) -- the layout pylc_bn_finalize_from_partial reads; saves that layer's statistics pass.
+template <int MODE, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 2 : 3, 8))) void dw_strip_kernel(const float* __restrict__ in, const float* __restrict__ aux, float* __restrict__ out,
-                                                       DwGeom d, DwStrip s, int cols, int RL, int CV, int accumulate) {
-    __shared__ f32x4 red[MODE == 2 ? 256 : 1];
+                                                       DwGeom d, DwStrip s, int cols, int RL, int CV, int accumulate, float* __restrict__ stats = nullptr) {
+    __shared__ f32x4 red[(MODE == 2 || STATS) ? 256 : 1];
     const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
     const int in_pitch = MODE == 1 ? d.y_pitch : d.x_pitch;
     const int out_pitch = MODE == 1 ? d.x_pitch : d.y_pitch;      // MODE 2: pitch of dy
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const int cv = cb + tx;
         const bool active = ty < RL && cv < CV;
         f32x4 k[9];                                                 // filter taps (MODE 0/1) or accumulators (MODE 2)
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) k[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) {
@@ -222,6 +225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             }                                                                                                             \
             st4(out + o0 + (size_t)ww * out_pitch, a0);                                                                   \
             if (two) st4(out + o1 + (size_t)ww * out_pitch, a1);                                                          \
+            if (STATS) {                                                                                                  \
+                st1 += a0; st2 += a0 * a0;                                                                                \
+                if (two) { st1 += a1; st2 += a1 * a1; }                                                                   \
+            }                                                                                                             \
         }                                                                                                                 \
         if (++ww >= w1) break;                                                                                            \
     }
@@ -232,6 +239,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     PYLC_DW_STEP(cd, ca, cb_, cc)
                 }
 #undef PYLC_DW_STEP
+            }
+        }
+        if (STATS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                red[threadIdx.x] = t == 0 ? st1 : st2;
+                __syncthreads();
+                if (ty == 0 && cv < CV) {
+                    f32x4 sum = t == 0 ? st1 : st2;
+                    for (int q = 1; q < RL; ++q) sum += red[q * cols + tx];
+                    st4(stats + (size_t)blockIdx.x * 2 * d.C + t * d.C + 4 * cv, sum);
+                }
+                __syncthreads();
             }
         }
         if (MODE == 2) {
@@ -316,6 +336,24 @@ extern "C" int pylc_dwconv3x3_fwd(const PylcDwDesc* d, const float* x, const flo
         return PYLC_OK;
     }
     hipLaunchKernelGGL(dw_fwd_kernel, dim3(g.nslab), dim3(256), 0, as_stream(stream), x, w, y, geom(d), g);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" int pylc_dwconv3x3_fwd_stats_rows(const PylcDwDesc* d) {
+    if (check_dw(d) || !dw_fast(d)) return 0;
+    const Slab g = make_slab((long long)d->B * d->OH * d->OW, d->C);
+    const DwStrip s = make_strips(d, g.cols, g.RL);
+    return cdiv(s.n_strips, s.strips_per_block);
+}
+
+extern "C" int pylc_dwconv3x3_fwd_stats(const PylcDwDesc* d, const float* x, const float* w, float* y, float* stats_partial, void* stream) {
+    if (int rc = check_dw(d)) return rc;
+    PYLC_REQUIRE(x && w && y && stats_partial && dw_fast(d), "dwconv_fwd_stats: null pointer / not a stride-1 dilation-1 shape (pylc_dwconv3x3_fwd_stats_rows == 0)");
+    const Slab g = make_slab((long long)d->B * d->OH * d->OW, d->C);
+    const DwStrip s = make_strips(d, g.cols, g.RL);
+    hipLaunchKernelGGL((dw_strip_kernel<0, true>), dim3(cdiv(s.n_strips, s.strips_per_block)), dim3(256), 0, as_stream(stream), x, w, y, geom(d), s,
+                       g.cols, g.RL, g.CV, 0, stats_partial);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

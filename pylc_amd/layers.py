@@ -53,7 +53,7 @@ class DepthwiseConv3x3(nn.Module):
         self.weight = nn.Parameter(torch.empty(c, 1, 3, 3).normal_(0, math.sqrt(2.0 / (9 * c))))
 
     def forward(self, x, res_link=None):
-        return ops.dwconv3x3(x, self.weight, self.stride, self.dilation, res_link)
+        return ops.dwconv3x3(x, self.weight, self.stride, self.dilation, res_link, want_stats=self.training)     # always followed by a BatchNorm
 
 
 class BatchNorm2d(nn.Module):

@@ -77,6 +77,8 @@ SIGNATURES = {
     'pylc_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _SZ, _P]),
     'pylc_weight_transpose': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_dwconv3x3_fwd': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
+    'pylc_dwconv3x3_fwd_stats_rows': (_I, [C.POINTER(DwDesc)]),
+    'pylc_dwconv3x3_fwd_stats': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P]),
     'pylc_dwconv3x3_dgrad': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
     'pylc_dwconv3x3_dgrad_acc': (_I, [C.POINTER(DwDesc), _P, _P, _P, _I, _P]),
     'pylc_dwconv3x3_wgrad_workspace': (_SZ, [C.POINTER(DwDesc)]),

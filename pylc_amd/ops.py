@@ -853,8 +853,9 @@ def _dw_desc(x, stride, dil, xp, yp):
 
 class DwConv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, dil, res_link=None):
+    def forward(ctx, x, w, stride, dil, res_link=None, want_stats=False):
         L.init()
+        ctx.set_materialize_grads(False)
         x = as_nhwc(x)
         b, c, h, wd = x.shape
         if tuple(w.shape) != (c, 1, 3, 3) or not w.is_contiguous():
@@ -864,13 +865,24 @@ class DwConv3x3Fn(torch.autograd.Function):
             res_link.pending += 1           # one more backward node that adds its part of x's gradient into the shared buffer
         d = _dw_desc(x, stride, dil, pitch_of(x), c)
         y = empty_nhwc(b, c, d.OH, d.OW, x.device)
-        check(lib.pylc_dwconv3x3_fwd(C.byref(d), ptr(x), ptr(w), ptr(y), stream()))
+        rows = lib.pylc_dwconv3x3_fwd_stats_rows(C.byref(d)) if want_stats else 0
+        sums = None
+        if rows > 0:        # the statistics of the BatchNorm that follows come out of this pass (stride-1 / dilation-1 shapes)
+            sums = torch.empty((rows, 2 * c), device=x.device, dtype=torch.float32)
+            check(lib.pylc_dwconv3x3_fwd_stats(C.byref(d), ptr(x), ptr(w), ptr(y), ptr(sums), stream()))
+        else:
+            check(lib.pylc_dwconv3x3_fwd(C.byref(d), ptr(x), ptr(w), ptr(y), stream()))
         ctx.save_for_backward(x)
         ctx.w_param, ctx.geom = w, (stride, dil)
+        if sums is not None:
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return (None,) * 6
         (x,) = ctx.saved_tensors
         w = ctx.w_param
         stride, dil = ctx.geom
@@ -900,11 +912,17 @@ class DwConv3x3Fn(torch.autograd.Function):
             dw = tgt if tgt is not None else torch.empty_like(w)
             check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, st))
             dw = _deliver_grad(w, dw)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def dwconv3x3(x, w, stride=1, dil=1, res_link=None):
-    return DwConv3x3Fn.apply(x, w, stride, dil, res_link)
+def dwconv3x3(x, w, stride=1, dil=1, res_link=None, want_stats=False):
+    """want_stats: the output feeds a training-mode BatchNorm -- attach the statistics partials the forward pass can emit (as ops.conv2d)."""
+    out = DwConv3x3Fn.apply(x, w, stride, dil, res_link, bool(want_stats and torch.is_grad_enabled()))
+    if isinstance(out, tuple):
+        y, sums = out
+        y._pylc_sums = sums
+        return y
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

@@ -131,7 +131,7 @@ torch.library.register_autograd('pylc_hip::conv2d', _conv2d_bwd, setup_context=_
 # ------------------------------------------------------------------------------------------------------------------------------
 @torch.library.custom_op('pylc_hip::dwconv3x3', mutates_args=())
 def dwconv3x3(x: Tensor, weight: Tensor, stride: int, dilation: int) -> Tensor:
-    return ops.DwConv3x3Fn.forward(_Ctx((False, False)), x, weight, stride, dilation)
+    return ops.DwConv3x3Fn.forward(_Ctx((False, False)), x, weight, stride, dilation, None, False)
 
 
 @dwconv3x3.register_fake

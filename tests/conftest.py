@@ -10,6 +10,11 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle runs small networks: on the GPU box's 128 host threads oneDNN spends its time synchronising them (the Xception
+    # mIoU trajectory: 180 s there against 30 s on 8 cores)
+    import torch
+    if torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
 
 
 @pytest.fixture(scope='session')

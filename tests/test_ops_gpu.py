@@ -217,6 +217,15 @@ def test_dwconv(dev, c, stride, dil, hw):
     assert rel_err(y, yr) < 2e-6
     assert rel_err(xd.grad, xr.grad) < 2e-6
     assert rel_err(wd.grad, wr.grad) < 5e-6
+    # the statistics partials of the BatchNorm that follows (strip-kernel shapes only): same output bits, sums == sums over the output
+    y2 = ops.dwconv3x3(xd, wd, stride, dil, want_stats=True)
+    assert torch.equal(y2, y)
+    part = getattr(y2, '_pylc_sums', None)
+    assert (part is not None) == (stride == 1 and dil == 1 and hw[1] >= 2)
+    if part is not None:
+        sums = part.double().sum(0)
+        yd = y.detach().double()
+        assert rel_err(sums[:c], yd.sum((0, 2, 3))) < 1e-5 and rel_err(sums[c:], (yd * yd).sum((0, 2, 3))) < 1e-5
 
 
 @pytest.mark.parametrize('c,b,hw,relu,res', [(64, 4, 16, True, False), (256, 2, 9, True, True), (48, 3, 11, True, False),
