@@ -288,6 +288,20 @@ def _runs_concurrently(cand, device):
     return ok
 
 
+_deferred_wgrad = {}     # device index -> closure that launches a held-back 1x1 wgrad (runtime.defer_wgrad_1x1)
+
+
+def _defer_wgrad(device, fn):
+    flush_deferred_wgrad(device)
+    _deferred_wgrad[torch.device(device).index] = fn
+
+
+def flush_deferred_wgrad(device):
+    fn = _deferred_wgrad.pop(torch.device(device).index, None)
+    if fn is not None:
+        fn()
+
+
 def _side_stream(device):
     key = torch.device(device).index
     if key not in _side_streams:
@@ -327,6 +341,8 @@ def _keep_for_side(device, *tensors):
 def sync_side_streams():
     """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
     all-reduce reads the arena), then release the tensors kept alive for it."""
+    for idx in list(_deferred_wgrad):
+        flush_deferred_wgrad(torch.device('cuda', idx))
     for st in _side_streams.values():
         torch.cuda.current_stream().wait_stream(st)
     for keep in _side_keep.values():
@@ -589,6 +605,7 @@ class Conv2dFn(torch.autograd.Function):
         if dy is None:
             return (None,) * 12
         x, w_k = ctx.saved_tensors
+        flush_deferred_wgrad(x.device)
         stride, pad, dil, cin_w, has_bias = ctx.geom
         w, bias = ctx.w_param, ctx.b_param
         x_pl = ctx.x_pl
@@ -664,28 +681,38 @@ class Conv2dFn(torch.autograd.Function):
             # wgrad is off the critical chain (only the optimiser needs it), so it runs on a side stream: the matrix-bound
             # wgrad kernels then overlap the HBM-bound BatchNorm-backward kernels of the layers that follow on the main stream
             side = _side_stream(x.device) if _runtime.wgrad_side_stream else None
-            if side is not None:
-                ev = torch.cuda.Event()      # recorded AFTER the dgrad launch: wgrad starts when the dgrad is done (letting it
-                ev.record()                  # start next to the dgrad was measured 5 % slower, making every dgrad wait for the
-                                             # previous wgrad 2 % slower)
-                side.wait_event(ev)
-                _keep_for_side(x.device, x, dy, w_k, dy_amax, x_amax)
-            with torch.cuda.stream(side) if side is not None else _nullcontext():
-                sst = stream()
-                nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
-                ws = _ws(nbytes, x.device)
-                tgt = _grad_target(w)
-                if cin_w % 4 == 0:
-                    dw = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
-                    check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), None, ptr(ws), nbytes, sst))
-                else:
-                    dw4 = torch.empty((cout, r, s, cin), device=x.device)
-                    check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, sst))
-                    dw = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
-                    dw.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
-            if side is not None and tgt is None:
-                torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
-            dw = _deliver_grad(w, dw)
+            tgt = _grad_target(w)
+
+            def launch_wgrad(side=side, tgt=tgt, x=x, dy=dy, w=w, w_k=w_k, d=d, dy_amax=dy_amax, x_amax=x_amax):   # bound now: it may run later
+                if side is not None:
+                    ev = torch.cuda.Event()      # recorded AFTER the dgrad launch: wgrad starts when the dgrad is done (letting it
+                    ev.record()                  # start next to the dgrad was measured 5 % slower, making every dgrad wait for the
+                                                 # previous wgrad 2 % slower)
+                    side.wait_event(ev)
+                    _keep_for_side(x.device, x, dy, w_k, dy_amax, x_amax)
+                with torch.cuda.stream(side) if side is not None else _nullcontext():
+                    sst = stream()
+                    nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
+                    ws = _ws(nbytes, x.device)
+                    if cin_w % 4 == 0:
+                        dwl = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
+                        check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dwl), None, ptr(ws), nbytes, sst))
+                    else:
+                        dw4 = torch.empty((cout, r, s, cin), device=x.device)
+                        check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, sst))
+                        dwl = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
+                        dwl.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
+                if side is not None and tgt is None:
+                    torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
+                return _deliver_grad(w, dwl)
+
+            if _runtime.defer_wgrad_1x1 and r * s == 1 and side is not None and tgt is not None:
+                # an HBM-heavy 1x1 wgrad started now would run beside the (HBM-bound) BatchNorm backward that follows on the main
+                # stream; held back until the NEXT conv backward begins, it runs beside that conv's matrix-bound dgrad instead
+                _defer_wgrad(x.device, launch_wgrad)
+                dw = None
+            else:
+                dw = launch_wgrad()
         if has_bias and ctx.needs_input_grad[2]:
             if dy_pl:
                 dy, yp = from_planes(dy), _r4(cout)

@@ -16,6 +16,8 @@ class _Runtime:
         # BatchNorm statistics: re-measure ill-conditioned channels (mean^2 >> var) in a second pass (bn.hip kRefineRatio); PYLC_BN_REFINE=0
         # keeps the plain sum / sum-of-squares variance (A/B knob)
         self.bn_refine = os.environ.get('PYLC_BN_REFINE', '1') != '0'
+        # hold a 1x1 conv's wgrad back until the next conv backward starts (ops.Conv2dFn.backward): PYLC_DEFER_WGRAD=1 (A/B knob)
+        self.defer_wgrad_1x1 = os.environ.get('PYLC_DEFER_WGRAD', '0') == '1'
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)
