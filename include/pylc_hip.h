@@ -437,6 +437,9 @@ int pylc_debug_pp_flags(int flags);
 /* conv_pl.hip, 128-row tiles: start delay of the second block of every CU in the first round of blocks, in units of 2048 cycles
  * (< 0: the launch heuristic, about half a tile; 0: none) -- A/B knob for tools/pl_stagger_ab.py */
 int pylc_debug_stagger(int units);
+/* conv_p1.hip: 1 sends plain 1x1 / stride-1 launches to the persistent kernel whose stores leave under the next tile (off by default:
+ * measured neutral inside the step) */
+int pylc_debug_p1(int on);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */
 int pylc_debug_pp_stamps(unsigned long long* buf);

@@ -676,6 +676,7 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     if (a.dh_step > 2 || a.dh_step < -2 || a.dw_step > 2 || a.dw_step < -2) a.dbg_flags |= 4096;      // as launch_gg_pp
     a.ident = a.TR == 1 && a.TS == 1 && a.in_sh == 1 && a.in_sw == 1 && a.dh0 == 0 && a.dw0 == 0 && a.IH == a.P && a.IW == a.Q &&
               a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 && a.ow0 == 0 && a.OH == a.P && a.OW == a.Q;
+    if (!(g_pp_flags & (2048 | 8192)) && takes_p1(a)) return launch_gg_p1(a, st);     // 1x1: the persistent kernel whose stores leave under the next tile's main loop
     // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
     // tile's prologue / epilogue) -- for long reductions on grids that still fill the chip.  128 rows: two blocks per CU.
     // 3x3 / unit steps / 16-aligned output: the halo kernel (A-operand DMA once per channel chunk instead of once per tap)

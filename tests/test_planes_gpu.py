@@ -226,3 +226,46 @@ def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
     e = (rel(y.detach(), yr.detach()), rel(x.grad, xr.grad), rel(conv.weight.grad.detach(), wr.grad))
     print('mode 3 %s: y %.2e dx %.2e dw %.2e' % (case, *e))
     assert max(e) < 1e-3, e
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 256, 1024), (2, 64, 1024, 256), (1, 128, 64, 256), (2, 70, 256, 48), (1, 96, 72, 200)])
+@pytest.mark.parametrize('mode', [2, 3])
+def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode):
+    """conv_p1.hip (off by default: pylc_debug_p1): the persistent 1x1 kernel whose finished tile is stored under the next tile's main
+    loop -- output bit-identical to the per-tile kernel, run twice (the counted vmcnt of its main loop depends on every store being
+    issued: masked rows / channel quads, here Cout = 48 and ragged M, must not change the count), BatchNorm statistics equal to sums
+    over the output."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib, check
+    B, H, cin, cout = shape
+    prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
+    check(lib.pylc_set_conv_precision(mode))
+    ops.PLANES_MIN_PIXELS = 0
+    try:
+        torch.manual_seed(2)
+        conv = layers.Conv2d(cin, cout, 1, 1, 0, 1, bn=True).to(dev)
+        arena = optim.FlatArena(conv)
+        x = nhwc(rnd(31, B, cin, H, H, scale=2.0), dev)
+        xp = ops.to_planes(x)
+        lib.pylc_debug_pp_flags(1024 | 2048 | 16384)         # the 128-row per-tile kernel as the reference (same statistics rows)
+        outs = []
+        with torch.no_grad():
+            for on in (0, 1, 1):
+                lib.pylc_debug_p1(on)
+                lib.pylc_debug_pp_flags((1024 | 2048 | 16384) if on == 0 else 0)
+                y = ops.conv2d(xp, conv.weight, None, 1, 0, 1, want_stats=True)
+                torch.cuda.synchronize()
+                outs.append((y.clone(), y._pylc_sums.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
+        assert torch.equal(outs[1][1], outs[2][1])
+        if outs[0][1].shape == outs[1][1].shape:
+            assert torch.equal(outs[0][1], outs[1][1])
+        yd = outs[1][0].double()
+        sums = outs[1][1].double().sum(0)
+        cp = sums.shape[0] // 2
+        assert rel(sums[:cout], yd.sum((0, 2, 3))) < 1e-5 and rel(sums[cp:cp + cout], (yd * yd).sum((0, 2, 3))) < 1e-5
+    finally:
+        lib.pylc_debug_p1(0)
+        lib.pylc_debug_pp_flags(0)
+        ops.PLANES_MIN_PIXELS = prev_min
+        check(lib.pylc_set_conv_precision(prev))
