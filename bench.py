@@ -182,6 +182,7 @@ def main():
         model.train(x, y)
     ops.amax_passes[:] = [0, 0]
     ops.plane_conversions[:] = [0, 0]
+    ops.planes_marked[0] = 0
     timer = None
     if not args.no_kernel_timing:
         timer = ops.KernelTimer()
@@ -199,6 +200,7 @@ def main():
     mallocs = torch.cuda.memory_stats().get('num_device_alloc', 0) - mallocs
     ops.set_kernel_timer(None)
     range_passes, conversions = ops.amax_passes[0] / args.steps, ops.plane_conversions[0] / args.steps
+    planes_marked = ops.planes_marked[0] / args.steps
     n_buckets = len(model._bucketer.buckets) if model._bucketer is not None else 0
     collectives = pylc_amd.runtime.collectives / args.steps + n_buckets if world > 1 else 0.0
     # N = 1: what the data-parallel code path costs before any fabric is involved -- the same model, a one-rank RCCL group switched on
@@ -252,7 +254,9 @@ def main():
                    'collectives_per_step': collectives if world > 1 else dp_collectives,
                    'dp_codepath_overhead': dp_overhead,
                    'standalone_range_passes_per_step': range_passes,
-                   'activation_format': 'fp32' if pylc_amd.runtime.no_planes else 'fp16 planes between BatchNorm and conv kernels (4 B/element)',
+                   'activation_format': ('fp32' if (pylc_amd.runtime.no_planes or planes_marked == 0) else
+                                         'fp16 planes between BatchNorm and conv kernels (%d B/element)' % (2 * ops.nplanes())),
+                   'plane_tensors_per_step': planes_marked,      # 0: this network's convs (bias) stay on the fp32-operand kernels
                    'planes_to_fp32_conversions_per_step': conversions,
                    'hipmalloc_calls_in_timed_region': mallocs,      # 0 in steady state (diagnostic: see DESIGN.md section 5.2, open observation)
                    'last_loss': [float(v) for v in losses[-1]] if losses else None},

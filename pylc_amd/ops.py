@@ -57,6 +57,7 @@ def pitch_of(t):
 # the dtype and shape it expects.  The marker attribute names the range bound the planes were scaled with.  Only kernels that know
 # the format may touch the bytes: every other op goes through as_nhwc(), which converts back to fp32 (one pass, counted).
 plane_conversions = [0, 0]      # [planes -> fp32 conversion passes, elements]: diagnostics (0 on the hot path)
+planes_marked = [0]             # tensors produced (or re-marked in a backward) in the fp16-plane format: diagnostics
 
 
 def is_planes(t):
@@ -102,6 +103,7 @@ def conv_takes_planes(w, pixels_in, pixels_out):
 
 
 def mark_planes(t, amax):
+    planes_marked[0] += 1
     t._pylc_pl = (amax, t._version)
     tag_amax(t, amax)
     return t
