@@ -440,6 +440,8 @@ int pylc_debug_stagger(int units);
 /* conv_p1.hip: 1 sends plain 1x1 / stride-1 launches to the persistent kernel whose stores leave under the next tile (off by default:
  * measured neutral inside the step) */
 int pylc_debug_p1(int on);
+/* wgrad_pl.hip: 1 runs the 128 x 128 f16x3 wgrad with one accumulator set under 128 registers per wave (A/B knob) */
+int pylc_debug_wgrad_acc1(int on);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */
 int pylc_debug_pp_stamps(unsigned long long* buf);

@@ -19,8 +19,14 @@
 
 namespace pylc {
 
-template <int BN, int BC, int WN, int WC, int NTERMS, int FAST>
-__global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
+// ACC1 (NTERMS 3 only): ONE accumulator set instead of two -- the plane-1 fragments are multiplied by 2^-11 in registers (8 v_pk_mul_f16
+// per K-step next to 24 MFMAs; gfx950's MFMA keeps fp16 subnormals) and all three terms add into the same fp32 accumulator.  Same
+// terms, fp32-grade result, NOT bit-identical to the two-accumulator form (the small terms are rounded into the large sum as they
+// arrive).  What it buys is registers: 64 instead of 128 accumulators put the kernel under 128 VGPRs, so that with two blocks per CU
+// (an LDS reservation keeps a third and fourth out) half of every SIMD's register file stays free for the BatchNorm kernels of the
+// main stream -- with the efficient 64 x 64 wave tiles, unlike the 8-wave experiment above.
+template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false>
+__global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const WgradArgs a) {
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
     constexpr int WAVES_C = BC / WC;
     constexpr int NT = WN / 32, CT = WC / 32;
@@ -55,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
     const bool a_col_ok = n0 + 8 * va < a.N_ld && (A_ALL || pra < 32);         // N_ld % 8 == 0 (launch_wg_pl)
 
     f32x16 acc[NT][CT];
-    f32x16 acc_lo[NTERMS == 3 ? NT : 1][NTERMS == 3 ? CT : 1];
+    constexpr bool TWO_ACC = NTERMS == 3 && !ACC1;
+    f32x16 acc_lo[TWO_ACC ? NT : 1][TWO_ACC ? CT : 1];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
-                if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+                if constexpr (TWO_ACC) acc_lo[i][j][r] = 0.f;
             }
     const float scale_a = pow2_scale_for(*a.amax_dy), scale_b = pow2_scale_for(*a.amax_x);
 
@@ -185,6 +192,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
                 for (int j = 0; j < CT; ++j)
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
+                if constexpr (NTERMS == 3 && ACC1) {
+                    // cross terms first, each term over all four accumulators (a dependent MFMA is four instructions away)
+                    const _Float16 k11 = (_Float16)(1.f / 2048.f);
+                    f16x8 a1s[NT], b1s[CT];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) a1s[i] = __builtin_bit_cast(f16x8, fa[i][1]) * k11;
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) b1s[j] = __builtin_bit_cast(f16x8, fb[j][1]) * k11;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s[i], __builtin_bit_cast(f16x8, fb[j][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), b1s[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[j][0]),
+                                                                               acc[i][j], 0, 0, 0);
+                } else
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -214,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wave_n * WN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float val = acc[i][j][r];
-                if constexpr (NTERMS == 3) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                if constexpr (TWO_ACC) val = (val + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
                 else val = val * unscale_a * unscale_b;
                 if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = val;
             }
@@ -225,10 +257,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_pl_kernel(const WgradArgs a) {
 template <int BN, int BC, int NTERMS>
 constexpr size_t wgpl_smem() { return (size_t)(NTERMS == 3 ? 2 : 1) * 32 * (wg_rowb(BN) + wg_rowb(BC)); }
 
+// Measured (tools/acc1_ab.sh): the BatchNorm kernels do speed up next to it, but the matrix-bound dgrads of the main stream, which now
+// share their SIMDs with wgrad waves instead of alternating with whole wgrad blocks, lose far more (3x3 dgrad 319 -> 204 TFLOP/s, 1x1
+// 159 -> 98): 352-354 vs 376 tiles/s; raising the conv kernels' wave priority (s_setprio 3) does not change that.  OFF by default.
+int g_wg_acc1 = 0;        // 1: the 128 x 128 f16x3 wgrad runs its one-accumulator, <= 128-register form (pylc_debug_wgrad_acc1)
+extern "C" int pylc_debug_wgrad_acc1(int on) { g_wg_acc1 = on; return PYLC_OK; }
+constexpr size_t kAcc1LdsReserve = 72 * 1024;      // two blocks per CU, not four: the other half of the register file is for other kernels
+
 template <int BN, int BC, int WN, int WC>
 static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
     const int fast = a.Q % 32 == 0 ? 1 : 2;
     const dim3 g((unsigned)grid), b(256);
+    if constexpr (BN == 128 && BC == 128) {
+        if (a.nterms == 3 && g_wg_acc1) {
+            if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, true>), g, b, kAcc1LdsReserve, st, a);
+            else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, true>), g, b, kAcc1LdsReserve, st, a);
+            PYLC_LAUNCH_CHECK();
+            return PYLC_OK;
+        }
+    }
     if (a.nterms == 1) {
         constexpr size_t lds = wgpl_smem<BN, BC, 1>();
         if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>), g, b, lds, st, a);
@@ -267,6 +314,8 @@ int wgrad_pl_init() {
     PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>, wgpl_smem<BN, BC, 1>()));                  \
     PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>, wgpl_smem<BN, BC, 1>()));
     PYLC_OPT(128, 128, 64, 64)
+    PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 1, true>, kAcc1LdsReserve));
+    PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 2, true>, kAcc1LdsReserve));
     PYLC_OPT(64, 64, 32, 32)
     PYLC_OPT(32, 128, 32, 32)
 #undef PYLC_OPT

@@ -62,6 +62,7 @@ SIGNATURES = {
     'pylc_debug_pp_flags': (_I, [_I]),
     'pylc_debug_stagger': (_I, [_I]),
     'pylc_debug_p1': (_I, [_I]),
+    'pylc_debug_wgrad_acc1': (_I, [_I]),
     'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
@@ -175,6 +176,8 @@ def init():
         flags = os.environ.get('PYLC_DEBUG_FLAGS')
         if flags is not None:
             lib.pylc_debug_pp_flags(int(flags))
+        if os.environ.get('PYLC_WGRAD_ACC1') is not None:     # 1: one-accumulator 128x128 wgrad under 128 registers (A/B)
+            lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
         _initialised = True

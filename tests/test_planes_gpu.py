@@ -269,3 +269,34 @@ def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode):
         lib.pylc_debug_pp_flags(0)
         ops.PLANES_MIN_PIXELS = prev_min
         check(lib.pylc_set_conv_precision(prev))
+
+
+def test_one_accumulator_wgrad_is_fp32_grade(dev, f16x3):
+    """wgrad_pl.hip ACC1 (off by default: pylc_debug_wgrad_acc1): the 128 x 128 wgrad with ONE accumulator set under 128 registers --
+    cross terms scaled by 2^-11 in registers and added into the same fp32 accumulator.  Not bit-identical to the two-accumulator form,
+    but the same accuracy class: against fp64 within 2x the default kernel's error."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib
+    torch.manual_seed(3)
+    conv = layers.Conv2d(256, 256, 3, 1, 1, 1).to(dev)
+    arena = optim.FlatArena(conv)
+    x = nhwc(rnd(5, 2, 256, 32, 32, scale=2.0), dev).requires_grad_(True)
+    errs = {}
+    try:
+        for on in (0, 1):
+            lib.pylc_debug_wgrad_acc1(on)
+            arena.g.zero_()
+            x.grad = None
+            y = conv(x)
+            dy = nhwc(rnd(6, *y.shape), dev)
+            y.backward(dy)
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            wr = conv.weight.detach().double().cpu().requires_grad_(True)
+            yr = torch.nn.functional.conv2d(x.detach().double().cpu(), wr, None, 1, 1, 1)
+            yr.backward(dy.double().cpu())
+            errs[on] = rel(conv.weight.grad.detach(), wr.grad)
+    finally:
+        lib.pylc_debug_wgrad_acc1(0)
+    print('wgrad error vs fp64: two accumulators %.2e, one accumulator %.2e' % (errs[0], errs[1]))
+    assert errs[0] < 3e-6 and errs[1] < max(3e-6, 2 * errs[0])
