@@ -118,6 +118,11 @@ int pylc_to_planes(const float* x, int x_pitch, void* planes, int p_pitch, long 
                    const unsigned int* amax, int nplanes, void* stream);
 int pylc_from_planes(const void* planes, int p_pitch, long long plane_stride, float* x, int x_pitch, long long M, int C,
                      const unsigned int* amax, int nplanes, void* stream);
+/* sums[0:C] = per-channel sum over the M pixels of a planes tensor: a conv's bias gradient (nn.Conv2d(bias=True) backward,
+ * unet.py:112,116) when its dy arrives as planes.  workspace: pylc_planes_colsum_workspace_floats(C) floats. */
+size_t pylc_planes_colsum_workspace_floats(int C);
+int pylc_planes_colsum(const void* planes, int p_pitch, long long plane_stride, int nplanes, const unsigned int* amax, long long M, int C,
+                       float* sums, float* workspace, void* stream);
 
 /* y = conv(x, w) + bias.  bias may be NULL.  Channels [Cout, roundup4(Cout)) of y are written as zeros
  * when they fit inside y_pitch (9/11-class heads use a 12-float pitch). */

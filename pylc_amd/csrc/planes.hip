@@ -66,6 +66,47 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const f16* __restrict_
     }
 }
 
+// Per-channel sum over the pixels of a planes tensor (a conv's bias gradient when its dy arrives as planes): partial[block][C] in fp32
+// per row slab, combined in fp64 / fixed order by column_sum_kernel (common.h) -- the arithmetic of pylc_bn_stats's first half.
+constexpr int kColsumSlabs = 768;
+template <int NPL>
+__global__ __launch_bounds__(256) void planes_colsum_kernel(const f16* __restrict__ planes, int p_pitch, long long plane_stride, long long M, int C8,
+                                                            int cols, int RL, long long rows_per_slab, const unsigned* __restrict__ amax,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[256][9];
+    const float inv = 1.f / pow2_scale_for(*amax);
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    const long long r_begin = (long long)blockIdx.x * rows_per_slab;
+    long long r_end = r_begin + rows_per_slab;
+    if (r_end > M) r_end = M;
+    for (int cb = 0; cb < C8; cb += cols) {
+        const int c8 = cb + tx;
+        const bool active = ty < RL && c8 < C8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            for (long long r = r_begin + ty; r < r_end; r += RL) {
+                const f16x8 h0 = *reinterpret_cast<const f16x8*>(planes + r * p_pitch + 8 * c8);
+                f16x8 h1 = {};
+                if constexpr (NPL == 2) h1 = *reinterpret_cast<const f16x8*>(planes + plane_stride + r * p_pitch + 8 * c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += ((float)h0[e] + (float)h1[e] * (1.f / 2048.f)) * inv;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+        __syncthreads();
+        if (ty == 0 && c8 < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sum = acc[e];
+                for (int q = 1; q < RL; ++q) sum += red[q * cols + tx][e];
+                partial[(size_t)blockIdx.x * (8 * C8) + 8 * c8 + e] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int check_planes(const void* planes, int p_pitch, long long plane_stride, long long M, int C, int nplanes, const char* what) {
     PYLC_REQUIRE(planes && M > 0 && C > 0 && C % 8 == 0, "%s: need M > 0 and C %% 8 == 0 (M=%lld C=%d)", what, M, C);
     PYLC_REQUIRE(p_pitch >= C && p_pitch % 8 == 0, "%s: plane pitch %d invalid for C=%d (multiple of 8)", what, p_pitch, C);
@@ -101,6 +142,31 @@ extern "C" int pylc_from_planes(const void* planes, int p_pitch, long long plane
     const dim3 g(blocks > 0 ? blocks : 1), b(256);
     if (nplanes == 2) hipLaunchKernelGGL((from_planes_kernel<2>), g, b, 0, as_stream(stream), static_cast<const f16*>(planes), p_pitch, plane_stride, x, x_pitch, M, C / 8, amax);
     else hipLaunchKernelGGL((from_planes_kernel<1>), g, b, 0, as_stream(stream), static_cast<const f16*>(planes), p_pitch, plane_stride, x, x_pitch, M, C / 8, amax);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+extern "C" size_t pylc_planes_colsum_workspace_floats(int C) { return (size_t)kColsumSlabs * (size_t)C; }
+
+extern "C" int pylc_planes_colsum(const void* planes, int p_pitch, long long plane_stride, int nplanes, const unsigned int* amax, long long M, int C,
+                                  float* sums, float* workspace, void* stream) {
+    if (int rc = check_planes(planes, p_pitch, plane_stride, M, C, nplanes, "planes_colsum")) return rc;
+    PYLC_REQUIRE(amax && sums && workspace, "planes_colsum: null pointer");
+    const int C8 = C / 8;
+    const int cols = C8 < 256 ? C8 : 256;
+    const int RL = 256 / cols;
+    long long rps = cdiv<long long>(M, kColsumSlabs);
+    if (rps < (long long)RL * 8) rps = (long long)RL * 8;
+    rps = cdiv<long long>(rps, RL) * RL;
+    const int nslab = (int)cdiv<long long>(M, rps);
+    hipStream_t st = as_stream(stream);
+    const f16* p = static_cast<const f16*>(planes);
+    if (nplanes == 2)
+        hipLaunchKernelGGL(planes_colsum_kernel<2>, dim3(nslab), dim3(256), 0, st, p, p_pitch, plane_stride, M, C8, cols, RL, rps, amax, workspace);
+    else
+        hipLaunchKernelGGL(planes_colsum_kernel<1>, dim3(nslab), dim3(256), 0, st, p, p_pitch, plane_stride, M, C8, cols, RL, rps, amax, workspace);
+    PYLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, workspace, nslab, C, sums);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

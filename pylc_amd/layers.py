@@ -37,7 +37,7 @@ class Conv2d(nn.Module):
 
     def takes_planes(self):
         """Static part of ops.conv_takes_planes: a BatchNorm that feeds ONLY convs for which this holds may write fp16 planes."""
-        return self.cout % 4 == 0 and self.cin % 8 == 0 and self.bias is None
+        return self.cout % 4 == 0 and self.cin % 8 == 0
 
     def extra_repr(self):
         return '%d, %d, k=%d, s=%d, p=%d, d=%d%s' % (self.cin, self.cout, self.k, self.stride, self.padding, self.dilation,

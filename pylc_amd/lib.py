@@ -68,6 +68,8 @@ SIGNATURES = {
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
     'pylc_to_planes': (_I, [_P, _I, _P, _I, _LL, _LL, _I, _P, _I, _P]),
     'pylc_from_planes': (_I, [_P, _I, _LL, _P, _I, _LL, _I, _P, _I, _P]),
+    'pylc_planes_colsum_workspace_floats': (C.c_size_t, [_I]),
+    'pylc_planes_colsum': (_I, [_P, _I, _LL, _I, _P, _LL, _I, _P, _P, _P]),
     'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),
     'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),

@@ -521,9 +521,9 @@ class Conv2dFn(torch.autograd.Function):
             res_link.pending += 1
         cout, cin_w, r, s = w.shape
         b_, _, h_, w_ = x.shape
-        # (a conv with a bias keeps fp32 operands: its bias gradient is a column sum of dy, which wants fp32 -- only the U-Net's convs
-        # and the class heads carry one)
-        takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None and bias is None
+        # (a bias is added by the planes kernels' epilogue like any other; its gradient is a column sum over the dy planes,
+        # pylc_planes_colsum)
+        takes = conv_takes_planes(w, b_ * h_ * w_, 0) and w_amax is not None and out is None
         if takes and not is_planes(x) and convert:
             # (convert: training graphs only -- grad mode as seen by ops.conv2d; inference keeps fp32 operands and the kernels the
             # fused conv + BatchNorm epilogue path runs)
@@ -716,13 +716,15 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw = launch_wgrad()
         if has_bias and ctx.needs_input_grad[2]:
-            if dy_pl:
-                dy, yp = from_planes(dy), _r4(cout)
             m = dy.shape[0] * dy.shape[2] * dy.shape[3]
             cp = _r4(cout)
             sums = torch.empty(2 * cp, device=x.device)
-            ws = torch.empty(lib.pylc_bn_workspace_floats(m, cp), device=x.device)
-            check(lib.pylc_bn_stats(ptr(dy), m, cp, yp, ptr(sums), ptr(ws), st))
+            if dy_pl:       # per-channel sums straight from the planes (one read pass, as the fp32 form)
+                ws = torch.empty(lib.pylc_planes_colsum_workspace_floats(cout), device=x.device)
+                check(lib.pylc_planes_colsum(ptr(dy), cout, m * cout, nplanes(), ptr(planes_amax(dy)), m, cout, ptr(sums), ptr(ws), st))
+            else:
+                ws = torch.empty(lib.pylc_bn_workspace_floats(m, cp), device=x.device)
+                check(lib.pylc_bn_stats(ptr(dy), m, cp, yp, ptr(sums), ptr(ws), st))
             tgt = _grad_target(bias)
             if tgt is not None:
                 tgt.copy_(sums[:cout])

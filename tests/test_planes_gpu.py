@@ -300,3 +300,47 @@ def test_one_accumulator_wgrad_is_fp32_grade(dev, f16x3):
         lib.pylc_debug_wgrad_acc1(0)
     print('wgrad error vs fp64: two accumulators %.2e, one accumulator %.2e' % (errs[0], errs[1]))
     assert errs[0] < 3e-6 and errs[1] < max(3e-6, 2 * errs[0])
+
+
+@pytest.mark.parametrize('case', [(128, 128, 3, 1, 0, 1, 2, 40, 40), (128, 256, 1, 1, 0, 1, 2, 32, 32), (64, 128, 3, 1, 0, 1, 2, 36, 36)])
+def test_conv_with_bias_on_planes(dev, f16x3, case):
+    """nn.Conv2d(bias=True) (the U-Net's convs, unet.py:112,116) on fp16-plane operands: the bias is added by the planes kernels' epilogue,
+    its gradient is a column sum over the dy planes (pylc_planes_colsum) -- y / dx / dw bit-identical to the fp32-operand kernels, db to
+    fp32 summation-order noise and against fp64."""
+    from pylc_amd import ops, layers, optim, runtime
+    from pylc_amd.lib import lib
+    cin, cout, k, st, pad, dil, B, H, W = case
+    torch.manual_seed(4)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil, bias=True).to(dev)
+    conv.bias.data.uniform_(-0.5, 0.5)
+    arena = optim.FlatArena(conv)
+    assert conv.takes_planes()
+    x = nhwc(rnd(5, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    out = {}
+    for mode in ('fp32', 'planes'):
+        runtime.no_planes = mode == 'fp32'
+        lib.pylc_debug_pp_flags(1024 if mode == 'fp32' else 0)
+        x.grad = None
+        arena.g.zero_()
+        y = conv(x)
+        if mode == 'planes':
+            assert getattr(y, '_pylc_dy_pl', False)
+        dy = nhwc(rnd(6, *y.shape), dev)
+        if mode == 'planes':
+            dy = ops.to_planes(dy)                      # as a BatchNorm backward hands it over
+        y.backward(dy)
+        ops.sync_side_streams()
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.detach().clone(), conv.bias.grad.detach().clone())
+    runtime.no_planes = False
+    lib.pylc_debug_pp_flags(0)
+    exact = {'y': cout > 64, 'dx': cin > 64, 'dw': True}        # as test_conv_on_planes_is_bit_identical: same MFMA shape on both sides
+    for name, a, b in zip(('y', 'dx', 'dw'), out['fp32'], out['planes']):
+        if exact[name]:
+            assert torch.equal(a, b), (name, rel(a, b))
+        else:
+            assert rel(a, b) < 2e-6, (name, rel(a, b))
+    db_ref = nhwc(rnd(6, *out['fp32'][0].shape), dev).double().sum((0, 2, 3)).cpu()
+    assert rel(out['planes'][3], db_ref) < 1e-5 and rel(out['fp32'][3], db_ref) < 1e-5
+    ref = torch.nn.functional.conv2d(x.detach().double().cpu(), conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), st, pad, dil)
+    assert rel(out['planes'][0], ref) < 3e-6
