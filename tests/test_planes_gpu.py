@@ -344,3 +344,69 @@ def test_conv_with_bias_on_planes(dev, f16x3, case):
     assert rel(out['planes'][3], db_ref) < 1e-5 and rel(out['fp32'][3], db_ref) < 1e-5
     ref = torch.nn.functional.conv2d(x.detach().double().cpu(), conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), st, pad, dil)
     assert rel(out['planes'][0], ref) < 3e-6
+
+
+@pytest.mark.parametrize('case', [(128, 128, 8, 64, 64), (64, 256, 4, 128, 128), (256, 136, 8, 48, 80)])
+def test_halo_kernel_is_bit_identical(dev, f16x3, case):
+    """The 3x3 halo variant (conv_pl.hip gg_plh_kernel: a 16x16 output patch's 18x18 input rows DMA'd once per channel chunk) takes
+    launches of at least half a round of 256-pixel tiles -- larger than the other cases of this file: forward and dgrad (flipped taps)
+    against the fp32-operand kernel bit for bit and against the non-halo planes kernel (debug flag 16384), y also against fp64."""
+    from pylc_amd import ops, layers, optim, runtime
+    from pylc_amd.lib import lib
+    cin, cout, B, H, W = case
+    torch.manual_seed(5)
+    conv = layers.Conv2d(cin, cout, 3, 1, 1, 1).to(dev)
+    arena = optim.FlatArena(conv)
+    x = nhwc(rnd(7, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    out = {}
+    for mode, flags, nopl in (('fp32', 1024, True), ('halo', 0, False), ('nohalo', 16384, False)):
+        runtime.no_planes = nopl
+        lib.pylc_debug_pp_flags(flags)
+        x.grad = None
+        arena.g.zero_()
+        y = conv(x)
+        dy = nhwc(rnd(8, *y.shape), dev)
+        y.backward(dy)
+        ops.sync_side_streams()
+        torch.cuda.synchronize()
+        out[mode] = (y.detach().clone(), x.grad.clone())
+    runtime.no_planes = False
+    lib.pylc_debug_pp_flags(0)
+    assert torch.equal(out['halo'][0], out['nohalo'][0]) and torch.equal(out['halo'][1], out['nohalo'][1])
+    if cout > 64:
+        assert torch.equal(out['halo'][0], out['fp32'][0])
+    if cin > 64:
+        assert torch.equal(out['halo'][1], out['fp32'][1])
+    ref = torch.nn.functional.conv2d(x.detach().double().cpu(), conv.weight.detach().double().cpu(), None, 1, 1, 1)
+    assert rel(out['halo'][0], ref) < 3e-6
+
+
+@pytest.mark.parametrize('case', [(256, 256, 3, 1, 1, 1, 2, 32, 32), (72, 200, 3, 1, 6, 6, 3, 30, 30), (1024, 256, 1, 1, 0, 1, 2, 32, 32),
+                                  (128, 128, 3, 2, 1, 1, 2, 45, 45)])
+def test_256_row_planes_kernel_is_bit_identical(dev, f16x3, case):
+    """The 256 x 128 instantiation of gg_pl_kernel (8 waves, three LDS stages, counted vmcnt, wave-pair de-phasing) is picked for long
+    reductions on grids of >= 256 tiles -- larger than this file's cases, so it is forced here (debug flag 8192) and compared with the
+    128-row instantiation (flag 2048): forward and dgrad bit for bit, incl. row / channel tails, atrous tap skipping, stride-2 dgrad."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib
+    cin, cout, k, st, pad, dil, B, H, W = case
+    torch.manual_seed(6)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil).to(dev)
+    arena = optim.FlatArena(conv)
+    x = nhwc(rnd(9, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    out = {}
+    try:
+        for name, flags in (('128', 2048 | 16384), ('256', 8192 | 16384), ('256-lockstep', 8192 | 16384 | 32768)):
+            lib.pylc_debug_pp_flags(flags)
+            x.grad = None
+            arena.g.zero_()
+            y = conv(x)
+            dy = nhwc(rnd(10, *y.shape), dev)
+            y.backward(dy)
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            out[name] = (y.detach().clone(), x.grad.clone())
+    finally:
+        lib.pylc_debug_pp_flags(0)
+    for name in ('256', '256-lockstep'):
+        assert torch.equal(out[name][0], out['128'][0]) and torch.equal(out[name][1], out['128'][1]), name
