@@ -98,7 +98,11 @@ def cpu_baseline(hw, n_cls, budget_s=25.0):
     """Reference CPU path (oracle) on this box's host cores: bs=2 steps of the same train step, bounded in time."""
     import oracle
     from oracle import step as ostep
-    cores = torch.get_num_threads()
+    # the GPU box shows 128 host threads but a one-GPU job's CPU share is 16: at 128 threads oneDNN's workers mostly wait for each other
+    # (measured on the box, bs 2: 0.31 tiles/s at 128 threads, 0.84 at 64, 1.43 at 32, 2.39 at 16 -- tools/cpu_threads.py)
+    cores = min(torch.get_num_threads(), 16)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
     b = 2
     cfg = ostep.StepConfig('deeplab', 'resnet', n_cls, 3)
     sd = oracle.init_state(oracle.state_spec('deeplab', 'resnet', n_cls, 3), seed=0)
@@ -116,6 +120,7 @@ def cpu_baseline(hw, n_cls, budget_s=25.0):
     if not times:
         times = [warm]
     med = float(np.median(times))
+    torch.set_num_threads(prev_threads)
     return {'value': b / med, 'unit': 'tiles/s', 'cores': cores, 'kind': 'port',
             'sample': 'CPU oracle (restatement pinned bit-exactly to the reference), DeepLabV3+/R101 %dx%d bs=%d full '
                       'train step, %d timed step(s) after 1 warm-up, median' % (hw, hw, b, len(times))}
