@@ -68,6 +68,15 @@ def load_reference_file(path, map_location='cpu'):
     return data
 
 
+def load_losses_file(path):
+    """Read a `losses.pth` (RunningLoss.save, models/modules/loss.py:296-305) written by this package OR by the reference -- whose
+    entries are numpy scalars -- through the allow-listed unpickler.  Returns the raw dict."""
+    data = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_tolerant_pickle)
+    if not isinstance(data, dict) or 'train' not in data or 'best_dice' not in data:
+        raise ValueError('%s is not a PyLC loss log (no "train" / "best_dice" entries)' % path)
+    return data
+
+
 def meta_from_reference(ref_meta, base=None):
     """Copy the hot-path fields of a (bagged) config.Parameters into a Meta (config.py:259-269 semantics)."""
     meta = base if base is not None else Meta()

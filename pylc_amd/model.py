@@ -95,9 +95,20 @@ class LossLog:
         if not resume:
             os.remove(path)
             return False
-        res = torch.load(path, map_location='cpu', weights_only=True)
-        self.train, self.valid, self.test = list(res['train']), list(res['valid']), list(res.get('test', []))
-        self.best_dice = float(res['best_dice'])
+        # The reference's RunningLoss stores validation averages and best_dice as NUMPY scalars (Model.eval appends `.cpu().numpy()`
+        # values, models/model.py:360-363, loss.py:284-304), which torch.load(weights_only=True) refuses: read the file through the
+        # checkpoint module's allow-listed unpickler (numpy scalar / dtype / _reconstruct are on its list) and coerce to python floats.
+        from .checkpoint import load_losses_file
+        try:
+            res = load_losses_file(path)
+            rows = {k: [(int(row[0]),) + tuple(float(v) for v in row[1:]) for row in res.get(k, [])] for k in ('train', 'valid', 'test')}
+            best = float(res['best_dice'])
+        except Exception as e:      # an unreadable log must not abort the resume of the weights: restart the log
+            import warnings
+            warnings.warn('losses.pth at %s is unreadable (%s: %s); the loss log restarts' % (path, type(e).__name__, e))
+            return False
+        self.train, self.valid, self.test = rows['train'], rows['valid'], rows['test']
+        self.best_dice = best
         return True
 
     def push(self, triple):
@@ -135,6 +146,7 @@ class Model:
         self.iter = 0
         self.epoch = 0
         self._bucketer = None
+        self._ranges_checked = False        # eval / test: False until the first batch after a training step has re-measured the weight ranges
 
     def update_meta(self, params):
         self.meta.update(params)
@@ -203,6 +215,7 @@ class Model:
     def train(self, x, y):
         """One optimisation step (model.py:282-336)."""
         self.net.train()       # (parameter ranges / prepared filters are current: refreshed by every optimiser step and state load)
+        self._ranges_checked = False
         x4 = self.pack_input(x)
         y = self.crop_target(y.to(self.device, non_blocking=True).long())
         y_hat = self.net(x4)
@@ -211,9 +224,11 @@ class Model:
         self.optim.zero_grad()
         if runtime.sync_group is not None:
             from .parallel import GradBucketer, assert_equal_shards
-            if getattr(self, '_dp_batch', None) != x.shape[0]:
-                # n_global = n_local * world everywhere (SyncBN, loss head): checked at set-up and again whenever the local batch size
-                # changes (a shorter final batch) -- a collective, so the batch size has to change on all ranks in the same step
+            if getattr(self, '_dp_batch', None) is None:
+                # n_global = n_local * world everywhere (SyncBN, loss head).  Checked by a collective ONCE, at every rank's first step (the
+                # same step on all ranks, so the collective sequences stay aligned); afterwards every step's loss exchange carries the
+                # tile counts (ops.MultiLossFn) and the reduced pair is compared at the report interval (self.log) -- a shorter final
+                # batch on SOME ranks then raises there instead of desynchronising the ranks with a collective only they enter.
                 assert_equal_shards(x.shape[0], runtime.sync_group)
                 self._dp_batch = x.shape[0]
             if self._bucketer is None:
@@ -236,7 +251,7 @@ class Model:
     def eval(self, x, y):
         """Validation step (model.py:338-365): eval-mode forward, the three losses, returns [y_hat]."""
         self.net.eval()
-        self.arena.refresh_if_changed()
+        self._refresh_for_inference()
         x4 = self.pack_input(x)
         y = self.crop_target(y.to(self.device, non_blocking=True).long())
         with torch.no_grad():
@@ -246,12 +261,21 @@ class Model:
 
     def test(self, x):
         """Inference forward (model.py:367-382)."""
-        self.arena.refresh_if_changed()
+        self._refresh_for_inference()
         x4 = self.pack_input(x, default=self.meta.normalize_default)
         with torch.no_grad():
             return [self.net(x4)]
 
+    def _refresh_for_inference(self):
+        """Weight ranges / prepared filter planes for an eval-mode forward: re-measured unconditionally on the first batch after a training
+        step or after construction (a `p.data` write -- EMA, weight surgery -- does not bump the version counters refresh_if_changed
+        compares), then only when a counter moved or `arena.invalidate()` was called."""
+        self.arena.refresh_if_changed(force=not self._ranges_checked)
+        self._ranges_checked = True
+
     def log(self):
+        if runtime.sync_group is not None:
+            ops.check_equal_shards()
         self.loss.log(self.iter, self.net.training)
 
     def get_lr(self):

@@ -2114,6 +2114,30 @@ def pack_nchw(x, pitch):
 # ----------------------------------------------------------------------------------------------
 # MultiLoss
 # ----------------------------------------------------------------------------------------------
+_shard_pairs = {}
+
+
+def _shard_pair(b, dev):
+    """[b, b^2] as a cached device tensor (exact in fp32 for any realistic per-rank tile count)."""
+    key = (int(b), str(dev))
+    if key not in _shard_pairs:
+        _shard_pairs[key] = torch.tensor([float(b), float(b) * float(b)], device=dev)
+    return _shard_pairs[key]
+
+
+def check_equal_shards():
+    """Raise if the last data-parallel loss exchange saw different tile counts on different ranks (the pair that rode on it, see
+    MultiLossFn.forward).  One tiny D2H copy: called where the host reads the loss log anyway (Model.log)."""
+    chk, _runtime.shard_check = _runtime.shard_check, None
+    if chk is None:
+        return
+    pair, world = chk
+    sb, sb2 = (float(v) for v in pair.cpu().tolist())
+    if abs(sb2 * world - sb * sb) > 0.5:
+        raise RuntimeError('data-parallel ranks hold different batch sizes (sum b = %g, sum b^2 = %g over %d ranks): SyncBN and the loss '
+                           'head need equal shards -- use a drop_last loader' % (sb, sb2, world))
+
+
 class MultiLossFn(torch.autograd.Function):
     """Returns a [4] tensor (total, ce, dice, focal); only total carries gradient."""
 
@@ -2129,13 +2153,19 @@ class MultiLossFn(torch.autograd.Function):
         dev = logits.device
         st = stream()
         k = 3 + 3 * c
-        stats = torch.empty(k, device=dev)
+        # data parallel: two more floats ride on the statistics message -- this rank's tile count b and b^2 -- so that unequal shards are
+        # DETECTED without a collective of their own (sum b^2 * world == (sum b)^2 iff all equal; Model.train checks the reduced pair at its
+        # report interval).  A separate all_gather triggered by a rank-local condition would desynchronise the ranks' collective sequences
+        # in exactly the case it is meant to catch.
+        stats = torch.empty(k + (2 if group is not None else 0), device=dev)
         ws = torch.empty(lib.pylc_multiloss_workspace_floats(n, c), device=dev)
         check(lib.pylc_multiloss_stats(ptr(logits), pitch_of(logits), ptr(target), n, c, ptr(class_weights), ptr(stats), ptr(ws), st))
         n_global = float(n)
         if group is not None:
+            stats[k:].copy_(_shard_pair(b, dev), non_blocking=True)
             _runtime.sync_all_reduce(stats, group)   # Dice / weighted CE are not shard-decomposable
             n_global = float(n) * dist.get_world_size(group)
+            _runtime.shard_check = (stats[k:], dist.get_world_size(group))
         losses = torch.empty(4, device=dev)
         check(lib.pylc_multiloss_finalize(ptr(stats), n_global, c, w_ce, w_dice, w_focal, ptr(losses), st))
         ctx.save_for_backward(logits, target, stats, class_weights)

@@ -75,24 +75,36 @@ class FlatArena:
                                   self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
         self._index = {id(p): i for i, p in enumerate(params)}
         self._delivered = set()          # parameters whose gradient a backward kernel wrote since the last zero_grad()
+        self._stale = False              # invalidate(): values changed through a path the version counters do not see
         self.generation = 0              # bumped whenever parameter VALUES may have changed (refresh_ranges): derived buffers key on it
         me = weakref.ref(self)           # no module -> arena strong reference: a dropped model frees its memory by refcount
         module.register_load_state_dict_post_hook(lambda *_: me() is not None and me().refresh_ranges())
         self.refresh_ranges()
 
-    def refresh_if_changed(self):
+    def refresh_if_changed(self, force=False):
         """refresh_ranges() unless nothing can have moved the parameters since the last refresh: everything in this package that writes them
         (the flat optimisers, load_state_dict through the hook above, parallel.broadcast_parameters) refreshes by itself, and an in-place
-        torch operation on a parameter bumps its version counter, which is what is compared here.  Model.eval / Model.test call this per
-        batch: an inference loop then neither re-measures 59 M weights nor invalidates what was derived from them (generation)."""
-        if sum(p._version for p in self.params) != self._version_sum:
+        torch operation ON THE PARAMETER (`p.mul_()`, `p.copy_()` under no_grad) bumps its version counter, which is what is compared here.
+        NOT detected: writes through `p.data` (`p.data.copy_()`, EMA / weight surgery idioms) and raw-pointer writers -- `.data` is a
+        fresh alias whose writes do not bump `p._version`.  After such a write call `invalidate()` (or `refresh_ranges()`): stale ranges
+        mean stale fp16 scales and prepared filter planes, and weights that outgrew the old range would overflow the f16 split.
+        Model.eval / Model.test call this per batch -- an inference loop then neither re-measures 59 M weights nor invalidates what was
+        derived from them (generation) -- and FORCE it on the first batch after a training step or a mode change, so a `.data` write made
+        between training and validation is picked up without the caller knowing about this cache."""
+        if force or self._stale or sum(p._version for p in self.params) != self._version_sum:
             self.refresh_ranges()
+
+    def invalidate(self):
+        """Declare the parameter values changed behind this arena's back (a `.data` write, a raw-pointer writer): the next
+        refresh_if_changed() -- i.e. the next Model.eval / Model.test batch -- re-measures the ranges and rebuilds the filter planes."""
+        self._stale = True
 
     def refresh_ranges(self, ranges_current=False):
         """Recompute every parameter's max magnitude and rebuild the prepared filter planes from it.  Call after anything
         that changes parameter values (the optimiser steps here do; Model refreshes at the start of each step as well).
         ranges_current: self.amax was just written by the kernel that changed the parameters (pylc_adamw_step_ranges)."""
         self.generation += 1
+        self._stale = False
         self._version_sum = sum(p._version for p in self.params)
         if self.p.is_cuda:
             L.init()

@@ -59,6 +59,7 @@ class _Runtime:
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         # PYLC_NO_PLANES=1: keep every activation fp32 (the conv kernels split operands themselves) -- A/B and bit-identity tests
         self.no_planes = bool(os.environ.get('PYLC_NO_PLANES'))
+        self.shard_check = None       # (reduced [sum b, sum b^2] device pair, world) of the last data-parallel loss exchange (ops.check_equal_shards)
         self.collectives = 0          # SyncBN / loss collectives issued (diagnostics: bench.py collectives_per_step)
         self.seed = 0x5EED
         self._counter = itertools.count(1)

@@ -1,7 +1,9 @@
 """CPU suite (-m "not gpu"): the N>1 path on 2 and on 8 gloo processes (the world size of the node the scaling bench runs on) --
-bucketed gradient SUM all-reduce over the flat arena, bucket firing order, parameter broadcast, the "N ranks == one process at the
-global batch" algebra of the SyncBN / loss-head exchanges (the wire formats all-reduced by pylc_amd/ops.py) checked against the CPU
-oracle on the global batch, and the inference tile gather with ragged shards (35 tiles, some ranks holding none)."""
+bucketed gradient SUM all-reduce over the flat arena, bucket firing order, parameter broadcast, the product's lock-step SyncBN message
+driver (ops._drive_collectives: one collective per round whatever the number of layers), the equal-shard check that rides on the loss
+exchange, and the inference tile gather with ragged shards (35 tiles, some ranks holding none).  The "N ranks == one process at the
+global batch" equivalence of the SyncBN / loss-head exchanges is checked with the REAL kernels and wire formats on the GPU
+(tests/test_nets_gpu.py::test_ranks_equal_one_process_at_global_batch, 2 and 4 ranks), not restated here."""
 import os
 import subprocess
 import sys
@@ -65,41 +67,44 @@ assert fired == sorted(fired, reverse=True) and len(fired) == len(gb.buckets) - 
 gb.finish()
 assert torch.equal(arena.g, torch.arange(arena.numel, dtype=torch.float32) %% 777 * (world * (world + 3) // 2))
 
-# --- 2. SyncBN algebra: all-reduced [sum, sumsq, n] -> global-batch statistics ----------------------------------------
-rs = np.random.RandomState(5)
-xg = torch.from_numpy(rs.standard_normal((8, 16, 6, 6)).astype(np.float32) * 2 + 0.3)     # global batch
-per = 8 // world
-xl = xg[rank * per:(rank + 1) * per]
-c = 16
-sums = torch.cat([xl.sum((0, 2, 3)), (xl * xl).sum((0, 2, 3)), torch.tensor([float(xl.numel() // c)])])
-dist.all_reduce(sums)
-n = sums[2 * c].item()
-mean = sums[:c] / n
-var = sums[c:2 * c] / n - mean * mean
-rm, rv = torch.zeros(c), torch.ones(c)
-ref = F.batch_norm(xg, rm, rv, None, None, True, 0.1, 1e-5)
-mine = (xl - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5)
-assert (mine - ref[rank * per:(rank + 1) * per]).abs().max().item() < 1e-5
-assert (rv - (0.9 + 0.1 * var * n / (n - 1))).abs().max().item() < 1e-5
+# --- 2. SyncBN message coalescing: the PRODUCT's lock-step driver (ops._drive_collectives, what ops.GroupBnActFn runs the ASPP's five
+#        BatchNorm generators through) on %(world)d ranks.  The generators here are stand-ins that yield CPU tensors the way BnActFn._forward /
+#        _backward yield theirs (fp64 [sum | sumsq | n] moments of 2C+1 entries; fp32 [sum g xhat | sum g] of 2C) -- the kernels that fill
+#        the real messages need the GPU and run in tests/test_nets_gpu.py::test_ranks_equal_one_process_at_global_batch. ---------------
+from pylc_amd import ops
+def layer(c, rounds, dtype):
+    got = []
+    for r in range(rounds):
+        msg = torch.arange(2 * c + 1, dtype=dtype) * (rank + 1) + 100 * r
+        yield msg                                    # the driver all-reduces it IN PLACE (alone) or through one concatenated message
+        got.append(msg.clone())
+    return (c, got)
+tri = world * (world + 1) // 2
+for spec in ([(16, 2)], [(16, 1), (8, 1), (32, 1), (8, 1), (256, 1)], [(16, 2), (8, 0), (4, 1), (4, 3)]):
+    c0 = runtime.collectives
+    res = ops._drive_collectives([layer(c, r, torch.float64) for c, r in spec], runtime.sync_group)
+    assert runtime.collectives - c0 == max(r for _, r in spec)          # ONE collective per round, however many layers take part
+    for (c, rounds), (c_back, got) in zip(spec, res):
+        assert c_back == c and len(got) == rounds
+        for r, msg in enumerate(got):
+            assert msg.dtype == torch.float64 and torch.equal(msg, torch.arange(2 * c + 1, dtype=torch.float64) * tri + 100 * r * world)
+res = ops._drive_collectives([layer(8, 1, torch.float32), layer(24, 1, torch.float32)], runtime.sync_group)      # the backward's fp32 sums
+assert all(torch.equal(g[0], torch.arange(2 * c + 1, dtype=torch.float32) * tri) for c, g in res)
 
-# --- 3. loss-head algebra: all-reduced 3+3C partials -> the global-batch MultiLoss of the oracle ---------------------
-C = 9
-z = torch.from_numpy(rs.standard_normal((8, C, 10, 10)).astype(np.float32) * 2)
-t = torch.from_numpy(rs.randint(0, C, (8, 10, 10)).astype(np.int64))
-zl, tl = z[rank * per:(rank + 1) * per], t[rank * per:(rank + 1) * per]
-p = F.softmax(zl, 1)
-oh = F.one_hot(tl, C).permute(0, 3, 1, 2).float()
-pt = (p * oh).sum(1)
-stats = torch.cat([(-torch.log_softmax(zl, 1) * oh).sum().reshape(1), torch.tensor([float(tl.numel())]),
-                   (-0.25 * (1 - (pt + 1e-8)) ** 2 * torch.log(pt + 1e-8)).sum().reshape(1),
-                   (p * oh).sum((0, 2, 3)), p.sum((0, 2, 3)), oh.sum((0, 2, 3))])
-dist.all_reduce(stats)
-ng = float(t.numel())
-ce = stats[0] / stats[1]
-fl = stats[2] / ng
-dice = (1 - (2 * stats[3:3 + C] + 1) / (stats[3 + C:3 + 2 * C] + stats[3 + 2 * C:] + 1)).mean()
-tot, oce, odice, ofl = oracle.multiloss(z, t)
-assert abs(ce - oce) < 1e-5 and abs(dice - odice) < 1e-5 and abs(fl - ofl) < 1e-5
+# --- 3. equal shards ride on the loss exchange (ops.MultiLossFn appends [b, b^2] to its 3+3C statistics; ops.check_equal_shards compares
+#        the reduced pair where the host reads the loss log): no collective of its own, so a rank-local condition cannot desynchronise
+#        the ranks -- every rank raises, none hangs ---------------------------------------------------------------------------------
+for b_local, ok in ((4, True), (4 + (rank == world - 1), False)):
+    msg = torch.cat([torch.zeros(3 + 3 * 9), ops._shard_pair(b_local, torch.device('cpu'))])
+    runtime.sync_all_reduce(msg, runtime.sync_group)
+    runtime.shard_check = (msg[3 + 3 * 9:], world)
+    try:
+        ops.check_equal_shards()
+        assert ok, 'unequal shards were accepted'
+    except RuntimeError as e:
+        assert not ok and 'equal shards' in str(e)
+assert runtime.shard_check is None
+
 # --- 4. multi-GPU inference replicas (test.py:69-84 walks the tile batches of an image serially; here they are dealt round-robin
 #        over the ranks and the logit tiles are gathered to rank 0 in image order) -----------------------------------------------
 from pylc_amd import inference

@@ -235,6 +235,61 @@ def test_loss_log_persists_like_running_loss(tmp_path):
     assert not c.load(path, resume=True)
 
 
+def test_reference_written_loss_log_resumes(tmp_path):
+    """the reference's RunningLoss stores validation averages and best_dice as NUMPY scalars (Model.eval appends
+    `.cpu().numpy()` values, models/model.py:360-363, loss.py:284-304), which torch.load(weights_only=True) refuses.
+    tests/golden/ref_losses_tiny.pth was written by the reference's RunningLoss.save (make_checkpoint_fixture.py); LossLog.load must take
+    it through the allow-listed unpickler, coerce every entry to python floats, and `load_into(..., resume=True)` must not raise for a
+    reference directory that holds a losses.pth.  An unreadable file restarts the log with a warning instead of aborting the resume."""
+    import json
+    import shutil
+    import warnings
+    from pylc_amd.model import LossLog
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    want = json.load(open(os.path.join(here, 'ref_checkpoint_tiny.json')))['losses']
+    assert want['valid_types'][1:] == ['float32'] * 3           # the fixture really holds numpy scalars
+    with pytest.raises(Exception):
+        torch.load(os.path.join(here, 'ref_losses_tiny.pth'), weights_only=True)      # why the plain loader is not enough
+    log = LossLog()
+    assert log.load(os.path.join(here, 'ref_losses_tiny.pth'), resume=True)
+    assert [list(r) for r in log.train] == want['train'] and [list(r) for r in log.valid] == want['valid'] and log.best_dice == want['best_dice']
+    assert all(type(row[0]) is int and all(type(v) is float for v in row[1:]) for row in log.train + log.valid) and type(log.best_dice) is float
+    out = str(tmp_path / 'again.pth')
+    log.save(out)                                               # and what we write back stays loadable by the strict loader
+    assert torch.load(out, weights_only=True)['best_dice'] == want['best_dice']
+    # a torn / foreign file: warn, restart the log, keep going
+    bad = str(tmp_path / 'losses.pth')
+    open(bad, 'wb').write(b'not a zip')
+    fresh = LossLog()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert fresh.load(bad, resume=True) is False and fresh.train == [] and fresh.best_dice == 1.0
+    assert any('loss log restarts' in str(x.message) for x in w)
+    # checkpoint.load_into(resume=True) next to a reference-written losses.pth (the tiny stem checkpoint needs a matching net)
+    from torch import nn
+    from pylc_amd import checkpoint as ck, layers, optim
+
+    class Stem(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = nn.Module()
+            self.backbone.conv1 = layers.Conv2d(3, 64, 7, 2, 3)
+            self.backbone.bn1 = layers.BatchNorm2d(64)
+
+    class Holder:
+        pass
+    d = tmp_path / 'run'
+    d.mkdir()
+    shutil.copy(os.path.join(here, 'ref_checkpoint_tiny.pth'), str(d / 'checkpoint.pth'))
+    shutil.copy(os.path.join(here, 'ref_losses_tiny.pth'), str(d / 'losses.pth'))
+    m = Holder()
+    m.net = Stem()
+    m.optim = optim.FlatAdamW(optim.FlatArena(m.net))
+    m.loss = LossLog()
+    ck.load_into(m, str(d / 'checkpoint.pth'), resume=True)
+    assert (m.epoch, m.iter) == (3, 41) and m.loss.best_dice == want['best_dice'] and len(m.loss.valid) == 1
+
+
 def test_model_file_with_numpy_meta_loads(tmp_path):
     """torch.save's default pickle protocol 2 serialises numpy scalars / arrays through _codecs.encode, which the allowlisted
     unpickler has to resolve -- a meta holding np.float64 / np.float32 / an ndarray (profile.py's statistics) must load."""
@@ -333,4 +388,25 @@ def test_arena_refreshes_ranges_only_when_a_parameter_changed():
     arena.refresh_ranges()                 # what the optimisers and load_state_dict do themselves
     assert arena.generation == g0 + 2
     arena.refresh_if_changed()
+    assert arena.generation == g0 + 2
+
+
+def test_arena_data_writes_need_invalidate_or_the_forced_refresh():
+    """`p.data.copy_()` / `p.data.mul_()` do NOT bump `p._version`, so refresh_if_changed() alone misses them.  The two remedies:
+    `arena.invalidate()`, and the forced refresh that Model.eval / Model.test make on the first batch after a training step."""
+    import torch
+    from pylc_amd import UNet
+    from pylc_amd.optim import FlatArena
+    net = UNet(in_channels=3, n_classes=4, depth=2, wf=2)
+    arena = FlatArena(net)
+    g0 = arena.generation
+    next(net.parameters()).data.mul_(2.0)             # invisible to the version counters
+    arena.refresh_if_changed()
+    assert arena.generation == g0                      # (documented blind spot)
+    arena.invalidate()
+    arena.refresh_if_changed()
+    assert arena.generation == g0 + 1
+    arena.refresh_if_changed()
+    assert arena.generation == g0 + 1
+    arena.refresh_if_changed(force=True)               # what Model._refresh_for_inference does after a training step
     assert arena.generation == g0 + 2
