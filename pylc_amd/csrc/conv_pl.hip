@@ -100,6 +100,17 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                 if constexpr (NTERMS == 3) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
                 else acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
             }
+    // one-plane fp16 output: the BatchNorm that follows normalises the ROUNDED tensor, so its statistics (and nothing else differs: the store
+    // below reproduces the same halves exactly, hscale being a power of two) are taken from the rounded values, not from the accumulators
+    if (a.out_half) {
+        const float inv_h = 1.f / hscale;
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < AT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (float)(_Float16)(acc[i][j][r] * hscale) * inv_h;
+    }
     __builtin_amdgcn_sched_barrier(0);
     float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
     // BatchNorm-backward mode (dgrad launches, a.bn_y != NULL): the tile being stored is the gradient `dout` of a BatchNorm OUTPUT, so the

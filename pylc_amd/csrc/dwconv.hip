@@ -262,6 +262,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             stq<HOUT>(out, o0 + (size_t)ww * out_pitch, a0, out_scale);                                                   \
             if (two) stq<HOUT>(out, o1 + (size_t)ww * out_pitch, a1, out_scale);                                          \
             if (STATS) {                                                                                                  \
+                if (HOUT) {        /* statistics of the ROUNDED halves: the tensor the BatchNorm will read */               \
+                    a0 = half4_to_f32(f32_to_half4(a0 * out_scale)) * (1.f / out_scale);                                  \
+                    if (two) a1 = half4_to_f32(f32_to_half4(a1 * out_scale)) * (1.f / out_scale);                         \
+                }                                                                                                         \
                 st1 += a0; st2 += a0 * a0;                                                                                \
                 if (two) { st1 += a1; st2 += a1 * a1; }                                                                   \
             }                                                                                                             \
@@ -401,14 +405,22 @@ __device__ __forceinline__ void dw_emit_pair(const f32x4 a0, const f32x4 a1, int
             v[4] += (m & 16u) ? hi.x : 0.f; v[5] += (m & 32u) ? hi.y : 0.f; v[6] += (m & 64u) ? hi.z : 0.f; v[7] += (m & 128u) ? hi.w : 0.f;
         }
     }
-    if (STATS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { st1[i] += v[i]; st2[i] += v[i] * v[i]; }
-    }
     if constexpr (HOUT) {
         const uint2 lo = f32_to_half4(f32x4{v[0], v[1], v[2], v[3]} * out_scale), hi = f32_to_half4(f32x4{v[4], v[5], v[6], v[7]} * out_scale);
+        if (STATS) {
+            // the BatchNorm that follows normalises the ROUNDED halves: its statistics are those of the tensor it will read
+            const float inv = 1.f / out_scale;          // a power of two: exact
+            const f32x4 rl = half4_to_f32(lo) * inv, rh = half4_to_f32(hi) * inv;
+            v[0] = rl.x; v[1] = rl.y; v[2] = rl.z; v[3] = rl.w; v[4] = rh.x; v[5] = rh.y; v[6] = rh.z; v[7] = rh.w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { st1[i] += v[i]; st2[i] += v[i] * v[i]; }
+        }
         *reinterpret_cast<uint4*>(static_cast<_Float16*>(out) + e) = uint4{lo.x, lo.y, hi.x, hi.y};
     } else {
+        if (STATS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { st1[i] += v[i]; st2[i] += v[i] * v[i]; }
+        }
         st4(static_cast<float*>(out) + e, f32x4{v[0], v[1], v[2], v[3]});
         st4(static_cast<float*>(out) + e + 4, f32x4{v[4], v[5], v[6], v[7]});
     }

@@ -69,6 +69,14 @@ class Decoder(nn.Module):
                                _4=Conv2d(256, 256, 3, 1, 1, init='kaiming', bn=True), _5=BatchNorm2d(256),
                                _8=Conv2d(256, n_classes, 1, bias=True, init='kaiming'))
         self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
+        # Launch ORDER of the backward (ops.Conv2dFn.backward, runtime.wgrad_hold): the 304->256 conv's wgrad fills every CU for ~2.9 ms on
+        # the side queue; launched right after its dgrad it sits in front of the next kernels of the main queue -- the 48-channel BatchNorm
+        # backward and the 256->48 dgrad of conv1 (decoder.py:27), 0.17 ms of work that then took 2.1 ms.  Autograd runs conv1's backward
+        # right after last_conv[0]'s (the later-created branch of the concat first), so the wgrad is held until the conv backward after
+        # THAT one begins (the ASPP's 1x1, a matrix-bound neighbour).
+        import os
+        self.last_conv.child(0).weight._pylc_wgrad_hold = int(os.environ.get('PYLC_DECODER_HOLD0', '2'))
+        self.last_conv.child(4).weight._pylc_wgrad_hold = int(os.environ.get('PYLC_DECODER_HOLD4', '0'))
 
     def forward(self, x, low):
         # torch.cat (decoder.py:47) by slice: the up-sampled ASPP output and the reduced low-level features are written into the two channel

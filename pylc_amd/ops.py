@@ -221,15 +221,18 @@ class KernelTimer:
 
     TERMS = {1: 6, 2: 3, 3: 1}
 
-    def __init__(self):
+    def __init__(self, inference=False):
         self.records = []          # (start_event, end_event, flops, launches, kind)
         self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
         self.mode = lib.pylc_get_conv_precision()
         self.planes = self.mode >= 2 and not _runtime.no_planes
+        self.inference = bool(inference)      # eval-mode nets: the fused conv + BatchNorm(+ residual + ReLU) launches (conv_bn_act_eval) are bracketed
         # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
         # activations travel as planes; '*' = both tile heights (rocprof lists them as two rows) and the 3x3 halo variant: one kernel
         # family (conv_pl.hip), the same loop body, dispatched by shape
-        self.KERNEL = ('gg_pl_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 2) if self.planes else
+        self.KERNEL = ('gather_gemm_pp_kernel<..., %s> (pylc_conv2d_fwd_bnact: conv + eval BatchNorm + residual + ReLU in the epilogue)'
+                       % ('ONE-plane fp16' if self.mode == 3 else 'f16x3') if self.inference else
+                       'gg_pl_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 2) if self.planes else
                        'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
                        'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
 
@@ -357,18 +360,27 @@ def _runs_concurrently(cand, device):
     return ok
 
 
-_deferred_wgrad = {}     # device index -> closure that launches a held-back 1x1 wgrad (runtime.defer_wgrad_1x1)
+_deferred_wgrad = {}     # device index -> [[conv backwards still to pass, closure that launches the held-back wgrad], ...] in launch order
 
 
-def _defer_wgrad(device, fn):
-    flush_deferred_wgrad(device)
-    _deferred_wgrad[torch.device(device).index] = fn
+def _defer_wgrad(device, fn, hold=1):
+    """Hold a wgrad launch back until `hold` more conv backwards have STARTED on this device (each conv backward calls
+    flush_deferred_wgrad first), or until sync_side_streams().  hold = 1: the wgrad starts beside the next conv's dgrad."""
+    _deferred_wgrad.setdefault(torch.device(device).index, []).append([int(hold), fn])
 
 
-def flush_deferred_wgrad(device):
-    fn = _deferred_wgrad.pop(torch.device(device).index, None)
-    if fn is not None:
-        fn()
+def flush_deferred_wgrad(device, everything=False):
+    held = _deferred_wgrad.get(torch.device(device).index)
+    if not held:
+        return
+    keep = []
+    for item in held:
+        item[0] -= 1
+        if everything or item[0] <= 0:
+            item[1]()
+        else:
+            keep.append(item)
+    held[:] = keep
 
 
 def cu_masked_stream(device, n_cus, from_top=False):
@@ -423,7 +435,7 @@ def sync_side_streams():
     """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
     all-reduce reads the arena), then release the tensors kept alive for it."""
     for idx in list(_deferred_wgrad):
-        flush_deferred_wgrad(torch.device('cuda', idx))
+        flush_deferred_wgrad(torch.device('cuda', idx), everything=True)
     for st in _side_streams.values():
         torch.cuda.current_stream().wait_stream(st)
     for keep in _side_keep.values():
@@ -885,7 +897,14 @@ class Conv2dFn(torch.autograd.Function):
                     torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
                 return _deliver_grad(w, dwl)
 
-            if _runtime.defer_wgrad_1x1 and r * s == 1 and side is not None and tgt is not None:
+            hold = getattr(w, '_pylc_wgrad_hold', 0) if _runtime.wgrad_hold else 0
+            if hold and side is not None and tgt is not None:
+                # a layer-specific launch ORDER (set by the network, e.g. nets/deeplabv3p.py Decoder): this conv's wgrad fills every CU for
+                # milliseconds; started now it would sit in front of the short kernels that follow on the main queue (the 256->48 dgrad of
+                # decoder.py:27 waited 2 ms behind the 304->256 wgrad).  Held until `hold` further conv backwards have begun.
+                _defer_wgrad(x.device, launch_wgrad, hold)
+                dw = None
+            elif _runtime.defer_wgrad_1x1 and r * s == 1 and side is not None and tgt is not None:
                 # an HBM-heavy 1x1 wgrad started now would run beside the (HBM-bound) BatchNorm backward that follows on the main
                 # stream; held back until the NEXT conv backward begins, it runs beside that conv's matrix-bound dgrad instead
                 _defer_wgrad(x.device, launch_wgrad)
@@ -1066,8 +1085,14 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
         res = as_nhwc(residual)
         if tuple(res.shape) != tuple(y.shape) or pitch_of(res) != yp:
             raise L.PylcError('conv_bn_act_eval: the residual must have the output\'s shape and pitch')
+    ev = None
+    if _timer is not None and _timer.inference and cout > 64 and cin % 8 == 0:
+        ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd_bnact%dx%d' % (r, s), 4.0 * (b * h * wd * cin + w.numel() + b * oh * ow * cout))
+        ev[0].record()
     check(lib.pylc_conv2d_fwd_bnact(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(coef[:cout]), ptr(coef[cout:]), ptr(res), int(relu), ptr(y),
                                     ptr(amax), st))
+    if ev is not None:
+        ev[1].record()
     if amax is not None:
         tag_amax(y, amax)
     return y

@@ -20,6 +20,9 @@ class _Runtime:
         self.bn_refine = os.environ.get('PYLC_BN_REFINE', '1') != '0'
         # hold a 1x1 conv's wgrad back until the next conv backward starts (ops.Conv2dFn.backward): PYLC_DEFER_WGRAD=1 (A/B knob)
         self.defer_wgrad_1x1 = os.environ.get('PYLC_DEFER_WGRAD', '0') == '1'
+        # per-layer wgrad launch order (a weight's `_pylc_wgrad_hold`: start its wgrad only after that many further conv backwards have begun;
+        # set by nets/deeplabv3p.py for the decoder's two 3x3 convs); PYLC_WGRAD_HOLD=0 launches every wgrad right after its dgrad (A/B knob)
+        self.wgrad_hold = os.environ.get('PYLC_WGRAD_HOLD', '1') != '0'
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)

@@ -30,7 +30,8 @@ find $out/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kern
 find $out/trace -name "*kernel_trace.csv" | head -1 | xargs -I{} python3 tools/trace_streams.py {} > $out/trace_streams.txt 2>&1
 rm -rf $out/trace
 head -12 $out/kernel_stats.csv | cut -c1-160
-bash tools/pmc_bench.sh $out/pmc 400
+mkdir -p $out/pmc
+bash tools/pmc_bench.sh $out/pmc 400 || { echo "final_profile: HBM-traffic PMC passes failed (raw output kept under $out/pmc)"; exit 1; }
 rm -rf $out/pmc/fetch $out/pmc/write
-bash tools/pmc_mfma.sh $out/pmc_mfma > $out/pmc_mfma.log 2>&1
+bash tools/pmc_mfma.sh $out/pmc_mfma > $out/pmc_mfma.log 2>&1 || { tail -5 $out/pmc_mfma.log; echo "final_profile: matrix-pipe PMC passes failed"; exit 1; }
 tail -3 $out/pmc_mfma.log

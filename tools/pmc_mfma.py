@@ -9,11 +9,25 @@ SQ_VALU_MFMA_BUSY_CYCLES counts cycles (= 16 per v_mfma_f32_16x16x32_f16, summed
   waves            = SQ_WAVES per launch; occupancy = SQ_WAVE_CYCLES / (SQ_BUSY_CYCLES x ...) is left as the raw pair."""
 import csv, glob, json, sys, collections, os
 out = sys.argv[1]
-acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+# one launch = one Dispatch_Id: rows are summed per (pass, dispatch, counter) first -- rocprofv3 may emit several rows per dispatch (per XCD /
+# dimension) -- and `launches` counts distinct dispatches
+per_dispatch = collections.defaultdict(float)
+kname = {}
+n_rows = 0
 for f in glob.glob('%s/sq*/*/*counter_collection.csv' % out):
+    pass_dir = f.split(os.sep + 'sq')[-1].split(os.sep)[0]
     for r in csv.DictReader(open(f)):
-        a = acc[r['Kernel_Name']][r['Counter_Name']]
-        a[0] += float(r['Counter_Value']); a[1] += 1
+        key = (pass_dir, r.get('Dispatch_Id', n_rows), r['Counter_Name'])
+        per_dispatch[key] += float(r['Counter_Value'])
+        kname[key[:2]] = r['Kernel_Name']
+        n_rows += 1
+if not n_rows:
+    sys.stderr.write('pmc_mfma: no counter rows under %s/sq*\n' % out)
+    sys.exit(3)
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for (pd, did, cname), val in per_dispatch.items():
+    a = acc[kname[(pd, did)]][cname]
+    a[0] += val; a[1] += 1
 res = {}
 WANT = ('gg_pl_kernel', 'gg_plh_kernel', 'wgrad_pl_kernel', 'bn_bwd_apply_kernel', 'bn_reduce_kernel', 'bn_apply_kernel', 'gather_gemm', 'dw_strip', 'splitk')
 for k, d in acc.items():
