@@ -583,6 +583,10 @@ int pylc_debug_stagger(int units);
 /* conv_p1.hip: 1 sends plain 1x1 / stride-1 launches to the persistent kernel whose stores leave under the next tile (off by default:
  * measured neutral inside the step) */
 int pylc_debug_p1(int on);
+/* conv_ps.hip: the specialised-wave persistent 1x1 kernel (loader waves + compute waves, one block per CU) for plain 1x1 / stride-1
+ * launches (nn.Conv2d 1x1 forward / backward: resnet.py:21-26,92, aspp.py:64,67, decoder.py:27).  Bit 0: forward and plain dgrad launches;
+ * bit 1: also the dgrads that add a ReLU-masked residual gradient (pylc_conv2d_dgrad_add).  A/B knob, env PYLC_PS. */
+int pylc_debug_ps(int on);
 /* dwconv.hip, one-plane fp16 depthwise convs (A/B knob, env PYLC_DW_TILES; default 3): bit 0 = LDS-tiled kernels for stride 1 / dilation 1
  * (else the strip kernels), bit 1 = LDS-tiled kernels for stride 2 and for dilation 2 (else those shapes are not half-eligible) */
 int pylc_debug_dw_tiles(int on);

@@ -821,6 +821,7 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
                  "conv dgrad with a masked residual source needs a dense output (pitch == channels, channels %% 8 == 0) and no accumulation");
     PYLC_REQUIRE(a.bn_y == nullptr || (a.y_pitch == a.N_store && a.stats != nullptr && a.bn_mean && a.bn_invstd && (!a.bn_relu || a.bn_mask || (a.bn_scale && a.bn_shift))),
                  "conv dgrad with BatchNorm-backward sums needs a dense output, a partials buffer, mean / invstd and a mask source");
+    if (!(g_pp_flags & (2048 | 8192)) && takes_ps(a)) return launch_gg_ps(a, st);      // 1x1: loader waves + compute waves, one persistent block per CU
     if (!(g_pp_flags & (2048 | 8192)) && a.add_src == nullptr && a.bn_y == nullptr && !a.out_half && takes_p1(a)) return launch_gg_p1(a, st);     // 1x1: the persistent kernel whose stores leave under the next tile's main loop
     // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
     // tile's prologue / epilogue) -- for long reductions on grids that still fill the chip.  128 rows: two blocks per CU.

@@ -68,6 +68,7 @@ SIGNATURES = {
     'pylc_debug_pp_flags': (_I, [_I]),
     'pylc_debug_stagger': (_I, [_I]),
     'pylc_debug_p1': (_I, [_I]),
+    'pylc_debug_ps': (_I, [_I]),
     'pylc_debug_dw_tiles': (_I, [_I]),
     'pylc_range_product': (_I, [_P, _P, _F, _P, _P, _P]),
     'pylc_maxpool_fwd_planes': (_I, [_P, _P, _LL, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -212,6 +213,8 @@ def init():
             lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
+        if os.environ.get('PYLC_PS') is not None:        # bit 0: plain 1x1 launches on the specialised-wave kernel of conv_ps.hip, bit 1: + masked-residual dgrads
+            lib.pylc_debug_ps(int(os.environ['PYLC_PS']))
         if os.environ.get('PYLC_DW_TILES') is not None:  # 0: half depthwise convs on the strip kernels (A/B)
             lib.pylc_debug_dw_tiles(int(os.environ['PYLC_DW_TILES']))
         _initialised = True

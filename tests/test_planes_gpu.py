@@ -294,6 +294,87 @@ def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode):
         check(lib.pylc_set_conv_precision(prev))
 
 
+@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('shape', [(8, 64, 256, 1024), (8, 61, 96, 200), (2, 128, 64, 256), (8, 64, 1024, 256)])
+def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode):
+    """conv_ps.hip (pylc_debug_ps): the persistent 1x1 kernel whose loader waves stream the operand tiles through tile boundaries while its
+    compute waves multiply, fold, store and go on -- output bit-identical to the per-tile kernel (run twice), BatchNorm statistics partials
+    bit-identical to the 128-row per-tile kernel's and equal to sums over the output; ragged M (61^2 x 8 pixels), a ragged last channel tile
+    (Cout = 200), an odd number of K-steps (Cin = 96), two K-steps per tile (Cin = 64), more tiles than CUs in several rounds."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib, check
+    B, H, cin, cout = shape
+    prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
+    check(lib.pylc_set_conv_precision(mode))
+    ops.PLANES_MIN_PIXELS = 0
+    try:
+        torch.manual_seed(2)
+        conv = layers.Conv2d(cin, cout, 1, 1, 0, 1, bn=True).to(dev)
+        arena = optim.FlatArena(conv)
+        x = nhwc(rnd(31, B, cin, H, H, scale=2.0), dev)
+        xp = ops.to_planes(x)
+        outs = []
+        with torch.no_grad():
+            for on in (0, 1, 1):
+                lib.pylc_debug_ps(on)
+                lib.pylc_debug_pp_flags((1024 | 2048 | 16384) if on == 0 else 0)     # the 128-row per-tile kernel as the reference (same statistics rows)
+                y = ops.conv2d(xp, conv.weight, None, 1, 0, 1, want_stats=True)
+                torch.cuda.synchronize()
+                outs.append((y.clone(), y._pylc_sums.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
+        assert torch.equal(outs[1][1], outs[2][1])
+        assert outs[0][1].shape == outs[1][1].shape and torch.equal(outs[0][1], outs[1][1])
+        yd = outs[1][0].double()
+        sums = outs[1][1].double().sum(0)
+        cp = sums.shape[0] // 2
+        assert rel(sums[:cout], yd.sum((0, 2, 3))) < 1e-5 and rel(sums[cp:cp + cout], (yd * yd).sum((0, 2, 3))) < 1e-5
+        if mode == 2:
+            ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double())
+            assert rel(outs[1][0], ref) < 3e-6
+    finally:
+        lib.pylc_debug_ps(0)
+        lib.pylc_debug_pp_flags(0)
+        ops.PLANES_MIN_PIXELS = prev_min
+        check(lib.pylc_set_conv_precision(prev))
+
+
+def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3):
+    """The three launch kinds conv_ps.hip takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
+    of gradient), and the dgrad that adds the ReLU-masked residual gradient in its epilogue (conv1 of an identity bottleneck,
+    pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 8 x 61 x 67 pixels (ragged M): block output, input
+    gradient and every parameter gradient bit-identical to the per-tile kernels."""
+    from pylc_amd import ops, optim, runtime
+    from pylc_amd.lib import lib
+    from pylc_amd.nets.encoder_resnet import Bottleneck
+    prev_drop = runtime.dropout_enabled
+    runtime.dropout_enabled = False
+    try:
+        torch.manual_seed(4)
+        net = torch.nn.Sequential(Bottleneck(1024, 256, 1, 1, False), Bottleneck(1024, 256, 1, 1, False), Bottleneck(1024, 256, 1, 2, False)).to(dev)
+        for b in net:
+            b.out_planes = True
+        arena = optim.FlatArena(net)
+        net.train()
+        x0 = nhwc(rnd(1, 8, 1024, 61, 67), dev)
+        dout = nhwc(rnd(2, 8, 1024, 61, 67), dev)
+        got = {}
+        for on in (0, 3):
+            lib.pylc_debug_ps(on)
+            arena.g.zero_()
+            x = x0.clone().requires_grad_(True)
+            out = ops.export_activation(net(x))
+            out.backward(dout)
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            got[on] = (out.detach().clone(), x.grad.clone(), arena.g.clone())
+        for name, a, b in zip(('out', 'dx', 'parameter gradients'), got[0], got[3]):
+            assert torch.equal(a, b), name
+        assert float(got[3][1].abs().sum()) > 0
+    finally:
+        lib.pylc_debug_ps(0)
+        runtime.dropout_enabled = prev_drop
+
+
 def test_one_accumulator_wgrad_is_fp32_grade(dev, f16x3):
     """wgrad_pl.hip ACC1 (off by default: pylc_debug_wgrad_acc1): the 128 x 128 wgrad with ONE accumulator set under 128 registers --
     cross terms scaled by 2^-11 in registers and added into the same fp32 accumulator.  Not bit-identical to the two-accumulator form,

@@ -440,9 +440,11 @@ def test_half_depthwise_kernels_against_fp64(dev, c, b, h, w, stride, dil, tiles
         assert (y - y_ref).abs().max().item() <= 2.0 ** -10 * bound            # one fp16 rounding at the tensor's scale (+ fp32 accumulation)
         st = sums.double().sum(0)
         assert torch.isfinite(st).all()
-        ref1, ref2 = y_ref.sum((0, 1, 2)), (y_ref * y_ref).sum((0, 1, 2))
-        assert (st[:c] - ref1).abs().max().item() <= 1e-4 * (y_ref.abs().sum((0, 1, 2)).max().item() + 1)
-        assert ((st[c:] - ref2).abs() / (ref2 + 1e-6)).max().item() <= 1e-4
+        # the statistics are those of the ROUNDED halves -- the tensor the BatchNorm behind this conv normalises --, so they
+        # are compared with sums over what was stored, to fp32 accumulation accuracy (against the unrounded fp64 conv they differ by fp16's 2^-11)
+        ref1, ref2 = y.sum((0, 1, 2)), (y * y).sum((0, 1, 2))
+        assert (st[:c] - ref1).abs().max().item() <= 2e-5 * (y.abs().sum((0, 1, 2)).max().item() + 1)
+        assert ((st[c:] - ref2).abs() / (ref2 + 1e-6)).max().item() <= 2e-5
         # dgrad: fresh half output, accumulating half output, accumulating / fresh fp32 output
         dx_h = torch.zeros(b, h, w, c, dtype=torch.float16, device=dev)
         dxb = torch.zeros(1, dtype=torch.int32, device=dev)
