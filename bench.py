@@ -360,7 +360,19 @@ def main():
     dp_overhead = dp_collectives = None
     if world == 1 and not args.no_dp_overhead and not torch.distributed.is_initialized():
         try:
-            parallel.init_single_rank_group()
+            # RCCL prints its version banner to STDOUT when the group comes up: keep this process's stdout the one JSON line
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                parallel.init_single_rank_group()
+                x_ = torch.zeros(1, device=dev)
+                torch.distributed.all_reduce(x_)          # (the banner comes with the first collective)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             for _ in range(3):
                 model.train(x, y)
             pylc_amd.runtime.collectives = 0

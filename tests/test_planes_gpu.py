@@ -360,6 +360,9 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3):
         got = {}
         for on in (0, 3):
             lib.pylc_debug_ps(on)
+            # reference: the per-tile kernels with 128-row tiles for every plain launch (flag 2048; with 256-row tiles the BatchNorm
+            # statistics partials of conv1 would be summed in another order and the outputs would differ in the last bit)
+            lib.pylc_debug_pp_flags(2048 if on == 0 else 0)
             arena.g.zero_()
             x = x0.clone().requires_grad_(True)
             out = ops.export_activation(net(x))
@@ -372,6 +375,7 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3):
         assert float(got[3][1].abs().sum()) > 0
     finally:
         lib.pylc_debug_ps(0)
+        lib.pylc_debug_pp_flags(0)
         runtime.dropout_enabled = prev_drop
 
 
