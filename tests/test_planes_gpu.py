@@ -341,8 +341,9 @@ def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode):
 def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3):
     """The three launch kinds conv_ps.hip takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
     of gradient), and the dgrad that adds the ReLU-masked residual gradient in its epilogue (conv1 of an identity bottleneck,
-    pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 8 x 61 x 67 pixels (ragged M): block output, input
-    gradient and every parameter gradient bit-identical to the per-tile kernels."""
+    pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 8 x 61 x 64 pixels (ragged M; small enough that the
+    per-tile reference keeps 128-row tiles for its 32-step reductions, so both runs sum the same BatchNorm statistics partials): block
+    output, input gradient and every parameter gradient bit-identical to the per-tile kernels."""
     from pylc_amd import ops, optim, runtime
     from pylc_amd.lib import lib
     from pylc_amd.nets.encoder_resnet import Bottleneck
@@ -355,14 +356,11 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3):
             b.out_planes = True
         arena = optim.FlatArena(net)
         net.train()
-        x0 = nhwc(rnd(1, 8, 1024, 61, 67), dev)
-        dout = nhwc(rnd(2, 8, 1024, 61, 67), dev)
+        x0 = nhwc(rnd(1, 8, 1024, 61, 64), dev)
+        dout = nhwc(rnd(2, 8, 1024, 61, 64), dev)
         got = {}
         for on in (0, 3):
             lib.pylc_debug_ps(on)
-            # reference: the per-tile kernels with 128-row tiles for every plain launch (flag 2048; with 256-row tiles the BatchNorm
-            # statistics partials of conv1 would be summed in another order and the outputs would differ in the last bit)
-            lib.pylc_debug_pp_flags(2048 if on == 0 else 0)
             arena.g.zero_()
             x = x0.clone().requires_grad_(True)
             out = ops.export_activation(net(x))
