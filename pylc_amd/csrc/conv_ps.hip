@@ -113,8 +113,9 @@ __global__ __launch_bounds__(512, 1) void gg_ps_kernel(const GatherGemmArgs a) {
             }
         };
         // the DMA of one K-step (this wave's 64 rows, NPL planes) into the ring's next stage; masked lanes fetch zeros through an out-of-range offset
+        const bool no_dma = (a.dbg_flags & 64) != 0;                      // timing ablations (results are garbage): 64 = no DMA, 128 = no MFMAs, 256 = no stores
         auto issue = [&]() {
-            const bool cok = ld_chunk * BK + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
+            const bool cok = ld_chunk * BK + 8 * lc < a.Cin && !no_dma;      // Cin % 8 == 0; only the last chunk can be partial
             const unsigned so = sbase + (unsigned)(ld_chunk * BK * 2);
             char* const d = dst0 + ld_stage * RING;
 #pragma unroll
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(512, 1) void gg_ps_kernel(const GatherGemmArgs a) {
                 const bool ok = cok & (roff[i] != OOB);
                 const unsigned vo = ok ? roff[i] : OOB;
                 const unsigned vo1 = ok ? roff[i] + plane1 : OOB;
+                if (no_dma) continue;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_vptr)(d + 16 * i * ROW), 16, vo, so, 0, 0);
                 if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_vptr)(d + BM * ROW + 16 * i * ROW), 16, vo1, so, 0, 0);
             }
@@ -220,8 +222,10 @@ __global__ __launch_bounds__(512, 1) void gg_ps_kernel(const GatherGemmArgs a) {
     // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels 4 (l >> 4) .. +3)
     // -> 16-byte epilogue stores.  Same term order per accumulator as gg_pl_kernel (bit-identical sums).
     // `first`: a tile's first K-step starts from zero (inline-constant C operand) instead of from the accumulators -- no zeroing pass
+    const bool no_mfma = (a.dbg_flags & 128) != 0, no_store = (a.dbg_flags & 256) != 0;
     auto mfma1 = [&](auto first, int i, int j, const f16x8 (&fb)[NPL], const f16x8 (&fa)[NPL]) {
         constexpr bool FIRST = decltype(first)::value;
+        if (no_mfma) { if (FIRST) { acc[i][j] = fa[0][0] == (_Float16)77.f ? acc[i][j] + 1.f : acc[i][j]; } return; }
         const f32x4v z = {0.f, 0.f, 0.f, 0.f};
         if constexpr (NTERMS == 3) {
             acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0], fa[1], FIRST ? z : acc_lo[i][j], 0, 0, 0);
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void gg_ps_kernel(const GatherGemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < AT; ++i)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[i][j0 + jj]), ry,
-                                                           (int)(eoff[i][j0 + jj] == OOB ? OOB : eoff[i][j0 + jj] * 4u), 0, 0);
+                                                           (int)((eoff[i][j0 + jj] == OOB || no_store) ? OOB : eoff[i][j0 + jj] * 4u), 0, 0);
         };
         const f32x4v none[AT][PJ] = {};
         if constexpr (!ADD) {
