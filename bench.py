@@ -207,6 +207,10 @@ def inference_leg(args, cfg, model, rank, world, dev):
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    from pylc_amd import ops as _ops
+    _ops.eval_plane_convs[0] = 0
+    inference.predict_image(model, img, tile, stride, batch, group=group)
+    plane_convs = _ops.eval_plane_convs[0]
     # roofline leg: one more image with HIP events around the fused conv + BatchNorm launches (after the timed region)
     roof = None
     if not args.no_kernel_timing:
@@ -238,7 +242,8 @@ def inference_leg(args, cfg, model, rank, world, dev):
                    'parallelism': 'replicas x%d (tile batches round-robin, gather to rank 0)' % world,
                    'conv_arithmetic': {0: 'f32 MFMA', 1: 'bf16x6 split', 2: 'f16x3 split (fp32-grade)',
                                        3: 'fp16 operands (ONE plane per operand, rounded inside the fused conv kernel), fp32 accumulation, fp32 weights'}[prec]
-                                      + INFERENCE_FORMAT_NOTE,
+                                      + inference_format_note(),
+                   'plane_convs_per_image': plane_convs,
                    'mask_checksum': int(mask.to(torch.int64).sum().item()), 'pixels_per_s': h * w * args.steps / dt},
     }
     if roof is not None:
@@ -246,8 +251,14 @@ def inference_leg(args, cfg, model, rank, world, dev):
     print(json.dumps(line), flush=True)
 
 
-# what travels between the kernels of the inference path (kept next to the line so that the label cannot drift from the code again)
-INFERENCE_FORMAT_NOTE = '; activations between the kernels: fp32 (conv + eval BatchNorm + residual + ReLU fused in the conv epilogue, depthwise strips fp32)'
+def inference_format_note():
+    """What travels between the kernels of the inference path, derived from the switches the run used (so the label cannot drift from the code)."""
+    import pylc_amd
+    from pylc_amd import ops
+    if pylc_amd.runtime.eval_planes and not pylc_amd.runtime.no_planes and ops.eval_plane_convs[0] > 0:
+        return ('; activations between the kernels: fp16 planes (%d B/element) written by the fused conv + eval-BatchNorm + residual + ReLU epilogues '
+                '(pylc_conv2d_fwd_bnact_ex)%s' % (2 * ops.nplanes(), ', depthwise convs half -> half (pylc_dwconv3x3_fwd_h_eval)' if ops.nplanes() == 1 else ''))
+    return '; activations between the kernels: fp32 (conv + eval BatchNorm + residual + ReLU fused in the conv epilogue, depthwise strips fp32)'
 
 
 def main():

@@ -71,7 +71,8 @@ typedef struct PylcConvDesc {
      * bound the producer scaled with.  Needs precision mode >= 2, Cin resp. Cout % 8 == 0 and pitches % 8 == 0. */
     int x_fmt;
     int dy_fmt;
-    /* Output format of pylc_conv2d_fwd / _fwd_stats (y) and of the stride-1 pylc_conv2d_dgrad (dx): 0 = fp32 (default); 1 = a ONE-PLANE fp16
+    /* Output format of pylc_conv2d_fwd / _fwd_stats (y) and of the stride-1 pylc_conv2d_dgrad (dx) (pylc_conv2d_fwd_bnact_ex also takes 2 =
+     * two fp16 planes, the f16x3 operand format): 0 = fp32 (default); 1 = a ONE-PLANE fp16
      * tensor (precision mode 3: element = rn16(s v), 2 bytes per element, pitch in elements) whose range bound -- reduction length x the two
      * operand bounds -- is derived in the kernel and written to *out_bound for the consumer.  Needs fp16-plane operands (x_fmt / dy_fmt = 1),
      * no bias, no accumulation. */
@@ -160,6 +161,30 @@ int pylc_conv2d_fwd(const PylcConvDesc* d, const float* x, const float* w_krsc, 
 int pylc_conv2d_fwd_bnact(const PylcConvDesc* d, const float* x, const float* w_krsc, const float* bias,
                           const float* scale, const float* shift, const float* residual, int relu, float* y,
                           unsigned int* amax_out, void* stream);
+
+/* pylc_conv2d_fwd_bnact on fp16-PLANE tensors (inference without fp32 round trips between the kernels): x arrives as planes (d->x_fmt = 1,
+ * d->x_amax = the bound it was scaled with), the residual as fp32 or planes, y leaves as fp32 (d->out_fmt = 0), ONE fp16 plane (1:
+ * precision mode 3) or TWO planes (2: f16x3).  Replaces the same call sites as pylc_conv2d_fwd_bnact -- nn.Conv2d + BatchNorm2d.eval()
+ * (+ residual add + ReLU) in models/backbone/resnet.py:36-51,92, models/backbone/xception.py:34-39,60-97, models/modules/aspp.py:18-30,
+ * models/decoder.py:27-38, models/architectures/unet.py:107-126 as run by Model.eval / Model.test (models/model.py:338-382).
+ * An eval-mode network has no batch statistics to re-anchor range bounds, so a plane tensor carries TWO device scalars: the bound it was
+ * SCALED with (formed before the kernel writes: Cin R S x true max|x| x max|w| x max|scale| + max|shift| + max|residual|, written to
+ * *d->out_bound) and its TRUE maximum (max-accumulated by the epilogue into amax_out, zero-initialised by the caller), which is what the
+ * consumer's bound starts from. */
+typedef struct PylcFwdEp {
+    const float* scale;                    /* eval-BatchNorm coefficients (pylc_bn_eval_coeffs), [Cout] each                   */
+    const float* shift;
+    const unsigned int* scale_amax;        /* device scalars: float bits of max|scale|, max|shift| (plane outputs only)        */
+    const unsigned int* shift_amax;
+    const void* residual;                  /* y's geometry, dense; NULL = none                                                  */
+    int res_fmt;                           /* 0 = fp32, 1 = one fp16 plane, 2 = two fp16 planes (plane 1 at + B OH OW Cout halves) */
+    const unsigned int* res_scale_bound;   /* res_fmt 1 / 2: the bound the residual was scaled with                             */
+    const unsigned int* res_amax;          /* true max|residual| (plane outputs only)                                           */
+    const unsigned int* x_true_amax;       /* true max|x| (NULL: d->x_amax, the scale bound, is used for the output bound too)  */
+    int relu;
+    unsigned int* amax_out;                /* receives max|y| (atomic max of float bits); may be NULL for an fp32 output        */
+} PylcFwdEp;
+int pylc_conv2d_fwd_bnact_ex(const PylcConvDesc* d, const void* x, const float* w, const float* bias, const PylcFwdEp* ep, void* y, void* stream);
 /* pylc_conv2d_fwd that additionally emits per-M-tile partial column sums of y for the BatchNorm that follows (saves a full read
  * of y): stats_partial has pylc_conv2d_fwd_stats_floats(d) floats, laid out [rows][2][roundup4(Cout)] = (sum | sum of
  * squares) of (y - bias) -- taken BEFORE the bias is added, so that a bias much larger than the spread does not cost the variance its
@@ -250,6 +275,11 @@ int pylc_dwconv3x3_half_ok(const PylcDwDesc* d);
 int pylc_dwconv3x3_fwd_h_stats_rows(const PylcDwDesc* d);
 int pylc_dwconv3x3_fwd_h(const PylcDwDesc* d, const void* x_h, const unsigned int* x_bound, const float* w_c9, const unsigned int* w_amax,
                          void* y_h, unsigned int* y_bound_out, float* stats_partial, void* stream);
+/* pylc_dwconv3x3_fwd_h for inference on one-plane tensors (xception.py:29-31 under Model.test, models/model.py:367-382): x was scaled with
+ * x_bound but its TRUE maximum is x_true_amax (left by the producing pylc_conv2d_fwd_bnact_ex); y is scaled with, and *y_bound_out receives,
+ * 9 max|w| x_true_amax -- the bound does not inherit the looseness of x's.  No statistics. */
+int pylc_dwconv3x3_fwd_h_eval(const PylcDwDesc* d, const void* x_h, const unsigned int* x_bound, const unsigned int* x_true_amax, const float* w,
+                              const unsigned int* w_amax, void* y_h, unsigned int* y_bound_out, void* stream);
 int pylc_dwconv3x3_dgrad_h(const PylcDwDesc* d, const void* dy_h, const unsigned int* dy_bound, const float* w_c9, const unsigned int* w_amax,
                            void* dx_h, unsigned int* dx_bound_out, int accumulate, const unsigned int* acc_bound, void* stream);
 /* pylc_dwconv3x3_dgrad_h with an fp32 dx that also receives a ReLU'd residual gradient: dx = dw^T(dy) + (mask ? add_src : 0), add_src fp32 of

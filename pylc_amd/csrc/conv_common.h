@@ -117,6 +117,21 @@ struct GatherGemmArgs {
     const float* ep_res;    // same geometry and pitch as y
     unsigned* ep_amax;
     int ep_relu;
+    // ... on fp16-plane tensors (conv_pl.hip, EP instantiations; pylc_conv2d_fwd_bnact_ex): the residual may arrive as planes
+    // (ep_res_fmt 1 = one plane, 2 = two planes at + ep_res_plane_stride halves, scaled with the bound behind ep_res_scale), the output may
+    // leave as planes (out_half = one plane; out_planes2 = two planes at + out_plane_stride halves).  The output's scale comes from the bound
+    //     out_bound_k x TRUE max|x| (bound_x; amax_x is the -- looser -- bound x was SCALED with) x max|w| x max|scale| + max|shift| + max|residual|
+    // formed in the kernel from device scalars and written to *out_bound; the TRUE maximum of what is stored is max-accumulated into
+    // ep_amax for the next layer's bound, so the looseness of one layer's bound never compounds into the next
+    const unsigned* bound_x;
+    const unsigned* ep_scale_amax;
+    const unsigned* ep_shift_amax;
+    const unsigned* ep_res_amax;
+    const unsigned* ep_res_scale;
+    int ep_res_fmt;
+    long long ep_res_plane_stride;
+    int out_planes2;
+    long long out_plane_stride;
     int tiles_n;
     int n_tiles;            // tiles_m * tiles_n (the persistent ping-pong kernel walks them)
     const unsigned* amax_x; // PREC 2: device scalars holding the float bits of max|x| and max|w| (upper bounds are fine)

@@ -1720,7 +1720,10 @@ extern "C" int pylc_debug_pp_flags(int flags) { g_pp_flags = flags; g_wgrad_fast
 extern "C" int pylc_debug_set_big_tile(int on) { g_big_tile = on; return PYLC_OK; }
 
 namespace {
-struct FwdEpilogue { const float* scale; const float* shift; const float* res; unsigned* amax; int relu; };
+struct FwdEpilogue {
+    const float* scale; const float* shift; const float* res; unsigned* amax; int relu;
+    const PylcFwdEp* ex = nullptr;          // pylc_conv2d_fwd_bnact_ex: plane residual / plane output / true input range
+};
 }
 static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats, int* stats_rows,
                            void* stream, const FwdEpilogue* ep = nullptr);
@@ -1737,6 +1740,24 @@ extern "C" int pylc_conv2d_fwd_bnact(const PylcConvDesc* d, const float* x, cons
     PYLC_REQUIRE(scale && shift, "conv2d_fwd_bnact: null scale / shift");
     const FwdEpilogue ep{scale, shift, residual, amax_out, relu};
     return conv2d_fwd_impl(d, x, w, bias, y, nullptr, nullptr, stream, &ep);
+}
+
+// ... with fp16-plane tensors on either side (PylcFwdEp): x as planes (d->x_fmt = 1), the residual as fp32 or planes, y as fp32
+// (d->out_fmt = 0), one fp16 plane (1, precision mode 3) or two planes (2, f16x3).  A plane output is scaled with the bound the kernel forms
+// from device scalars -- Cin R S x TRUE max|x| x max|w| x max|scale| + max|shift| + max|residual| -- and writes to *d->out_bound; the true
+// maximum of what it stores is max-accumulated into ep->amax_out (zero-initialised by the caller) and is what the NEXT layer's bound
+// starts from, so that the looseness of the bounds does not compound through an eval-mode network, which has no batch statistics to
+// re-anchor them (DESIGN.md "inference on plane tensors").
+extern "C" int pylc_conv2d_fwd_bnact_ex(const PylcConvDesc* d, const void* x, const float* w, const float* bias, const PylcFwdEp* ep, void* y,
+                                        void* stream) {
+    PYLC_REQUIRE(ep != nullptr && ep->scale && ep->shift, "conv2d_fwd_bnact_ex: null epilogue / scale / shift");
+    PYLC_REQUIRE(d->x_fmt == 1, "conv2d_fwd_bnact_ex: x must be an fp16-plane tensor (pylc_conv2d_fwd_bnact takes fp32 tensors)");
+    PYLC_REQUIRE(ep->res_fmt >= 0 && ep->res_fmt <= 2 && (ep->res_fmt == 0 || (ep->residual && ep->res_scale_bound)),
+                 "conv2d_fwd_bnact_ex: res_fmt 1 / 2 needs the residual planes and the bound they were scaled with");
+    PYLC_REQUIRE(d->out_fmt == 0 || (d->out_bound && ep->scale_amax && ep->shift_amax && (ep->residual == nullptr || ep->res_amax)),
+                 "conv2d_fwd_bnact_ex: a plane output needs out_bound, max|scale|, max|shift| and (with a residual) max|residual|");
+    const FwdEpilogue fe{ep->scale, ep->shift, ep->res_fmt == 0 ? static_cast<const float*>(ep->residual) : nullptr, ep->amax_out, ep->relu, ep};
+    return conv2d_fwd_impl(d, static_cast<const float*>(x), w, bias, static_cast<float*>(y), nullptr, nullptr, stream, &fe);
 }
 
 extern "C" size_t pylc_conv2d_fwd_stats_floats(const PylcConvDesc* d) {
@@ -1780,7 +1801,23 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     a.N = d->Cout; a.N_store = roundup4(d->Cout) <= d->y_pitch ? roundup4(d->Cout) : d->Cout;
     a.OH = d->OH; a.OW = d->OW; a.out_sh = a.out_sw = 1; a.oh0 = a.ow0 = 0; a.y_pitch = d->y_pitch;
     a.accumulate = 0;
-    if (d->out_fmt == 1) {
+    if (ep != nullptr && ep->ex != nullptr) {
+        const PylcFwdEp* ex = ep->ex;
+        a.bound_x = ex->x_true_amax;
+        a.ep_scale_amax = ex->scale_amax; a.ep_shift_amax = ex->shift_amax;
+        if (ex->residual != nullptr) {
+            a.ep_res = static_cast<const float*>(ex->residual);
+            a.ep_res_fmt = ex->res_fmt; a.ep_res_scale = ex->res_scale_bound; a.ep_res_amax = ex->res_amax;
+            a.ep_res_plane_stride = (long long)d->B * d->OH * d->OW * d->Cout;
+        }
+        if (d->out_fmt != 0) {
+            PYLC_REQUIRE((d->out_fmt == 1 || d->out_fmt == 2) && d->y_pitch == d->Cout && d->Cout % 4 == 0,
+                         "conv2d_fwd_bnact_ex: a plane output (out_fmt 1 / 2) needs a dense y with Cout %% 4 == 0");
+            a.out_half = d->out_fmt == 1; a.out_planes2 = d->out_fmt == 2;
+            a.out_plane_stride = (long long)d->B * d->OH * d->OW * d->Cout;
+            a.out_bound_k = (float)(d->Cin * d->R * d->S); a.out_bound = d->out_bound;
+        }
+    } else if (d->out_fmt == 1) {
         PYLC_REQUIRE(d->x_fmt == 1 && d->out_bound && bias == nullptr && ep == nullptr && d->y_pitch == d->Cout && d->Cout % 4 == 0,
                      "conv2d_fwd: a one-plane fp16 output needs fp16-plane input, out_bound, no bias / fused epilogue and a dense y");
         a.out_half = 1; a.out_bound_k = (float)(d->Cin * d->R * d->S); a.out_bound = d->out_bound;

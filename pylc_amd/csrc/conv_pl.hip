@@ -54,7 +54,7 @@ constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, B
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
 // AM: 16-row fragments per wave along the pixel axis -- 4 (64 x 64 wave tiles, waves 2 wide) or 2 (32 x 64 wave tiles, every wave in the
 // first 64 columns: the NARROW launches for at most 64 output channels)
-template <int NTERMS, int BM, bool BNB = false, int AM = 4>
+template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false>
 __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
                                             const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid) {
     constexpr int BN = PL_BN, WM = 16 * AM, WN = 64, AT = 4;
@@ -65,16 +65,28 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
     const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
-    float hscale = 1.f;                                  // out_half: the output leaves as one fp16 plane
-    if (a.out_half) {
-        const float b = a.out_bound_k * __uint_as_float(*a.amax_x) * __uint_as_float(*a.amax_w);
+    float hscale = 1.f;                                  // out_half / out_planes2: the output leaves as one / two fp16 planes
+    if (a.out_half || (EP && a.out_planes2)) {
+        float b;
+        if constexpr (EP) {
+            // fused inference epilogue: bound of act(conv * scale + shift + residual) from the TRUE input maximum (GatherGemmArgs::bound_x)
+            b = a.out_bound_k * __uint_as_float(*(a.bound_x != nullptr ? a.bound_x : a.amax_x)) * __uint_as_float(*a.amax_w);
+            if (a.ep_scale_amax != nullptr) b = b * __uint_as_float(*a.ep_scale_amax) + __uint_as_float(*a.ep_shift_amax);
+            if (a.ep_res_amax != nullptr) b += __uint_as_float(*a.ep_res_amax);
+        } else {
+            b = a.out_bound_k * __uint_as_float(*a.amax_x) * __uint_as_float(*a.amax_w);
+        }
         hscale = pow2_scale_for(__float_as_uint(b));
         if (blockIdx.x == 0 && tid == 0) *a.out_bound = __float_as_uint(b);
     }
-    const float* extra = a.add_src != nullptr ? a.add_src : (a.accumulate ? a.y : nullptr);
+    const float* extra = a.add_src != nullptr ? a.add_src : (a.accumulate ? a.y : ((EP && a.ep_res_fmt == 0) ? a.ep_res : nullptr));
+    const bool res_planes = EP && a.ep_res != nullptr && a.ep_res_fmt != 0;      // residual as fp16 planes (y's geometry, dense)
+    const float res_unscale = res_planes ? 1.f / pow2_scale_for(*a.ep_res_scale) : 1.f;
     const unsigned char* amask = a.add_mask;         // (with add_src; y_pitch == N_store: element offset / 4 = the mask's vector index)
     int eoff[AM][AT];
     float bv[AT][4];
+    float esc[EP ? AT : 1][4], esh[EP ? AT : 1][4];          // fused inference epilogue: eval-BatchNorm scale / shift of this lane's channels
+    float ep_max = 0.f;
     {
         int offs[AM];
 #pragma unroll
@@ -87,6 +99,13 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             for (int i = 0; i < AM; ++i) eoff[i][j] = (nok && offs[i] >= 0) ? offs[i] + n4 : -1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[j][r] = (a.bias != nullptr && n4 + r < a.N) ? a.bias[n4 + r] : 0.f;
+            if constexpr (EP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    esc[j][r] = (a.ep_scale != nullptr && n4 + r < a.N) ? a.ep_scale[n4 + r] : 1.f;
+                    esh[j][r] = (a.ep_scale != nullptr && n4 + r < a.N) ? a.ep_shift[n4 + r] : 0.f;
+                }
+            }
         }
     }
     constexpr int PJ = 2;
@@ -102,7 +121,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             }
     // one-plane fp16 output: the BatchNorm that follows normalises the ROUNDED tensor, so its statistics (and nothing else differs: the store
     // below reproduces the same halves exactly, hscale being a power of two) are taken from the rounded values, not from the accumulators
-    if (a.out_half) {
+    if (!EP && a.out_half) {
         const float inv_h = 1.f / hscale;
 #pragma unroll
         for (int i = 0; i < AM; ++i)
@@ -144,7 +163,12 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float val = acc[i][j][r] + bv[j][r];
+                    if constexpr (EP) val = val * esc[j][r] + esh[j][r];          // BatchNorm-apply's own expression and order (conv_igemm.hip's fused epilogue)
                     if constexpr (decltype(has_prev)::value) val += prev[i][jj][r];
+                    if constexpr (EP) {
+                        if (a.ep_relu) val = fmaxf(val, 0.f);
+                        ep_max = fmaxf(ep_max, stored ? fabsf(val) : 0.f);
+                    }
                     acc[i][j][r] = val;
                     if constexpr (decltype(has_y)::value) {
                         const float yy = yv[i][jj][r];      // (jj indexes the columns held: j - j0)
@@ -181,6 +205,12 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                         const f32x4v_ v = acc[i][j0 + jj] * hscale;
                         const f16x4_ h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                         *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(a.y) + eoff[i][j0 + jj]) = __builtin_bit_cast(uint2, h);
+                    } else if (EP && a.out_planes2) {          // two planes: h0 = rn16(s v), h1 = rn16(2^11 (s v - h0)) -- what pylc_to_planes writes
+                        uint2 p0, p1;
+                        split2(acc[i][j0 + jj], hscale, p0, p1);
+                        _Float16* const dst = reinterpret_cast<_Float16*>(a.y) + eoff[i][j0 + jj];
+                        *reinterpret_cast<uint2*>(dst) = p0;
+                        *reinterpret_cast<uint2*>(dst + a.out_plane_stride) = p1;
                     } else {
                         *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
                     }
@@ -229,8 +259,38 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                 ym[i][jj] = (a.bn_mask != nullptr && e >= 0) ? (unsigned)a.bn_mask[e >> 3] >> (((e >> 2) & 1) * 4) : 0u;
             }
     };
+    // residual of the fused inference epilogue arriving as fp16 planes: element = (h0 + 2^-11 h1) / s
+    auto fetch_res = [&](int j0) {
+        typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+        const _Float16* const rp = reinterpret_cast<const _Float16*>(a.ep_res);
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PJ; ++jj) {
+                const int e = eoff[i][j0 + jj];
+                f32x4v_ v = {0.f, 0.f, 0.f, 0.f};
+                if (e >= 0) {
+                    const f16x4_ h0 = __builtin_bit_cast(f16x4_, *reinterpret_cast<const uint2*>(rp + e));
+                    v = __builtin_convertvector(h0, f32x4v_);
+                    if (a.ep_res_fmt == 2) {
+                        const f16x4_ h1 = __builtin_bit_cast(f16x4_, *reinterpret_cast<const uint2*>(rp + e + a.ep_res_plane_stride));
+                        v += __builtin_convertvector(h1, f32x4v_) * (1.f / 2048.f);
+                    }
+                    v *= res_unscale;
+                }
+                prev[i][jj] = v;
+            }
+    };
     if constexpr (!bn) {
-        if (extra == nullptr) {
+        if (res_planes) {
+            fetch_res(0);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 0>{}, prev, none, nomask);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_res(2);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 2>{}, prev, none, nomask);
+        } else if (extra == nullptr) {
             finish(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{}, none, none, nomask);
         } else {
             fetch(0);
@@ -265,6 +325,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
         }
     }
     if (bn && a.bn_gmax != nullptr) amax_commit(gmax, a.bn_gmax);
+    if (EP && a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
     if (do_stats) {
         __syncthreads();
         if (tid < BN) {
@@ -286,7 +347,8 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
 // NARROW: launches with at most 64 output channels.  The 2-wide wave grid would leave the waves of the second column -- SIMDs 2 and 3 --
 // multiplying zeros while SIMDs 0 and 1 do all the work; here every wave sits in the first 64 columns on a 32 x 64 tile (half the
 // MFMAs per wave, all four SIMDs busy).  Same LDS image, DMA and reduction order per output element as the wide form: bit-identical.
-template <int NTERMS, int BM, bool STAMPS = false, bool BNB = false, bool NARROW = false>
+// EP: the fused inference epilogue (eval BatchNorm + residual + ReLU, plane outputs; pl_epilogue<.., EP>) is compiled in only here
+template <int NTERMS, int BM, bool STAMPS = false, bool BNB = false, bool NARROW = false, bool EP = false>
 __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a) {
     constexpr int BN = PL_BN, AM = NARROW ? 2 : 4, WM = 16 * AM, WN = 64, AT = 4, ROW = PL_ROW;
     constexpr int NW = BM / 32;                             // waves: 4 (2 M x 2 N) or 8 (4 M x 2 N)
@@ -568,7 +630,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     PL_STAMP();
     __syncthreads();          // LDS stage 0 is reused for the statistics; orders the row table when S == 0
 
-    pl_epilogue<NTERMS, BM, BNB, AM>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tile / a.tiles_n, n0, wave_m, wave_n, lane, tid);
+    pl_epilogue<NTERMS, BM, BNB, AM, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tile / a.tiles_n, n0, wave_m, wave_n, lane, tid);
     if constexpr (STAMPS) {
         __builtin_amdgcn_sched_barrier(0);
         PL_STAMP();
@@ -606,7 +668,7 @@ constexpr int plh_bstage_bytes() { return (NTERMS == 3 ? 2 : 1) * PL_BN * PL_ROW
 template <int NTERMS>
 constexpr int plh_lds_bytes() { return 2 * plh_halo_bytes<NTERMS>() + 3 * plh_bstage_bytes<NTERMS>() + 256 * 4 + 64; }
 
-template <int NTERMS, bool BNB = false>
+template <int NTERMS, bool BNB = false, bool EP = false>
 __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) {
     constexpr int BM = 256, BN = PL_BN, WN = 64, AT = 4, ROW = PL_ROW;
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
@@ -760,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // LDS is reused for the statistics; orders the row table
-    pl_epilogue<NTERMS, BM, BNB>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid);
+    pl_epilogue<NTERMS, BM, BNB, 4, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid);
 }
 
 template __global__ void gg_plh_kernel<3>(const GatherGemmArgs);
@@ -782,6 +844,16 @@ template __global__ void gg_pl_kernel<1, 128, false, false, true>(const GatherGe
 template __global__ void gg_pl_kernel<1, 256, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_plh_kernel<3, true>(const GatherGemmArgs);
 template __global__ void gg_plh_kernel<1, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 128, false, false, false, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 256, false, false, false, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 128, false, false, false, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 256, false, false, false, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 128, false, false, true, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<3, 256, false, false, true, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 128, false, false, true, true>(const GatherGemmArgs);
+template __global__ void gg_pl_kernel<1, 256, false, false, true, true>(const GatherGemmArgs);
+template __global__ void gg_plh_kernel<3, false, true>(const GatherGemmArgs);
+template __global__ void gg_plh_kernel<1, false, true>(const GatherGemmArgs);
 
 
 // geometry / size conditions on top of: A operand given as planes, prepared filter planes present
@@ -794,7 +866,7 @@ bool takes_pl(const GatherGemmArgs& a) {
     const bool aligned = a.y_pitch % 4 == 0 && a.N_store % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(a.x_planes) & 15) == 0 && (a.x_plane_stride % 8) == 0 && a.x_pitch % 8 == 0;
     return a.x_planes != nullptr && a.w_planes != nullptr && aligned && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) &&
-           a.w_plane_stride * 4 < (1ll << 31) && a.ep_scale == nullptr;
+           a.w_plane_stride * 4 < (1ll << 31);
 }
 
 template <int NTERMS, int BM>
@@ -804,7 +876,10 @@ static void launch_pl(const GatherGemmArgs& a, unsigned grid, hipStream_t st) {
         hipLaunchKernelGGL((gg_pl_kernel<3, BM, true>), dim3(grid), dim3(BM * 2), lds_bytes + 4096, st, a);
         return;
     }
-    if (a.bn_y != nullptr) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+    const bool ep = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;      // fused inference epilogue
+    if (ep && a.N_store <= 64 && !(g_pp_flags & 65536)) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, true, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+    else if (ep) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+    else if (a.bn_y != nullptr) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
     else if (a.N_store <= 64 && !(g_pp_flags & 65536)) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
     else hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
 }
@@ -815,8 +890,15 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     if (a.dh_step > 2 || a.dh_step < -2 || a.dw_step > 2 || a.dw_step < -2) a.dbg_flags |= 4096;      // as launch_gg_pp
     a.ident = a.TR == 1 && a.TS == 1 && a.in_sh == 1 && a.in_sw == 1 && a.dh0 == 0 && a.dw0 == 0 && a.IH == a.P && a.IW == a.Q &&
               a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 && a.ow0 == 0 && a.OH == a.P && a.OW == a.Q;
-    PYLC_REQUIRE(!a.out_half || (a.out_bound != nullptr && a.amax_x && a.amax_w && !a.accumulate && a.add_src == nullptr && a.bn_y == nullptr && a.bias == nullptr),
-                 "conv with a one-plane fp16 output: needs out_bound and the operand ranges; no accumulation, residual source, BatchNorm sums or bias");
+    PYLC_REQUIRE(!(a.out_half || a.out_planes2) ||
+                     (a.out_bound != nullptr && a.amax_x && a.amax_w && !a.accumulate && a.add_src == nullptr && a.bn_y == nullptr &&
+                      (a.bias == nullptr || a.ep_scale != nullptr) && a.y_pitch == a.N_store),
+                 "conv with an fp16-plane output: needs out_bound, the operand ranges and a dense y; no accumulation, residual-gradient source or BatchNorm sums "
+                 "(a bias only with the fused inference epilogue)");
+    PYLC_REQUIRE(a.ep_res == nullptr || a.ep_res_fmt == 0 || (a.ep_res_scale != nullptr && a.y_pitch == a.N_store && a.N_store % 4 == 0),
+                 "conv with a fused fp16-plane residual: needs the residual's scale bound and a dense y");
+    PYLC_REQUIRE(!(a.ep_scale != nullptr || a.out_planes2 || a.ep_res != nullptr) || (a.stats == nullptr && !a.accumulate && a.add_src == nullptr && a.bn_y == nullptr),
+                 "conv with the fused inference epilogue: no statistics, accumulation or backward fusions");
     PYLC_REQUIRE(a.add_src == nullptr || (a.y_pitch == a.N_store && a.N_store % 8 == 0 && !a.accumulate),
                  "conv dgrad with a masked residual source needs a dense output (pitch == channels, channels %% 8 == 0) and no accumulation");
     PYLC_REQUIRE(a.bn_y == nullptr || (a.y_pitch == a.N_store && a.stats != nullptr && a.bn_mean && a.bn_invstd && (!a.bn_relu || a.bn_mask || (a.bn_scale && a.bn_shift))),
@@ -840,7 +922,10 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
         a.halo_tiles_m = (int)halo_tiles_m;
         const long long n_tiles = halo_tiles_m * a.tiles_n;
         a.n_tiles = (int)n_tiles;
-        if (a.bn_y != nullptr) {
+        if (a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr) {
+            if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1, false, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
+            else hipLaunchKernelGGL((gg_plh_kernel<3, false, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
+        } else if (a.bn_y != nullptr) {
             if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
             else hipLaunchKernelGGL((gg_plh_kernel<3, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
         } else if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
@@ -898,6 +983,16 @@ int conv_pl_init() {
     PYLC_HIP(opt_in((gg_pl_kernel<1, 256, false, false, true>), pl_lds_bytes<1, 256>()));
     PYLC_HIP(opt_in((gg_plh_kernel<3, true>), plh_lds_bytes<3>()));
     PYLC_HIP(opt_in((gg_plh_kernel<1, true>), plh_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, false, false, true>), pl_lds_bytes<3, 128>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, false, false, true>), pl_lds_bytes<3, 256>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<1, 128, false, false, false, true>), pl_lds_bytes<1, 128>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<1, 256, false, false, false, true>), pl_lds_bytes<1, 256>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, false, true, true>), pl_lds_bytes<3, 128>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, false, true, true>), pl_lds_bytes<3, 256>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<1, 128, false, false, true, true>), pl_lds_bytes<1, 128>()));
+    PYLC_HIP(opt_in((gg_pl_kernel<1, 256, false, false, true, true>), pl_lds_bytes<1, 256>()));
+    PYLC_HIP(opt_in((gg_plh_kernel<3, false, true>), plh_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plh_kernel<1, false, true>), plh_lds_bytes<1>()));
     PYLC_HIP(opt_in(gg_pl_kernel<3, 128, true>, pl_lds_bytes<3, 128>() + 4096));
     PYLC_HIP(opt_in(gg_pl_kernel<3, 256, true>, pl_lds_bytes<3, 256>() + 4096));
 

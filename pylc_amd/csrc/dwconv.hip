@@ -165,6 +165,9 @@ struct DwHalf {
     const float* in_shift = nullptr;
     const unsigned* y_bound = nullptr;
     int in_relu = 0;
+    // inference (pylc_dwconv3x3_fwd_h_eval): the TRUE max|in| when the tensor was scaled with a looser bound -- the output's bound is then
+    // 9 * w_amax * in_true, so that the looseness of one layer's bound does not compound into the next (conv_common.h GatherGemmArgs::bound_x)
+    const unsigned* in_true = nullptr;
 };
 
 template <bool HALF>
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         if (MODE == 2) aux_inv = 1.f / half_scale_for(*hf.aux_bound);
     }
     if constexpr (HOUT && MODE != 2) {
-        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*hf.in_bound);
+        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*(hf.in_true != nullptr ? hf.in_true : hf.in_bound));
         if (MODE == 1 && accumulate) { b += __uint_as_float(*hf.acc_bound); acc_inv = 1.f / half_scale_for(*hf.acc_bound); }
         out_scale = half_scale_for(__float_as_uint(b));
         if (blockIdx.x == 0 && threadIdx.x == 0) *hf.out_bound = __float_as_uint(b);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const void* __restrict__ i
     float aux_inv = 1.f, out_scale = 1.f, acc_inv = 1.f;
     if (MODE == 2) aux_inv = 1.f / half_scale_for(*hf.aux_bound);
     if constexpr (HOUT && MODE != 2) {
-        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*hf.in_bound);
+        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*(hf.in_true != nullptr ? hf.in_true : hf.in_bound));
         if (MODE == 1 && accumulate) { b += __uint_as_float(*hf.acc_bound); acc_inv = 1.f / half_scale_for(*hf.acc_bound); }
         out_scale = half_scale_for(__float_as_uint(b));
         if (blockIdx.x == 0 && threadIdx.x == 0) *hf.out_bound = __float_as_uint(b);
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256) void dw_tileg_kernel(const void* __restrict__ 
     float aux_inv = 1.f, out_scale = 1.f, acc_inv = 1.f;
     if (MODE == 2) aux_inv = 1.f / half_scale_for(*hf.aux_bound);
     if constexpr (HOUT && MODE != 2) {
-        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*hf.in_bound);
+        float b = 9.f * __uint_as_float(*hf.w_amax) * __uint_as_float(*(hf.in_true != nullptr ? hf.in_true : hf.in_bound));
         if (MODE == 1 && accumulate) { b += __uint_as_float(*hf.acc_bound); acc_inv = 1.f / half_scale_for(*hf.acc_bound); }
         out_scale = half_scale_for(__float_as_uint(b));
         if (blockIdx.x == 0 && threadIdx.x == 0) *hf.out_bound = __float_as_uint(b);
@@ -949,6 +952,18 @@ extern "C" int pylc_dwconv3x3_fwd_h(const PylcDwDesc* d, const void* x_h, const 
                  "dwconv_fwd_h: null pointer, or not a dense stride-1 / dilation-1 shape (pylc_dwconv3x3_half_ok)");
     const DwHalf hf{x_bound, nullptr, w_amax, nullptr, y_bound_out};
     return dw_fwd_h_impl(d, x_h, w, y_h, stats_partial, hf, stream);
+}
+
+// pylc_dwconv3x3_fwd_h for inference on plane tensors: x_true_amax = the true max|x| (x_bound is what x was SCALED with); the output is
+// scaled with -- and *y_bound_out receives -- 9 max|w| x_true_amax.  No statistics.
+extern "C" int pylc_dwconv3x3_fwd_h_eval(const PylcDwDesc* d, const void* x_h, const unsigned int* x_bound, const unsigned int* x_true_amax, const float* w,
+                                         const unsigned int* w_amax, void* y_h, unsigned int* y_bound_out, void* stream) {
+    if (int rc = check_dw(d)) return rc;
+    PYLC_REQUIRE(x_h && x_bound && x_true_amax && w && w_amax && y_h && y_bound_out && pylc_dwconv3x3_half_ok(d),
+                 "dwconv_fwd_h_eval: null pointer, or not a shape of the half kernels (pylc_dwconv3x3_half_ok)");
+    DwHalf hf{x_bound, nullptr, w_amax, nullptr, y_bound_out};
+    hf.in_true = x_true_amax;
+    return dw_fwd_h_impl(d, x_h, w, y_h, nullptr, hf, stream);
 }
 
 // pylc_dwconv3x3_fwd_h on the INPUT of the BatchNorm (+ ReLU) that produces x: see DwHalf::in_scale.  Tiled kernels only.

@@ -105,6 +105,19 @@ class BatchNorm2d(nn.Module):
             self._coef, self._coef_key = coef, key
         return self._coef
 
+    def eval_coeff_ranges(self):
+        """int32[2]: float bits of max|scale|, max|shift| of eval_coeffs() -- what the fused inference conv needs to bound a plane output
+        (ops.conv_bn_act_eval_planes); cached with the coefficients."""
+        coef = self.eval_coeffs()
+        if getattr(self, '_coef_rng_key', None) is not self._coef_key or getattr(self, '_coef_rng', None) is None:
+            from .lib import lib, check, ptr, stream
+            c = self.num_features
+            rng = torch.zeros(2, dtype=torch.int32, device=coef.device)
+            check(lib.pylc_amax(ptr(coef[:c]), 1, c, c, ptr(rng[0:1]), stream()))
+            check(lib.pylc_amax(ptr(coef[c:]), 1, c, c, ptr(rng[1:2]), stream()))
+            self._coef_rng, self._coef_rng_key = rng, self._coef_key
+        return self._coef_rng
+
     def flush_counter(self):
         if self._nbt_pending:
             self.num_batches_tracked += self._nbt_pending
@@ -127,9 +140,10 @@ def conv_bn(conv, bn, x, residual=None, relu=False, conv_link=None, out_planes=F
     inside the conv epilogue (ops.conv_bn_act_eval); otherwise the two modules are called as usual (the conv output has ONE consumer,
     the BatchNorm: that is what lets its backward hand dy back as fp16 planes)."""
     if (not bn.training and not torch.is_grad_enabled() and runtime.fuse_eval_bn and conv.cin % 4 == 0
-            and (residual is None or ops.pitch_of(ops.as_nhwc(residual)) == ((conv.cout + 3) & ~3))):
+            and (residual is None or ops.is_planes(residual) or ops.pitch_of(ops.as_nhwc(residual)) == ((conv.cout + 3) & ~3))):
         return ops.conv_bn_act_eval(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn.running_mean,
-                                    bn.running_var, bn.weight, bn.bias, bn.eps, residual, relu, into, coef=bn.eval_coeffs())
+                                    bn.running_var, bn.weight, bn.bias, bn.eps, residual, relu, into, coef=bn.eval_coeffs(),
+                                    coef_ranges=bn.eval_coeff_ranges(), out_planes=out_planes)
     # sole: the caller states that the result has exactly ONE consumer, a conv -- whose dgrad may then take this BatchNorm's backward sums
     return bn(conv(x, res_link=conv_link), residual=residual, relu=relu, out_planes=out_planes, drop=drop, into=into, sole=sole)
 

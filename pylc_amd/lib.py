@@ -46,6 +46,13 @@ class BnBack(C.Structure):
                 ('relu_mask', C.c_void_p), ('relu', C.c_int), ('g_amax', C.c_void_p)]
 
 
+class FwdEp(C.Structure):
+    """PylcFwdEp: the fused inference epilogue of pylc_conv2d_fwd_bnact_ex (plane residual / plane output / true input range)."""
+    _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('scale_amax', C.c_void_p), ('shift_amax', C.c_void_p), ('residual', C.c_void_p),
+                ('res_fmt', C.c_int), ('res_scale_bound', C.c_void_p), ('res_amax', C.c_void_p), ('x_true_amax', C.c_void_p), ('relu', C.c_int),
+                ('amax_out', C.c_void_p)]
+
+
 class DwDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'H', 'W', 'C', 'stride', 'dil', 'OH', 'OW', 'x_pitch', 'y_pitch')]
 
@@ -86,6 +93,7 @@ SIGNATURES = {
     'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     'pylc_conv2d_fwd_bnact': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'pylc_conv2d_fwd_bnact_ex': (_I, [C.POINTER(ConvDesc), _P, _P, _P, C.POINTER(FwdEp), _P, _P]),
     'pylc_conv2d_fwd_stats_floats': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd_stats': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(_I), _P]),
     'pylc_conv2d_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P]),
@@ -112,6 +120,7 @@ SIGNATURES = {
     'pylc_dwconv3x3_dgrad_h_add_ok': (_I, [C.POINTER(DwDesc)]),
     'pylc_dwconv3x3_dgrad_h_add': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_dwconv3x3_fwd_h': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pylc_dwconv3x3_fwd_h_eval': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'pylc_dwconv3x3_dgrad_h': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'pylc_dwconv3x3_wgrad_h': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'pylc_bn_workspace_floats': (_SZ, [_LL, _I]),

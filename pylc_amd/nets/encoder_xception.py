@@ -80,6 +80,14 @@ class SeparableConv2d(nn.Module):
         inner BatchNorm folded into its filter and the outer BatchNorm, the residual add and the ReLU in its epilogue (ops.conv_bn_act_eval)
         -- instead of four passes."""
         w2, b2 = self._folded()
+        if ops.ranges_needed() and runtime.eval_planes and not runtime.no_planes:
+            # precision mode 3: the whole group on one-plane fp16 tensors -- depthwise half -> half, pointwise conv planes -> planes with the
+            # outer BatchNorm / residual / ReLU in its epilogue (ops.conv_bn_act_eval_planes)
+            yh = ops.dwconv3x3_eval_half(x, self.conv1.weight, self.conv1.stride, self.conv1.dilation)
+            if yh is not None:
+                return ops.conv_bn_act_eval(yh, w2, b2, 1, 0, 1, bn_out.running_mean, bn_out.running_var, bn_out.weight, bn_out.bias,
+                                            bn_out.eps, residual, relu, coef=bn_out.eval_coeffs(), coef_ranges=bn_out.eval_coeff_ranges(),
+                                            out_planes=True)
         y = self.conv1(x)
         if ops.ranges_needed():
             # the pointwise conv's arithmetic needs a bound of |y|: 9 max|w_dw| max|x| from the two operand ranges instead of a pass over y

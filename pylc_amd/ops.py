@@ -230,8 +230,10 @@ class KernelTimer:
         # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
         # activations travel as planes; '*' = both tile heights (rocprof lists them as two rows) and the 3x3 halo variant: one kernel
         # family (conv_pl.hip), the same loop body, dispatched by shape
-        self.KERNEL = ('gather_gemm_pp_kernel<..., %s> (pylc_conv2d_fwd_bnact: conv + eval BatchNorm + residual + ReLU in the epilogue)'
-                       % ('ONE-plane fp16' if self.mode == 3 else 'f16x3') if self.inference else
+        self.KERNEL = (('gg_pl_kernel<%d,*,EP> + gg_plh_kernel<%d,EP> (pylc_conv2d_fwd_bnact_ex: plane tensors, conv + eval BatchNorm + residual + ReLU '
+                        'in the epilogue)' % (((3 if self.mode == 2 else 1),) * 2) if (_runtime.eval_planes and self.planes) else
+                        'gather_gemm_pp_kernel<..., %s> (pylc_conv2d_fwd_bnact: conv + eval BatchNorm + residual + ReLU in the epilogue)'
+                        % ('ONE-plane fp16' if self.mode == 3 else 'f16x3')) if self.inference else
                        'gg_pl_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 2) if self.planes else
                        'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
                        'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
@@ -1046,12 +1048,85 @@ def conv_transpose2x2(x, w, bias=None):
     return ConvTranspose2x2Fn.apply(x, w, bias)
 
 
-def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False, into=None, coef=None):
+eval_plane_convs = [0]      # diagnostics: fused inference convs that ran on fp16-plane tensors (conv_bn_act_eval_planes)
+
+
+def conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes):
+    """conv_bn_act_eval on fp16-PLANE tensors (pylc_conv2d_fwd_bnact_ex): x is (or is converted to) a planes tensor, the residual is read
+    as planes or fp32, the result leaves as planes (out_planes: every consumer reads that format) or fp32.  A planes tensor of the
+    inference path carries two device scalars -- the bound it was SCALED with (the `_pylc_pl` marker, what a consumer needs to undo the
+    scale) and its TRUE maximum (the `_pylc_amax` tag, max-accumulated by the producing epilogue, what the consumer's own bound starts
+    from): an eval-mode net has no batch statistics to re-anchor the bounds, and a bound derived from the previous bound would grow by
+    ~2^8 per layer.  Returns None when the launch is not eligible (the caller takes the fp32 form)."""
+    cout, cin_w, r, s = w.shape
+    planes = getattr(w, '_pylc_planes', None)
+    if not is_planes(x):
+        x = as_nhwc(x)
+    b, cin, h, wd = x.shape
+    oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+    if (planes is None or cin != cin_w or not conv_takes_planes(w, b * h * wd, b * oh * ow) or cout % 8 or not planes_ok(cout, b * oh * ow)
+            or not w.permute(0, 2, 3, 1).is_contiguous()):
+        return None
+    if residual is not None and not is_planes(residual):
+        residual = as_nhwc(residual)
+        if tuple(residual.shape) != (b, cout, oh, ow) or pitch_of(residual) != cout:
+            return None
+    if not is_planes(x):
+        x_true = amax_of(x)                       # (a valid tag, or one read pass: the stem / a pooled tensor)
+        x = to_planes(x, x_true)
+    else:
+        x_true = amax_of(x)                       # the producer's true maximum if it left one, else the scale bound itself
+    d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, cin, cout)
+    d.x_fmt = 1
+    w_amax = weight_amax(w)
+    d.x_amax, d.w_amax, d.w_planes = ptr(planes_amax(x)), ptr(w_amax), ptr(planes[0])
+    y = empty_nhwc(b, cout, oh, ow, x.device)
+    true_amax = amax_slot(x.device)
+    bound = None
+    if out_planes:
+        bound = amax_slot(x.device)
+        d.out_fmt, d.out_bound = nplanes(), ptr(bound)
+    ep = L.FwdEp()
+    ep.scale, ep.shift = ptr(coef[:cout]), ptr(coef[cout:])
+    ep.scale_amax, ep.shift_amax = ptr(coef_ranges[0:1]), ptr(coef_ranges[1:2])
+    ep.x_true_amax, ep.relu, ep.amax_out = ptr(x_true), int(relu), ptr(true_amax)
+    keep = [x_true, w_amax, coef_ranges]
+    if residual is not None:
+        ep.residual = ptr(residual)
+        if is_planes(residual):
+            ep.res_fmt, ep.res_scale_bound = nplanes(), ptr(planes_amax(residual))
+        res_true = amax_of(residual)
+        ep.res_amax = ptr(res_true)
+        keep.append(res_true)
+    ev = None
+    if _timer is not None and _timer.inference and cout > 64:
+        ev = _timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd_bnact%dx%d' % (r, s), 4.0 * (b * h * wd * cin + w.numel() + b * oh * ow * cout))
+        ev[0].record()
+    check(lib.pylc_conv2d_fwd_bnact_ex(C.byref(d), ptr(x), ptr(w), ptr(bias), C.byref(ep), ptr(y), stream()))
+    if ev is not None:
+        ev[1].record()
+    eval_plane_convs[0] += 1
+    if out_planes:
+        mark_planes(y, bound)
+    tag_amax(y, true_amax)                        # (after mark_planes, which tags with the bound)
+    return y
+
+
+def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, gamma, beta, eps, residual=None, relu=False, into=None, coef=None,
+                     coef_ranges=None, out_planes=False):
     """Inference only (no autograd): act(BN_eval(conv(x)) (+ residual)) with the BatchNorm coefficients, the residual add and
     the ReLU applied in the conv epilogue -- bit-identical to conv2d followed by bn_act(training=False), one pass less.
-    into = ([buffer], c0): write the result into channels [c0, c0 + Cout) of that NHWC concat buffer (aspp.py:80, decoder.py:47)."""
+    into = ([buffer], c0): write the result into channels [c0, c0 + Cout) of that NHWC concat buffer (aspp.py:80, decoder.py:47).
+    coef_ranges (int32[2]: float bits of max|scale|, max|shift|) switches the fp16-plane form on where the launch is eligible
+    (conv_bn_act_eval_planes); out_planes: the caller states that every consumer of the result reads planes."""
     L.init()
+    if (coef is not None and coef_ranges is not None and into is None and ranges_needed() and _runtime.eval_planes and not _runtime.no_planes):
+        y = conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes)
+        if y is not None:
+            return y
     x = as_nhwc(x)
+    if residual is not None:
+        residual = as_nhwc(residual)
     cout, cin_w, r, s = w.shape
     cin = x.shape[1]
     if cin != cin_w or cin_w % 4 or not w.permute(0, 2, 3, 1).is_contiguous():
@@ -1256,6 +1331,29 @@ class DwConv3x3Fn(torch.autograd.Function):
             check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, st))
             dw = _deliver_grad(w, dw)
         return dx, dw, None, None, None, None, None
+
+
+def dwconv3x3_eval_half(x, w, stride=1, dil=1):
+    """Inference, precision mode 3: depthwise 3x3 on a ONE-PLANE fp16 tensor (pylc_dwconv3x3_fwd_h_eval) -> one-plane tensor scaled with
+    9 max|w| x (true max|x|), which is also its tag (the true maximum of a depthwise output is not taken: the bound is within 2^3 of it).
+    Returns None when the geometry has no half kernel or x is not / cannot be held as a plane."""
+    L.init()
+    if not (half_dw() and nplanes() == 1):
+        return None
+    b, c, h, wd = x.shape
+    d = _dw_desc(x, stride, dil, c, c)
+    if not (lib.pylc_dwconv3x3_half_ok(C.byref(d)) and planes_ok(c, b * h * wd) and planes_ok(c, b * d.OH * d.OW)):
+        return None
+    if not is_planes(x):
+        x = as_nhwc(x)
+        true = amax_of(x)
+        x = to_planes(x, true)
+    else:
+        true = amax_of(x)
+    y = empty_nhwc(b, c, d.OH, d.OW, x.device)
+    bound = amax_slot(x.device)
+    check(lib.pylc_dwconv3x3_fwd_h_eval(C.byref(d), ptr(x), ptr(planes_amax(x)), ptr(true), ptr(w), ptr(weight_amax(w)), ptr(y), ptr(bound), stream()))
+    return mark_planes(y, bound)
 
 
 def dwconv3x3(x, w, stride=1, dil=1, res_link=None, want_stats=False):

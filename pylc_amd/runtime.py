@@ -57,6 +57,9 @@ class _Runtime:
         self.half_acts = os.environ.get('PYLC_HALF_ACTS', '1') != '0'
         # ... and the depthwise kernels' operands with them (PYLC_HALF_DW=0: the tensors around the depthwise convs stay fp32) (A/B knob)
         self.half_dw = os.environ.get('PYLC_HALF_DW', '1') != '0'
+        # inference: the fused conv + BatchNorm kernels read and write fp16-plane tensors where producer and consumer allow it
+        # (ops.conv_bn_act_eval_planes); PYLC_EVAL_PLANES=0 keeps fp32 activations between the kernels (the round-3 path; A/B knob)
+        self.eval_planes = os.environ.get('PYLC_EVAL_PLANES', '1') != '0'
         self.fuse_eval_bn = True      # inference: eval-mode BatchNorm (+ residual + ReLU) inside the conv epilogue (layers.conv_bn)
         self.bn_clamp_eps = False     # True = vendored SyncBN's clamp(var, eps)^-1/2 (batchnorm.py:125)
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)

@@ -1,0 +1,171 @@
+"""Inference on fp16-plane tensors (-m gpu): pylc_conv2d_fwd_bnact_ex / pylc_dwconv3x3_fwd_h_eval behind ops.conv_bn_act_eval and the nets'
+eval paths (Model.eval / Model.test, models/model.py:338-382).  The plane form must compute what the fp32-tensor form computes -- same
+kernels' arithmetic, the tensors between them rounded to the operand format (2^-22 relative for the two-plane f16x3 format, 2^-11 for the
+one-plane format of precision mode 3) -- and every plane tensor must carry a scale bound that covers it and a true maximum that is one."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def nhwc(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.fixture(params=[2, 3], ids=['f16x3', 'mode3'])
+def mode(request, dev):
+    from pylc_amd.lib import lib, check
+    from pylc_amd import ops, runtime
+    prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
+    check(lib.pylc_set_conv_precision(request.param))
+    ops.PLANES_MIN_PIXELS = 0
+    yield request.param
+    ops.PLANES_MIN_PIXELS = prev_min
+    runtime.eval_planes = prev_ep
+    check(lib.pylc_set_conv_precision(prev))
+
+
+# cin, cout, k, stride, pad, dil, B, H, W, residual ('none' | 'fp32' | 'planes'), relu
+CASES = [
+    (256, 1024, 1, 1, 0, 1, 2, 32, 32, 'planes', True),      # bottleneck conv3 + identity residual (resnet.py:47-51)
+    (1024, 256, 1, 1, 0, 1, 2, 32, 32, 'none', True),        # conv1
+    (256, 256, 3, 1, 1, 1, 2, 32, 32, 'none', True),         # conv2: the halo kernel
+    (64, 64, 3, 1, 1, 1, 2, 48, 48, 'none', True),           # layer1 3x3: narrow wave layout
+    (256, 64, 1, 1, 0, 1, 2, 40, 36, 'fp32', False),         # narrow 1x1, ragged M, fp32 residual, no ReLU
+    (128, 128, 3, 2, 1, 1, 2, 45, 45, 'none', True),         # stride 2
+    (2048, 256, 3, 1, 12, 12, 2, 32, 32, 'none', True),      # ASPP branch: tap skipping
+    (728, 728, 1, 1, 0, 1, 2, 16, 16, 'planes', False),      # Xception pointwise + skip, channel tails
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('out_planes', [True, False])
+def test_fused_inference_conv_on_planes(dev, mode, case, out_planes):
+    from pylc_amd import ops, layers, optim, runtime
+    cin, cout, k, st, pad, dil, B, H, W, res_kind, relu = case
+    torch.manual_seed(5)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil, bn=True).to(dev)
+    bn = layers.BatchNorm2d(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * rnd(1, cout).to(dev))
+        bn.bias.copy_(0.2 * rnd(2, cout).to(dev))
+        bn.running_mean.copy_(0.1 * rnd(3, cout).to(dev))
+        bn.running_var.copy_(1 + 0.2 * rnd(4, cout).abs().to(dev))
+    arena = optim.FlatArena(torch.nn.ModuleList([conv, bn]))
+    conv.eval(); bn.eval()
+    x = nhwc(rnd(6, B, cin, H, W, scale=1.5), dev)
+    oh, ow = ops.conv_out_size(H, k, st, pad, dil), ops.conv_out_size(W, k, st, pad, dil)
+    res = nhwc(rnd(7, B, cout, oh, ow), dev) if res_kind != 'none' else None
+    with torch.no_grad():
+        runtime.eval_planes = False
+        want = layers.conv_bn(conv, bn, x, residual=res, relu=relu)
+        assert not ops.is_planes(want)
+        runtime.eval_planes = True
+        n0 = ops.eval_plane_convs[0]
+        xp = ops.to_planes(x)
+        rp = ops.to_planes(res) if res_kind == 'planes' else res
+        got = layers.conv_bn(conv, bn, xp, residual=rp, relu=relu, out_planes=out_planes)
+        torch.cuda.synchronize()
+        assert ops.eval_plane_convs[0] == n0 + 1, 'the plane form did not run'
+        assert ops.is_planes(got) == out_planes
+        true = ops.amax_of(got).view(torch.float32).item()
+        vals = ops.as_nhwc(got) if out_planes else got
+        peak = want.abs().max().item()
+        # operands: x (and a plane residual) rounded to the operand format; output: rounded once more when it leaves as planes
+        eps = 2.0 ** -21 if mode == 2 else 2.0 ** -9
+        err = (vals - want).abs().max().item()
+        assert err <= (8 if (out_planes or mode == 3) else 4) * eps * max(peak, 1.0), (err, peak)
+        assert abs(true - vals.abs().max().item()) <= 4 * eps * peak + 1e-30          # the TRUE maximum travels with the tensor
+        if out_planes:
+            bound = ops.planes_amax(got).view(torch.float32).item()
+            assert bound >= true and bound <= 2.0 ** 14 * max(true, 1e-30)             # a bound, and not absurdly loose
+    del arena
+
+
+def test_resnet_eval_on_planes_matches_fp32_tensors(dev):
+    """DeepLabV3+/R101 in eval mode, 2 x 3 x 192 x 160 tiles: logits of the plane-tensor inference path against the fp32-tensor path
+    (PYLC_EVAL_PLANES=0, the round-3 path, itself pinned to the reference by the fixtures) -- both fp32-grade, so they agree far inside the
+    1e-3 bar, argmax identical off near-ties -- and the plane path really ran (counter), with at most a handful of format conversions."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import ops, runtime
+    from pylc_amd.lib import lib, check
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
+    check(lib.pylc_set_conv_precision(2))
+    ops.PLANES_MIN_PIXELS = 0
+    try:
+        cfg = ostep.StepConfig('deeplab', 'resnet', 9, 3, dropout=False)
+        x = D.tiles(5, 2, 3, 192, 160)
+        w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec('deeplab', 'resnet', 9, 3), salt=8), cfg, x.clone())
+        model = Model(Meta(), dev).build()
+        model.net.load_state_dict(w)
+        model.net.eval()
+        out = {}
+        for on in (False, True):
+            runtime.eval_planes = on
+            ops.eval_plane_convs[0] = 0
+            ops.plane_conversions[:] = [0, 0]
+            out[on] = model.test(x)[0].float().cpu()
+            n_pl, n_conv = ops.eval_plane_convs[0], ops.plane_conversions[0]
+        assert n_pl >= 100, n_pl                                   # 104 convs of the R101 + ASPP + decoder behind a BatchNorm
+        assert n_conv <= 8, n_conv
+        diff = (out[True] - out[False]).abs().max().item()
+        print('R101 eval: plane tensors vs fp32 tensors max |logit diff| %.3g over %d plane convs, %d conversions' % (diff, n_pl, n_conv))
+        assert diff < 2e-4
+        top2 = out[False].topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert torch.equal(out[True].argmax(1)[clear], out[False].argmax(1)[clear])
+        want = ostep.test_step({k: v.clone() for k, v in w.items()}, cfg, x.clone())
+        assert (out[True] - want).abs().max().item() < 1e-3        # and against the CPU oracle: the north_star's bar
+    finally:
+        runtime.eval_planes = prev_ep
+        ops.PLANES_MIN_PIXELS = prev_min
+        check(lib.pylc_set_conv_precision(prev))
+
+
+def test_xception_eval_on_half_planes_mode3(dev):
+    """DeepLabV3+/Xception, precision mode 3, eval: every separable conv as depthwise (half -> half, pylc_dwconv3x3_fwd_h_eval) + pointwise
+    conv with the folded inner BatchNorm and the outer BatchNorm / residual / ReLU in its epilogue on ONE-PLANE tensors, against the same
+    mode with fp32 tensors between the kernels (the round-3 path): logits agree to the one-plane format's accuracy, argmax off near-ties."""
+    import oracle
+    from oracle import step as ostep
+    from pylc_amd import ops, runtime
+    from pylc_amd.lib import lib, check
+    from pylc_amd.model import Model, Meta
+    from tests import _data as D
+    prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
+    check(lib.pylc_set_conv_precision(3))
+    ops.PLANES_MIN_PIXELS = 0
+    try:
+        cfg = ostep.StepConfig('deeplab', 'xception', 11, 1, dropout=False)
+        x = D.tiles(6, 2, 1, 256, 192)
+        w = ostep.calibrate_bn(oracle.formula_state(oracle.state_spec('deeplab', 'xception', 11, 1), salt=9), cfg, x.clone())
+        model = Model(Meta(backbone='xception', ch=1, n_classes=11), dev).build()
+        model.net.load_state_dict(w)
+        model.net.eval()
+        out = {}
+        for on in (False, True):
+            runtime.eval_planes = on
+            ops.eval_plane_convs[0] = 0
+            out[on] = model.test(x)[0].float().cpu()
+            n_pl = ops.eval_plane_convs[0]
+        assert n_pl >= 60, n_pl
+        scale = out[False].abs().max().item()
+        diff = (out[True] - out[False]).abs().max().item()
+        print('Xception eval (mode 3): half tensors vs fp32 tensors max |logit diff| %.3g (logit scale %.3g) over %d plane convs' % (diff, scale, n_pl))
+        assert diff < 2e-2 * max(scale, 1.0)
+        top2 = out[False].topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 5e-2 * max(scale, 1.0)
+        assert clear.float().mean().item() > 0.5
+        assert torch.equal(out[True].argmax(1)[clear], out[False].argmax(1)[clear])
+    finally:
+        runtime.eval_planes = prev_ep
+        ops.PLANES_MIN_PIXELS = prev_min
+        check(lib.pylc_set_conv_precision(prev))
