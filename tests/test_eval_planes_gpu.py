@@ -165,8 +165,8 @@ def test_xception_eval_on_half_planes_mode3(dev):
         # statistical bar for the 16-bit mode is argmax agreement off near-ties (and mIoU: tests/test_mode3_gpu.py, tests/test_fullsize_gpu.py)
         assert diff < 6e-2 * max(scale, 1.0)
         top2 = out[False].topk(2, dim=1).values
-        clear = (top2[:, 0] - top2[:, 1]) > 0.12 * max(scale, 1.0)
-        assert clear.float().mean().item() > 0.3
+        clear = (top2[:, 0] - top2[:, 1]) > 2.2 * diff            # a flip needs the two logits to move towards each other by the margin
+        assert clear.float().mean().item() > 0.15
         assert torch.equal(out[True].argmax(1)[clear], out[False].argmax(1)[clear])
     finally:
         runtime.eval_planes = prev_ep
