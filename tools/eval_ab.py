@@ -24,7 +24,7 @@ for name in (sys.argv[1:] or list(CFG)):
     res = {}
     with torch.no_grad():
         for rep in range(2):
-            for on in (False, True):
+            for on in ((False, True) if 'PYLC_EVAL_ONLY' not in os.environ else (os.environ['PYLC_EVAL_ONLY'] == '1',) * 2):
                 runtime.eval_planes = on
                 for _ in range(3): out = model.test(x)[0]
                 ops.eval_plane_convs[0] = 0; ops.plane_conversions[:] = [0, 0]; ops.amax_passes[:] = [0, 0]
@@ -33,6 +33,7 @@ for name in (sys.argv[1:] or list(CFG)):
                 for _ in range(n): out = model.test(x)[0]
                 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
                 res.setdefault(on, []).append((dt, ops.eval_plane_convs[0] // n, ops.plane_conversions[0] // n, ops.amax_passes[0] // n, out.float().clone()))
+    res.setdefault(True, res.get(False)); res.setdefault(False, res.get(True))
     d = (res[True][0][4] - res[False][0][4]).abs().max().item()
     agree = (res[True][0][4].argmax(1) == res[False][0][4].argmax(1)).float().mean().item()
     t0, t1 = min(r[0] for r in res[False]), min(r[0] for r in res[True])
