@@ -195,26 +195,48 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        // fp16 outputs: a lane holds 4 channels = 8 bytes per plane.  Lanes l and l + 16 (same pixel, the next channel quad) swap one half
+        // each (v_permlane16_swap: odd DPP rows of the first operand <-> even rows of the second), so that a store carries 16 bytes:
+        //   two planes: lanes of even rows write 8 channels of plane 0, lanes of odd rows the same 8 channels of plane 1;
+        //   one plane : lanes of even rows write 8 channels, lanes of odd rows nothing.
+        // (N_store % 8 == 0 for these formats, so a lane and its partner are stored or masked together.)
+        if (a.out_half || (EP && a.out_planes2)) {
+            typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+            const bool odd_row = (lane >> 4) & 1;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
+            for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-            for (int i = 0; i < AM; ++i)
-                if (eoff[i][j0 + jj] >= 0) {
+                for (int i = 0; i < AM; ++i) {
+                    const int e = eoff[i][j0 + jj];
+                    uint4 q;
+                    _Float16* dst = reinterpret_cast<_Float16*>(a.y) + (odd_row ? e - 4 : e);
                     if (a.out_half) {
-                        typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
                         const f32x4v_ v = acc[i][j0 + jj] * hscale;
                         const f16x4_ h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(a.y) + eoff[i][j0 + jj]) = __builtin_bit_cast(uint2, h);
-                    } else if (EP && a.out_planes2) {          // two planes: h0 = rn16(s v), h1 = rn16(2^11 (s v - h0)) -- what pylc_to_planes writes
-                        uint2 p0, p1;
-                        split2(acc[i][j0 + jj], hscale, p0, p1);
-                        _Float16* const dst = reinterpret_cast<_Float16*>(a.y) + eoff[i][j0 + jj];
-                        *reinterpret_cast<uint2*>(dst) = p0;
-                        *reinterpret_cast<uint2*>(dst + a.out_plane_stride) = p1;
+                        const uint2 hu = __builtin_bit_cast(uint2, h);
+                        const u32x2_ sx = __builtin_amdgcn_permlane16_swap(hu.x, hu.x, false, false);      // .y: even rows <- partner's word
+                        const u32x2_ sy = __builtin_amdgcn_permlane16_swap(hu.y, hu.y, false, false);
+                        q = uint4{hu.x, hu.y, sx.y, sy.y};
+                        if (e >= 0 && !odd_row) *reinterpret_cast<uint4*>(dst) = q;
                     } else {
-                        *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
+                        uint2 p0, p1;
+                        split2(acc[i][j0 + jj], hscale, p0, p1);      // h0 = rn16(s v), h1 = rn16(2^11 (s v - h0)): what pylc_to_planes writes
+                        const u32x2_ sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+                        const u32x2_ sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+                        // even rows: (own p0, partner's p0) -> plane 0;  odd rows: (partner's p1, own p1) -> plane 1, at the partner's channels
+                        q = uint4{sx.x, sy.x, sx.y, sy.y};
+                        if (odd_row) dst += a.out_plane_stride;
+                        if (e >= 0) *reinterpret_cast<uint4*>(dst) = q;
                     }
                 }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int i = 0; i < AM; ++i)
+                    if (eoff[i][j0 + jj] >= 0) *reinterpret_cast<f32x4v_*>(a.y + eoff[i][j0 + jj]) = acc[i][j0 + jj];
+        }
     };
     __builtin_amdgcn_sched_barrier(0);
     const f32x4v_ none[AM][PJ] = {};
@@ -262,21 +284,30 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     // residual of the fused inference epilogue arriving as fp16 planes: element = (h0 + 2^-11 h1) / s
     auto fetch_res = [&](int j0) {
         typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
         const _Float16* const rp = reinterpret_cast<const _Float16*>(a.ep_res);
+        const bool odd_row = (lane >> 4) & 1;
 #pragma unroll
         for (int i = 0; i < AM; ++i)
 #pragma unroll
             for (int jj = 0; jj < PJ; ++jj) {
                 const int e = eoff[i][j0 + jj];
                 f32x4v_ v = {0.f, 0.f, 0.f, 0.f};
-                if (e >= 0) {
+                if (a.ep_res_fmt == 2) {
+                    // lanes l / l + 16 (same pixel, adjacent channel quads): the even row fetches 16 bytes of plane 0, the odd row the same 8
+                    // channels of plane 1, and they swap halves (as the stores above, reversed)
+                    uint4 q = {0u, 0u, 0u, 0u};
+                    if (e >= 0) q = *reinterpret_cast<const uint4*>(rp + (odd_row ? e - 4 + a.ep_res_plane_stride : e));
+                    const u32x2_ s0 = __builtin_amdgcn_permlane16_swap(q.x, q.z, false, false);      // even: q.z <- partner's q.x; odd: q.x <- partner's q.z
+                    const u32x2_ s1 = __builtin_amdgcn_permlane16_swap(q.y, q.w, false, false);
+                    // even rows now hold (p0 own: s0.x s1.x | p1 own: s0.y s1.y); odd rows (p0 own: s0.x s1.x | p1 own: s0.y s1.y) as well
+                    const f16x4_ h0 = __builtin_bit_cast(f16x4_, uint2{s0.x, s1.x});
+                    const f16x4_ h1 = __builtin_bit_cast(f16x4_, uint2{s0.y, s1.y});
+                    v = (__builtin_convertvector(h0, f32x4v_) + __builtin_convertvector(h1, f32x4v_) * (1.f / 2048.f)) * res_unscale;
+                    if (e < 0) v = f32x4v_{0.f, 0.f, 0.f, 0.f};
+                } else if (e >= 0) {
                     const f16x4_ h0 = __builtin_bit_cast(f16x4_, *reinterpret_cast<const uint2*>(rp + e));
-                    v = __builtin_convertvector(h0, f32x4v_);
-                    if (a.ep_res_fmt == 2) {
-                        const f16x4_ h1 = __builtin_bit_cast(f16x4_, *reinterpret_cast<const uint2*>(rp + e + a.ep_res_plane_stride));
-                        v += __builtin_convertvector(h1, f32x4v_) * (1.f / 2048.f);
-                    }
-                    v *= res_unscale;
+                    v = __builtin_convertvector(h0, f32x4v_) * res_unscale;
                 }
                 prev[i][jj] = v;
             }
@@ -892,8 +923,8 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
               a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 && a.ow0 == 0 && a.OH == a.P && a.OW == a.Q;
     PYLC_REQUIRE(!(a.out_half || a.out_planes2) ||
                      (a.out_bound != nullptr && a.amax_x && a.amax_w && !a.accumulate && a.add_src == nullptr && a.bn_y == nullptr &&
-                      (a.bias == nullptr || a.ep_scale != nullptr) && a.y_pitch == a.N_store),
-                 "conv with an fp16-plane output: needs out_bound, the operand ranges and a dense y; no accumulation, residual-gradient source or BatchNorm sums "
+                      (a.bias == nullptr || a.ep_scale != nullptr) && a.y_pitch == a.N_store && a.N_store % 8 == 0),
+                 "conv with an fp16-plane output: needs out_bound, the operand ranges and a dense y of a multiple of 8 channels; no accumulation, residual-gradient source or BatchNorm sums "
                  "(a bias only with the fused inference epilogue)");
     PYLC_REQUIRE(a.ep_res == nullptr || a.ep_res_fmt == 0 || (a.ep_res_scale != nullptr && a.y_pitch == a.N_store && a.N_store % 4 == 0),
                  "conv with a fused fp16-plane residual: needs the residual's scale bound and a dense y");

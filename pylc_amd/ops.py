@@ -1051,7 +1051,7 @@ def conv_transpose2x2(x, w, bias=None):
 eval_plane_convs = [0]      # diagnostics: fused inference convs that ran on fp16-plane tensors (conv_bn_act_eval_planes)
 
 
-def conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes):
+def conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes, into=None):
     """conv_bn_act_eval on fp16-PLANE tensors (pylc_conv2d_fwd_bnact_ex): x is (or is converted to) a planes tensor, the residual is read
     as planes or fp32, the result leaves as planes (out_planes: every consumer reads that format) or fp32.  A planes tensor of the
     inference path carries two device scalars -- the bound it was SCALED with (the `_pylc_pl` marker, what a consumer needs to undo the
@@ -1076,11 +1076,18 @@ def conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, res
         x = to_planes(x, x_true)
     else:
         x_true = amax_of(x)                       # the producer's true maximum if it left one, else the scale bound itself
-    d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, cin, cout)
+    yp = cout
+    if into is not None:                  # fp32 result into channels [c0, c0 + Cout) of a caller-owned concat buffer (aspp.py:80, decoder.py:47)
+        buf, c0 = into[0][0], into[1]
+        if tuple(buf.shape[2:]) != (oh, ow) or buf.shape[0] != b or c0 % 4 or c0 + cout > buf.shape[1] or residual is not None:
+            raise L.PylcError('conv_bn_act_eval into=: slice [%d, %d) does not fit the %s buffer' % (c0, c0 + cout, tuple(buf.shape)))
+        y, yp, out_planes = buf[:, c0:c0 + cout], pitch_of(buf), False
+    else:
+        y = empty_nhwc(b, cout, oh, ow, x.device)
+    d = _conv_desc(x, cin, cout, r, s, stride, pad, dil, cin, yp)
     d.x_fmt = 1
     w_amax = weight_amax(w)
     d.x_amax, d.w_amax, d.w_planes = ptr(planes_amax(x)), ptr(w_amax), ptr(planes[0])
-    y = empty_nhwc(b, cout, oh, ow, x.device)
     true_amax = amax_slot(x.device)
     bound = None
     if out_planes:
@@ -1120,8 +1127,9 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
     coef_ranges (int32[2]: float bits of max|scale|, max|shift|) switches the fp16-plane form on where the launch is eligible
     (conv_bn_act_eval_planes); out_planes: the caller states that every consumer of the result reads planes."""
     L.init()
-    if (coef is not None and coef_ranges is not None and into is None and ranges_needed() and _runtime.eval_planes and not _runtime.no_planes):
-        y = conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes)
+    if (coef is not None and coef_ranges is not None and ranges_needed() and _runtime.eval_planes and not _runtime.no_planes
+            and (into is None or is_planes(x))):
+        y = conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, residual, relu, out_planes, into)
         if y is not None:
             return y
     x = as_nhwc(x)
