@@ -1,0 +1,638 @@
+"""torch.autograd bindings of the HIP kernels (host-side plumbing only: shapes, buffers, streams) -- shared part: tensor layout, fp16-plane
+tensors, range tags, streams, timing hooks, gradient links.  The operators live in conv.py / bn.py / dw.py / misc.py; `pylc_amd.ops` re-exports
+all of it.
+
+Tensor convention: every activation is a 4-D tensor of logical shape [B, C, H, W] whose MEMORY is
+NHWC (``channels_last``), possibly a channel slice of a wider buffer (pitch > C).  Conv weights are
+logical [Cout, Cin, kh, kw] with KRSC memory.  Nothing here computes on the CPU or through ATen math
+kernels; if libpylc_hip.so is missing, importing ``pylc_amd.lib`` already failed.
+"""
+import ctypes as C
+
+import os
+import time
+import torch
+import torch.distributed as dist
+
+from .. import lib as L
+from ..lib import lib, check, ptr, stream, ConvDesc, DwDesc
+from ..runtime import runtime as _runtime
+
+
+# ----------------------------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------------------------
+def empty_nhwc(b, c, h, w, device, pitch=None, dtype=torch.float32):
+    pitch = c if pitch is None else pitch
+    t = torch.empty((b, h, w, pitch), device=device, dtype=dtype).permute(0, 3, 1, 2)
+    return t if pitch == c else t[:, :c]
+
+
+def zeros_nhwc(b, c, h, w, device, pitch=None):
+    pitch = c if pitch is None else pitch
+    t = torch.zeros((b, h, w, pitch), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+    return t if pitch == c else t[:, :c]
+
+
+def pitch_of(t):
+    """Channel pitch (floats between pixels) of an NHWC-memory tensor; raises if the layout is anything else."""
+    b, c, h, w = t.shape
+    if w > 1:
+        p = t.stride(3)
+    elif h > 1:
+        p = t.stride(2)
+    elif b > 1:
+        p = t.stride(0)
+    else:
+        p = c
+    ok = (c == 1 or t.stride(1) == 1) and (h == 1 or t.stride(2) == w * p) and (b == 1 or t.stride(0) == h * w * p) and p >= c
+    if not ok:
+        raise L.PylcError('tensor is not NHWC-in-memory: shape %s strides %s' % (tuple(t.shape), t.stride()))
+    return p
+
+
+# ----------------------------------------------------------------------------------------------
+# fp16-plane tensors (include/pylc_hip.h "fp16 planes")
+# ----------------------------------------------------------------------------------------------
+# A planes tensor is carried through autograd as an ordinary float32 tensor of the logical [B, C, H, W] shape (NHWC memory, pitch ==
+# C) whose BYTES hold the two fp16 planes [2][B*H*W][C] -- the same 4 bytes per element, so no second allocation, and autograd sees
+# the dtype and shape it expects.  The marker attribute names the range bound the planes were scaled with.  Only kernels that know
+# the format may touch the bytes: every other op goes through as_nhwc(), which converts back to fp32 (one pass, counted).
+plane_conversions = [0, 0]      # [planes -> fp32 conversion passes, elements]: diagnostics (0 on the hot path)
+planes_marked = [0]             # tensors produced (or re-marked in a backward) in the fp16-plane format: diagnostics
+
+
+def is_planes(t):
+    tag = getattr(t, '_pylc_pl', None)
+    return tag is not None and tag[1] == t._version
+
+
+def planes_amax(t):
+    return t._pylc_pl[0]
+
+
+def nplanes():
+    """2 for the f16x3 arithmetic, 1 for plain fp16 operands (precision mode 3)."""
+    return 1 if lib.pylc_get_conv_precision() == 3 else 2
+
+
+def half_acts():
+    """Precision mode 3 with ONE-PLANE fp16 tensors end to end (2 bytes per element): conv and depthwise outputs y, and the gradients the
+    dgrads hand back, leave their kernels as a single fp16 plane (a planes tensor with nplanes() == 1) wherever the consumer reads that
+    format -- BatchNorm (y, dout), the depthwise kernels (x, dy), the conv kernels (as before)."""
+    return lib.pylc_get_conv_precision() == 3 and _runtime.half_acts
+
+
+def half_dw():
+    """half_acts() and the depthwise kernels take part (runtime.half_dw): a BatchNorm whose output a depthwise conv reads writes one fp16 plane."""
+    return half_acts() and _runtime.half_dw
+
+
+def planes_ok(c, pixels):
+    """Can an activation of `c` channels x `pixels` pixels be kept as fp16 planes (16-byte rows per 8 channels, one plane below 2 GiB)?"""
+    return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)
+
+
+# Below this many input pixels (64 row tiles of 128: a quarter of the chip) a conv is launch-bound and gains nothing from the planes
+# kernels; it keeps fp32 operands and the round-1 kernels.  This also keeps the 96x96 DeepLab golden fixtures on the kernels they
+# were tuned against: their BatchNorms average over as few as 72 pixels and amplify a last-bit change of ONE early conv output
+# into percents of the upstream gradients (tools/mode_sensitivity.py: f16x3 vs bf16x6, both fp32-grade, move the Xception fixture's
+# backbone gradients by 4e-3 elementwise; swapping the first three convs for their bit-compatible planes kernels -- which differ from
+# the small-grid fp32 kernels only in the MFMA shape -- by 2e-2).  The planes kernels themselves are pinned bit for bit against the
+# fp32-operand kernels in tests/test_planes_gpu.py, and the full-size network tests run them.
+PLANES_MIN_PIXELS = int(os.environ.get('PYLC_PLANES_MIN_PIXELS', '8192'))
+
+
+def conv_takes_planes(w, pixels_in, pixels_out):
+    """Will conv2d() run this filter on the fp16-plane kernels (conv_pl.hip / wgrad_pl.hip)?  Needs the prepared filter planes (flat
+    arena) and channel counts the 16-byte plane rows allow.  Narrow convs (<= 64 output channels) take them too: on a 128-wide tile
+    half the MFMAs multiply zeros, but those layers are bound by bytes and by the per-tile prologue / epilogue, which two blocks per
+    CU overlap (measured: the 256x128 one-block kernel ran the K = 48 / 64 dgrads of layer1 and the decoder at 6-90 TFLOP/s)."""
+    cout, cin, r, s_ = w.shape
+    only = os.environ.get('PYLC_PLANES_ONLY')          # debug: "cin:cout:k,cin:cout:k,..." with * wildcards -- planes for these filters only
+    if only and not any(all(p == '*' or int(p) == v for p, v in zip(pat.split(':'), (cin, cout, r))) for pat in only.split(',')):
+        return False
+    return (lib.pylc_get_conv_precision() >= 2 and getattr(w, '_pylc_planes', None) is not None and cin % 8 == 0 and cout % 4 == 0
+            and pixels_in >= PLANES_MIN_PIXELS and planes_ok(cin, pixels_in) and not _runtime.no_planes)
+
+
+mark_hook = None           # diagnostics: callable(tensor, bound) invoked for every tensor that is marked as planes (tests count / list them)
+
+
+def mark_planes(t, amax):
+    if mark_hook is not None:
+        mark_hook(t, amax)
+    planes_marked[0] += 1
+    t._pylc_pl = (amax, t._version)
+    tag_amax(t, amax)
+    return t
+
+
+def to_planes(x, amax=None):
+    """fp32 NHWC tensor -> planes tensor (one pass); `amax`: device int32[1] range bound (default: the tensor's own range)."""
+    L.init()
+    x = as_nhwc(x)
+    b, c, h, w = x.shape
+    if not planes_ok(c, b * h * w):
+        raise L.PylcError('to_planes: %d channels x %d pixels cannot be held as fp16 planes' % (c, b * h * w))
+    if amax is None:
+        amax = amax_of(x)
+    out = empty_nhwc(b, c, h, w, x.device)
+    m = b * h * w
+    check(lib.pylc_to_planes(ptr(x), pitch_of(x), ptr(out), c, m * c, m, c, ptr(amax), nplanes(), stream()))
+    return mark_planes(out, amax)
+
+
+def from_planes(t):
+    """planes tensor -> fp32 NHWC tensor (one pass)."""
+    L.init()
+    b, c, h, w = t.shape
+    m = b * h * w
+    out = empty_nhwc(b, c, h, w, t.device)
+    check(lib.pylc_from_planes(ptr(t), c, m * c, ptr(out), c, m, c, ptr(planes_amax(t)), nplanes(), stream()))
+    plane_conversions[0] += 1
+    plane_conversions[1] += t.numel()
+    tag_amax(out, planes_amax(t))
+    return out
+
+
+class FromPlanesFn(torch.autograd.Function):
+    """planes -> fp32 inside a training graph (the gradient passes through unchanged: the producer's backward takes fp32)."""
+
+    @staticmethod
+    def forward(ctx, t, amax):
+        if not is_planes(t):          # (should autograd hand the function a fresh alias of the tensor: restore the marker)
+            t._pylc_pl = (amax, t._version)
+        return from_planes(t)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def export_activation(t):
+    """What a module hands to a caller that does not know the fp16-plane format (a public module boundary: ResNet101.forward
+    without keep_planes): a planes tensor is a float32-TYPED tensor whose bytes are fp16 planes, so any foreign op -- a torch
+    function, a forward hook, feature extraction -- would compute on reinterpreted bytes without an error.  Converts (one pass,
+    differentiable); fp32 tensors pass through."""
+    if not is_planes(t):
+        return t
+    if torch.is_grad_enabled() and t.requires_grad:
+        return FromPlanesFn.apply(t, planes_amax(t))
+    return from_planes(t)
+
+
+def as_nhwc(t):
+    """Return `t` as an fp32 tensor with NHWC memory (copying through torch only if an upstream op handed us another layout;
+    converting if it is an fp16-plane tensor)."""
+    if is_planes(t):
+        return from_planes(t)
+    defer = getattr(t, '_pylc_defer', None)
+    if defer is not None and defer[4] == t._version:
+        # a BatchNorm output whose apply pass was left to its (depthwise) consumer: anything else that reads it gets the applied values
+        # (gradients do not flow through this copy -- the tensor has ONE designated consumer; this serves hooks and debugging)
+        from .bn import materialize_deferred          # (bn.py imports this module)
+        return from_planes(materialize_deferred(t))
+    if t.dtype != torch.float32:
+        t = t.float()
+    try:
+        pitch_of(t)
+        return t
+    except L.PylcError:
+        out = empty_nhwc(*t.shape, device=t.device)
+        out.copy_(t)
+        return out
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, device=device, dtype=torch.float32)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _r4(c):
+    return (c + 3) & ~3
+
+
+# ----------------------------------------------------------------------------------------------
+# live kernel timing (bench.py's roofline leg)
+# ----------------------------------------------------------------------------------------------
+class KernelTimer:
+    """HIP-event timing of the dominant kernel's launches on the stream they are launched on.
+
+    Only launches that dispatch to the 256x128-tile kernel (pylc_amd/csrc/conv_igemm.hip dispatch_gg_p: gather_gemm_pp_kernel
+    for the f16x3 arithmetic, gather_gemm_kernel<256,128,64,64,false,1> for bf16x6; stored Cout > 64, not the thin-input
+    mode, >= 192 tiles of 256x128, reduction channels % 8 == 0) are bracketed; FLOPs are algorithmic fp32 FLOPs (2*M*N*K, every tap counted).  The kernel executes 3 (f16x3) or
+    6 (bf16x6) 16-bit MFMA FLOPs per algorithmic FLOP, so its roofline is the dense 16-bit MFMA peak / 3 (or / 6)."""
+
+    TERMS = {1: 6, 2: 3, 3: 1}
+
+    def __init__(self, inference=False):
+        self.records = []          # (start_event, end_event, flops, launches, kind)
+        self.alg_bytes = 0.0       # algorithmic operand bytes (input + weights + output, each touched once)
+        self.mode = lib.pylc_get_conv_precision()
+        self.planes = self.mode >= 2 and not _runtime.no_planes
+        self.inference = bool(inference)      # eval-mode nets: the fused conv + BatchNorm(+ residual + ReLU) launches (conv_bn_act_eval) are bracketed
+        # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
+        # activations travel as planes; '*' = both tile heights (rocprof lists them as two rows) and the 3x3 halo variant: one kernel
+        # family (conv_pl.hip), the same loop body, dispatched by shape
+        self.KERNEL = (('gg_pl_kernel<%d,*,EP> + gg_plh_kernel<%d,EP> (pylc_conv2d_fwd_bnact_ex: plane tensors, conv + eval BatchNorm + residual + ReLU '
+                        'in the epilogue)' % (((3 if self.mode == 2 else 1),) * 2) if (_runtime.eval_planes and self.planes) else
+                        'gather_gemm_pp_kernel<..., %s> (pylc_conv2d_fwd_bnact: conv + eval BatchNorm + residual + ReLU in the epilogue)'
+                        % ('ONE-plane fp16' if self.mode == 3 else 'f16x3')) if self.inference else
+                       'gg_pl_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 2) if self.planes else
+                       'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
+                       'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
+
+    def bracket(self, flops, launches, kind, nbytes=0.0):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((a, b, flops, launches, kind))
+        self.alg_bytes += nbytes
+        return a, b
+
+    def roofline(self, peak_16bit_tflops=2500.0):
+        torch.cuda.synchronize()
+        tot_ms = sum(a.elapsed_time(b) for a, b, _, _, _ in self.records)
+        flops = sum(r[2] for r in self.records)
+        launches = sum(r[3] for r in self.records)
+        by = {}
+        for a, b, f, n, kind in self.records:
+            e = by.setdefault(kind, [0.0, 0.0, 0])
+            e[0] += a.elapsed_time(b); e[1] += f; e[2] += n
+        ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        terms = self.TERMS.get(self.mode, 6)
+        peak = peak_16bit_tflops / terms
+        arith = ('3-term scaled fp16 split ("f16x3": a0b0 + 2^-11 (a1b0 + a0b1), cross terms in their own fp32 accumulator) '
+                 'on v_mfma_f32_16x16x32_f16' if self.mode == 2 else
+                 'plain fp16 operands (scaled per tensor), fp32 accumulation, on v_mfma_f32_16x16x32_f16' if self.mode == 3 else
+                 '6-term bf16 split ("bf16x6") on v_mfma_f32_32x32x16_bf16')
+        return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'kernel': self.KERNEL, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1),
+                'kernel_time_ms_total': tot_ms, 'algorithmic_bytes_per_launch': self.alg_bytes / max(launches, 1),
+                'note': ('achieved = algorithmic FLOP/s; arithmetic = %s: 16-bit operand accuracy (2^-11 per operand, fp32 accumulation), NOT '
+                         'fp32-grade -- judged by the statistical parity bar (losses, argmax agreement, mIoU); peak = dense 16-bit MFMA peak '
+                         '(2500 TFLOP/s)' % arith) if self.mode == 3 else
+                        ('achieved = algorithmic fp32 FLOP/s; arithmetic = %s with fp32-grade accuracy (measured error vs fp64 '
+                         'no larger than the fp32 FMA chain\'s), so peak = dense 16-bit MFMA peak (2500 TFLOP/s) / %d; executed '
+                         'MFMA rate = %d x achieved; the exact-fp32 matrix pipe peaks at 157.3 TFLOP/s' % (arith, terms, terms)),
+                'mfma_executed_tflops': terms * ach,
+                'by_kind': {k: {'ms': v[0], 'tflops': v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0, 'launches': v[2]}
+                            for k, v in by.items()}}
+
+
+_timer = None
+bn_timing = None       # diagnostics (tools/bn_table.py): a list that receives (kind, M, C, bytes, start_event, end_event) per BatchNorm pass
+
+
+def _bn_time(kind, m, c, nbytes):
+    """Context manager bracketing one BatchNorm pass with HIP events when tools/bn_table.py has switched the table on."""
+    if bn_timing is None:
+        return _nullcontext()
+    return _BnTimed(kind, m, c, nbytes)
+
+
+class _BnTimed:
+    def __init__(self, kind, m, c, nbytes):
+        self.rec = [kind, m, c, nbytes, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        self.rec[4].record()
+
+    def __exit__(self, *a):
+        self.rec[5].record()
+        bn_timing.append(tuple(self.rec))
+        return False
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
+def _is_dominant_tile(m, n_store, cin, taps):
+    """Mirror of dispatch_gg_p in conv_igemm.hip: does this launch run the 256x128 8-wave split-arithmetic kernel?"""
+    if lib.pylc_get_conv_precision() == 0 or n_store <= 64 or (cin == 4 and taps > 1):
+        return False
+    if lib.pylc_get_conv_precision() == 2 and cin % 8:
+        return False
+    return ((m + 255) // 256) * ((n_store + 127) // 128) >= 192
+
+
+# ----------------------------------------------------------------------------------------------
+# dense convolution
+# ----------------------------------------------------------------------------------------------
+def _conv_desc(x, cin, cout, r, s, stride, pad, dil, x_pitch, y_pitch):
+    b, _, h, w = x.shape
+    d = ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.R, d.S = b, h, w, cin, cout, r, s
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.OH, d.OW = conv_out_size(h, r, stride, pad, dil), conv_out_size(w, s, stride, pad, dil)
+    d.x_pitch, d.y_pitch = x_pitch, y_pitch
+    return d
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_side_streams = {}
+
+
+def _runs_concurrently(cand, device):
+    """True if work on `cand` executes while the current stream is busy, i.e. the two HIP streams sit on different
+    hardware queues.  HIP multiplexes streams onto a few hardware queues in creation order, so a fresh stream can land on
+    the compute stream's queue -- observed once RCCL had created its streams -- and would then serialise behind it."""
+    with torch.cuda.stream(cand):                      # first use of a stream can take milliseconds (queue creation):
+        torch.zeros(1, device=device)                  # keep that out of the timed part
+    cand.synchronize()
+    try:
+        torch.cuda._sleep(40_000_000)                  # tens of ms of busy-wait on the current stream
+    except (AttributeError, RuntimeError):
+        return True                                    # cannot probe: take the stream as it is
+    with torch.cuda.stream(cand):
+        torch.zeros(1, device=device)
+        ev = torch.cuda.Event()
+        ev.record()
+    ok = False
+    t0 = time.perf_counter()
+    while not ok and time.perf_counter() - t0 < 0.010:
+        time.sleep(0.001)
+        ok = ev.query()
+    torch.cuda.synchronize(device)
+    if os.environ.get('PYLC_DEBUG_STREAMS'):
+        print('[pylc] side-stream candidate %s: %s' % (cand, 'concurrent' if ok else 'serialised behind the compute stream'), flush=True)
+    return ok
+
+
+_deferred_wgrad = {}     # device index -> [[conv backwards still to pass, closure that launches the held-back wgrad], ...] in launch order
+
+
+def _defer_wgrad(device, fn, hold=1):
+    """Hold a wgrad launch back until `hold` more conv backwards have STARTED on this device (each conv backward calls
+    flush_deferred_wgrad first), or until sync_side_streams().  hold = 1: the wgrad starts beside the next conv's dgrad."""
+    _deferred_wgrad.setdefault(torch.device(device).index, []).append([int(hold), fn])
+
+
+def flush_deferred_wgrad(device, everything=False):
+    held = _deferred_wgrad.get(torch.device(device).index)
+    if not held:
+        return
+    keep = []
+    for item in held:
+        item[0] -= 1
+        if everything or item[0] <= 0:
+            item[1]()
+        else:
+            keep.append(item)
+    held[:] = keep
+
+
+def cu_masked_stream(device, n_cus, from_top=False):
+    """A HIP stream whose kernels only occupy `n_cus` of the 256 compute units (pylc_stream_create_cu_mask), as a torch stream object.
+    The HIP stream lives as long as the process (side streams are created once per device)."""
+    L.init()
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        check(lib.pylc_stream_create_cu_mask(int(n_cus), int(bool(from_top)), C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side_streams:
+        cands = []
+        for _ in range(8):
+            # runtime.wgrad_cus (PYLC_WGRAD_CUS): confine the wgrad stream to that many compute units, so that the HBM-bound passes of
+            # the main stream keep the rest to themselves
+            st = cu_masked_stream(device, _runtime.wgrad_cus) if _runtime.wgrad_cus else torch.cuda.Stream(device=device)
+            cands.append(st)                          # keep the rejected ones alive so the next candidate is a new stream
+            if _runs_concurrently(st, device):
+                break
+        _side_streams[key] = cands[-1]
+    return _side_streams[key]
+
+
+def side_stream_if_any(device):
+    """The wgrad side stream of `device` if one has been created (None on CPU / before the first backward)."""
+    if not torch.device(device).type == 'cuda':
+        return None
+    return _side_streams.get(torch.device(device).index)
+
+
+_side_keep = {}      # device index -> tensors of the main stream that kernels queued on the side stream still read
+
+
+def _keep_for_side(device, *tensors):
+    """Keep main-stream tensors alive while side-stream kernels read them; sync_side_streams() lets go of them once the main
+    stream has been told to wait for the side stream, so their blocks return to the allocator in stream order.
+    (Tensor.record_stream would do, but it makes the blocks reusable only when the side stream's events have COMPLETED: with
+    the host a step ahead of the GPU nothing of the previous step is reusable yet and every step calls hipMalloc for its conv
+    inputs and gradients again -- measured: 281 hipMalloc calls inside bench.py's 10 timed steps, 74-95 GB reserved for models
+    that peak at 15-43 GB.)"""
+    keep = _side_keep.setdefault(torch.device(device).index, [])
+    keep.extend(t for t in tensors if t is not None)
+    if len(keep) > 8192:                 # a caller that never synchronises: do it for them rather than grow without bound
+        sync_side_streams()
+
+
+def sync_side_streams():
+    """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
+    all-reduce reads the arena), then release the tensors kept alive for it."""
+    for idx in list(_deferred_wgrad):
+        flush_deferred_wgrad(torch.device('cuda', idx), everything=True)
+    for st in _side_streams.values():
+        torch.cuda.current_stream().wait_stream(st)
+    for keep in _side_keep.values():
+        keep.clear()
+
+
+def _grad_target(param):
+    """Arena-backed gradient view for `param` if the optimiser registered one, else None."""
+    return getattr(param, '_pylc_grad', None)
+
+
+def _deliver_grad(param, g):
+    """Hand a parameter gradient back.  With an arena view registered the kernel already wrote into it:
+    publish it as .grad and tell autograd there is nothing to accumulate."""
+    if _grad_target(param) is not None:
+        if param.grad is None or param.grad.data_ptr() != g.data_ptr():
+            param.grad = g
+        arena = getattr(param, '_pylc_arena', None)
+        if arena is not None:
+            a = arena()
+            if a is not None:
+                a.mark_delivered(param)
+        if _runtime.grad_ready is not None:
+            _runtime.grad_ready(param)        # data-parallel: may trigger this bucket's asynchronous all-reduce
+        return None
+    return g
+
+
+amax_passes = [0, 0]      # [stand-alone range passes, elements read]: diagnostics for the producer-side fusion
+
+_amax_pools = {}          # device index -> [zeroed int32 pool, next free slot]
+
+
+def amax_slot(device):
+    """A zero-initialised device scalar for a kernel that max-accumulates a tensor's range into it (pylc_bn_apply,
+    pylc_bn_bwd_apply).  Slots are views of a pool that is zeroed once per 4096 slots instead of one memset per use."""
+    key = torch.device(device).index
+    pool = _amax_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]      # the old pool lives on while tags reference it
+        _amax_pools[key] = pool
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
+def ranges_needed():
+    """True when the conv kernels run the f16x3 arithmetic (precision mode 2), which scales every operand by a power of
+    two taken from its max magnitude."""
+    return lib.pylc_get_conv_precision() >= 2
+
+
+def tag_amax(t, amax):
+    """Attach a device scalar holding (the float bits of) an upper bound of max|t| to `t`; trusted only while the
+    tensor's version counter is unchanged (in-place autograd accumulation bumps it)."""
+    t._pylc_amax = (amax, t._version)
+
+
+def inherit_amax(out, src, binades=0):
+    """Tag `out` with an upper bound of its range derived from the tag of the tensor it was computed from, instead of a read
+    pass over `out`: max-pooling and (align_corners) bilinear interpolation never exceed max|src|; dropout scales by
+    1 / (1 - p) <= 2^binades.  The conv kernels only need an upper bound within a few binades."""
+    tag = getattr(src, '_pylc_amax', None)
+    if tag is None or tag[1] != src._version:
+        return out
+    a = tag[0]
+    if binades:
+        a = a + (binades << 23)            # float bits of 2^binades * amax (one-element int32 tensor)
+    tag_amax(out, a)
+    return out
+
+
+def cat_channels(parts):
+    """torch.cat along the channels (plumbing) that carries the parts' ranges along: max|cat| = max of the parts' maxima
+    (non-negative float bit patterns order like integers)."""
+    out = torch.cat(parts, 1)
+    if ranges_needed():
+        tags = [getattr(t, '_pylc_amax', None) for t in parts]
+        if all(tg is not None and tg[1] == t._version for tg, t in zip(tags, parts)):
+            a = tags[0][0]
+            for tg in tags[1:]:
+                a = torch.maximum(a, tg[0])
+            tag_amax(out, a)
+    return out
+
+
+def amax_of(t):
+    """Device int32[1] with the float bits of max|t| for an NHWC activation / gradient: the producer's tag when one is
+    attached and still valid, else one read pass over the tensor."""
+    tag = getattr(t, '_pylc_amax', None)
+    if tag is not None and tag[1] == t._version:
+        return tag[0]
+    t = as_nhwc(t)
+    b, c, h, w = t.shape
+    out = torch.empty(1, dtype=torch.int32, device=t.device)
+    check(lib.pylc_amax(ptr(t), b * h * w, c, pitch_of(t), ptr(out), stream()))
+    amax_passes[0] += 1
+    amax_passes[1] += t.numel()
+    tag_amax(t, out)
+    return out
+
+
+def bound_conv_output(y, x, w, bias=None):
+    """Tags the output y of a conv (no BatchNorm behind it) with the range BOUND Cin R S max|w| max|x| + max|bias| (pylc_range_product) when
+    x's range is known without a pass (fp16 planes or a valid tag) and the filter's is in the arena table: the U-Net's 1x1 up convs, whose
+    output only the interpolation + concat kernel reads.  The bound is loose by ~log2(sqrt(Cin)) + 3 binades, well inside the 2^29 the split
+    arithmetic tolerates (include/pylc_hip.h, precision mode 2).  Returns y."""
+    if not (ranges_needed() and _runtime.fused_grad_ranges) or is_planes(y):
+        return y
+    if is_planes(x):
+        xa = planes_amax(x)
+    else:
+        tag = getattr(x, '_pylc_amax', None)
+        if tag is None or tag[1] != x._version:
+            return y
+        xa = tag[0]
+    wa, ba = getattr(w, '_pylc_wamax', None), (getattr(bias, '_pylc_wamax', None) if bias is not None else None)
+    if wa is None or (bias is not None and ba is None):
+        return y
+    bound = torch.empty(1, dtype=torch.int32, device=y.device)
+    check(lib.pylc_range_product(ptr(xa), ptr(wa), float(w.shape[1] * w.shape[2] * w.shape[3]), ptr(ba), ptr(bound), stream()))
+    tag_amax(y, bound)
+    return y
+
+
+def weight_amax(w):
+    """Range of a conv filter: the flat arena's per-parameter table when the parameter lives in one (refreshed by
+    FlatArena.refresh_ranges), else computed here."""
+    tab = getattr(w, '_pylc_wamax', None)
+    if tab is not None:
+        return tab
+    out = torch.empty(1, dtype=torch.int32, device=w.device)
+    check(lib.pylc_amax(ptr(w), 1, w.numel(), w.numel(), ptr(out), stream()))
+    return out
+
+
+class ResidualLink:
+    """Couples the backward nodes that each produce a part of ONE tensor's gradient, so that the parts are summed by the
+    kernels that compute them instead of by autograd (an add is a 12 B/element pass):
+      * identity-residual block: BatchNorm(+residual x) parks its residual gradient here, the block's first conv (input x)
+        accumulates its dgrad into that buffer in the epilogue (`accumulate`);
+      * a tensor read by several convs (projection blocks: conv1 + downsample; the low-level features: layer2 + decoder;
+        the ASPP branches): the first dgrad to run writes a fresh buffer, the others accumulate into it.
+    Every conv armed in the forward counts in `pending`; the backward that brings it to zero returns the buffer as the whole
+    gradient of x, the earlier ones return None (autograd adds whatever other consumers of x deliver).  All consumers must
+    take part in the backward pass -- true for the networks of this package, where every branch reaches the loss."""
+    __slots__ = ('pending', 'buf', 'pool_armed', 'crop', 'masked')
+
+    def __init__(self):
+        self.pending = 0
+        self.buf = None
+        self.pool_armed = False     # U-Net skips: a max-pool reads x and will add the parked crop gradient in its backward
+        self.crop = None            # (dy of the concat buffer, channel offset, h0, w0) parked by CropConcatFn.backward
+        self.masked = None          # (dout, 1-bit ReLU mask) parked by BnActFn.backward INSTEAD of a written-out residual gradient: the
+                                    # conv dgrad that consumes the link forms relu'(dout) in its own epilogue (pylc_conv2d_dgrad_add)
+
+    @property
+    def armed(self):
+        return self.pending > 0
+
+
+def _link_sink(link):
+    """The buffer a backward node accumulates its part of x's gradient into (None: nothing parked yet).  A parked (dout, mask) pair is
+    written out first (one pass) -- the path of consumers that cannot form it in their own epilogue."""
+    if link is None:
+        return None
+    if link.masked is not None:
+        dout, mask = link.masked
+        link.masked = None
+        b, c, h, w = dout.shape
+        g = empty_nhwc(b, c, h, w, dout.device)
+        check(lib.pylc_relu_bwd_bits(ptr(dout), ptr(mask), ptr(g), b * h * w, c, stream()))
+        if link.buf is not None:
+            raise L.PylcError('gradient link holds both a buffer and a masked residual gradient')
+        link.buf = g
+    return link.buf
+
+
+def grad_link(x):
+    """The link shared by all consumers of tensor x (kept on the tensor object); None when x needs no gradient."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    link = getattr(x, '_pylc_link', None)
+    if link is None:
+        link = ResidualLink()
+        x._pylc_link = link
+    return link
+
+
+__all__ = [n for n in dir() if not n.startswith('__')]      # everything, underscore helpers included: the package re-exports it (pylc_amd/ops/__init__.py)

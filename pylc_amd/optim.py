@@ -20,7 +20,7 @@ def _dense_numel(p):
 class FlatArena:
     """Re-homes the parameters of `module` into one buffer (keeping every tensor's shape and strides, e.g. the
     KRSC memory of conv weights) and gives each a same-layout gradient view registered as `p._pylc_grad`,
-    which the backward kernels write directly (pylc_amd/ops.py:_deliver_grad)."""
+    which the backward kernels write directly (pylc_amd/ops/_core.py:_deliver_grad)."""
 
     ALIGN = 4       # floats (16 B): every tensor starts on a vector boundary
 

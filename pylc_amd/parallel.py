@@ -3,7 +3,7 @@
 The reference has no working multi-GPU path (nn.DataParallel is commented out at models/model.py:186-188 and
 the vendored models/sync_batchnorm is never constructed), so the contract here is "N ranks == one process at the
 global batch" (SURVEY.md section 8e):
-  * BatchNorm statistics and their backward sums are all-reduced per layer (pylc_amd/ops.py BnActFn) -- the
+  * BatchNorm statistics and their backward sums are all-reduced per layer (pylc_amd/ops/bn.py BnActFn) -- the
     RCCL form of batchnorm.py:48-125's master/slave reduce+broadcast;
   * the loss head all-reduces its 3+3C partial sums before the non-linear Dice / weighted-CE finalisation;
   * gradients are SUMMED over ranks (the loss is already the global mean) in a few large buckets of the flat
@@ -63,7 +63,7 @@ class GradBucketer:
 
     The flat gradient arena is cut into buckets of whole parameters (>= BUCKET_FLOATS each, in arena = module order).
     Backward produces gradients in reverse module order (decoder -> ASPP -> layer4 -> ... -> stem), so buckets complete
-    from the END of the arena; the moment the last gradient of a bucket has been written (pylc_amd/ops.py calls
+    from the END of the arena; the moment the last gradient of a bucket has been written (pylc_amd/ops/conv.py calls
     `ready(param)` right after launching the kernel that writes it) its SUM all-reduce is enqueued asynchronously (same
     communicator as the SyncBN messages unless PYLC_SEPARATE_GRAD_COMM=1, see init_from_env).  torch's NCCL work objects
     order each collective after the kernels already enqueued on the compute stream."""

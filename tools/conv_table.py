@@ -24,7 +24,8 @@ class Shim:
         if n in ('pylc_conv2d_fwd', 'pylc_conv2d_fwd_stats', 'pylc_conv2d_dgrad', 'pylc_conv2d_dgrad_add', 'pylc_conv2d_wgrad'):
             return wrap(n)
         return getattr(L.lib, n)
-ops.lib = Shim()
+for _m in (ops._core, ops.conv, ops.bn, ops.dw, ops.misc):
+    _m.lib = Shim()
 from pylc_amd.runtime import runtime
 runtime.wgrad_side_stream = not os.environ.get('PYLC_SERIAL')      # PYLC_SERIAL=1: wgrad on the main stream (un-overlapped kernel times)
 dev = torch.device('cuda:0')
