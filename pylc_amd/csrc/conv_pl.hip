@@ -42,8 +42,16 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 
 constexpr int PL_BN = 128;
 constexpr int PL_ROW = 64;                                  // bytes per LDS row per plane
+// gg_pl_kernel's LDS row: 64 bytes (a 32-deep K-step) for the two-plane f16x3 operands; 128 bytes (a 64-deep K-step, the same stage
+// size) for the one-plane operands of precision mode 3.  Why: a 64-byte piece is HALF of a 128-byte cache line, and the other half -- the
+// next K-step's chunk -- is requested again one step later, after the 32 KB L1 has turned over; tools/micro/dma_piece.hip measures the
+// L2 -> LDS rate of LDS-DMA at 21.8 TB/s for 16 rows x 64 B per instruction against 33.0 TB/s for 8 rows x 128 B
+// (profiles/r04_dma_piece.txt).  The one-plane loop is bound by exactly that rate (16 KB per 16 MFMAs per wave); the f16x3 loop has
+// no LDS left for 128-byte rows (two blocks x two stages x 64 KB).
+template <int NTERMS>
+constexpr int pl_row_bytes() { return NTERMS == 1 ? 128 : PL_ROW; }
 template <int NTERMS, int BM>
-constexpr int pl_stage_bytes() { return (NTERMS == 3 ? 2 : 1) * (BM + PL_BN) * PL_ROW; }
+constexpr int pl_stage_bytes() { return (NTERMS == 3 ? 2 : 1) * (BM + PL_BN) * pl_row_bytes<NTERMS>(); }
 template <int BM>
 constexpr int pl_stages() { return BM == 256 ? 3 : 2; }
 template <int NTERMS, int BM>
@@ -381,12 +389,15 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
 // EP: the fused inference epilogue (eval BatchNorm + residual + ReLU, plane outputs; pl_epilogue<.., EP>) is compiled in only here
 template <int NTERMS, int BM, bool STAMPS = false, bool BNB = false, bool NARROW = false, bool EP = false>
 __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a) {
-    constexpr int BN = PL_BN, AM = NARROW ? 2 : 4, WM = 16 * AM, WN = 64, AT = 4, ROW = PL_ROW;
+    constexpr int BN = PL_BN, AM = NARROW ? 2 : 4, WM = 16 * AM, WN = 64, AT = 4, ROW = pl_row_bytes<NTERMS>();
+    constexpr int KS = ROW / 2;                             // reduction depth of one LDS stage: 32, or 64 (two 32-deep MFMA sub-steps)
+    constexpr int RPI = 1024 / ROW;                         // rows per DMA instruction (1 KB, lane-linear): 16 or 8
     constexpr int NW = BM / 32;                             // waves: 4 (2 M x 2 N) or 8 (4 M x 2 N)
     constexpr int NST = pl_stages<BM>();
-    constexpr int BI = BN / (16 * NW);                      // filter rows per thread (16-row DMA pieces per wave): 2 or 1
+    constexpr int AI = 32 / RPI;                            // pixel-row pieces per wave (32 rows): 2 or 4
+    constexpr int BI = BN / (RPI * NW);                     // filter-row pieces per wave: 2 or 1 (64-byte rows), 4 or 2 (128-byte rows)
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
-    constexpr int NDMA = (2 + BI) * NPL;                    // DMA instructions per wave and K-step
+    constexpr int NDMA = (AI + BI) * NPL;                   // DMA instructions per wave and K-step
     constexpr int STAGE = pl_stage_bytes<NTERMS, BM>();
     constexpr int OFF_B = NPL * BM * ROW;
     constexpr unsigned OOB = 0x80000000u;                   // >= num_records of every descriptor (takes_pl: buffers below 2 GiB)
@@ -428,8 +439,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             }
         }
     }
-    const int lrow = lane >> 2;                                         // loader: 4 lanes per 64-byte row, 16 rows per DMA instruction
-    const int lc = (lane & 3) ^ (((lane >> 4) & 1) << 1);               // logical chunk this lane fetches for its LDS position
+    // loader: LPR lanes per LDS row, RPI rows per DMA instruction; `lc` = the logical 16-byte chunk this lane fetches for its (swizzled)
+    // LDS position.  64-byte rows: chunk ^ (((row >> 2) & 1) << 1).  128-byte rows: the low two chunk bits ^ ((row >> 1) & 3) -- eight
+    // consecutive rows of one chunk column then cover eight different 16-byte bank groups of a 256-byte bank sweep (conflict-free
+    // ds_read_b128 fragments), and the XOR stays inside a 64-byte half, i.e. inside one 32-deep sub-step.
+    const int lrow = ROW == 64 ? lane >> 2 : lane >> 3;
+    const int lc = ROW == 64 ? (lane & 3) ^ (((lane >> 4) & 1) << 1) : ((lane & 4) | ((lane & 3) ^ ((lane >> 4) & 3)));
     const bool ident = a.ident != 0;
     const bool stamper = STAMPS && (int)blockIdx.x == (a.dbg_flags >> 16) && lane == 0 && (wave == 0 || wave == NW - 1);
     PL_STAMP();
@@ -445,17 +460,17 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     unsigned woff_row[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int n = n0 + 16 * BI * wave + 16 * i + lrow;
+        const int n = n0 + RPI * BI * wave + RPI * i + lrow;
         woff_row[i] = n < a.N ? ((unsigned)n * (unsigned)a.w_row_stride + 8u * lc) * 2u : OOB;
     }
     const unsigned plane1_w = (unsigned)(a.w_plane_stride * 2);
 
     // ---- pixel rows of this thread ----
-    int rowh[2], roww[2];
-    unsigned xoff[2];
+    int rowh[AI], roww[AI];
+    unsigned xoff[AI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + 32 * wave + 16 * i + lrow;
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + 32 * wave + RPI * i + lrow;
         const bool ok = m < a.M;
         if (ident) {                       // 1x1, stride 1, no padding: input pixel == output pixel, no decode
             rowh[i] = ok ? 0 : -(1 << 28);
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     }
 
     const int T = a.TR * a.TS;
-    const int nchunks = (a.Cin + BK - 1) / BK;
+    const int nchunks = (a.Cin + KS - 1) / KS;
     // taps that reach at least one valid input pixel of this tile (the others are skipped): one ballot per tap, one barrier
     unsigned long long tapmask = ~0ull;
     if (T > 1) {
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             const int dh = a.dh0 + (t / a.TS) * a.dh_step, dw = a.dw0 + (t % a.TS) * a.dw_step;
             int any = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < AI; ++i)
                 any |= ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);
             if (__builtin_amdgcn_ballot_w64(any != 0) != 0) mine |= 1ull << t;
         }
@@ -544,58 +559,61 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     // LDS-DMA of the next reduction tile into `stage`: per thread 2 pixel rows + 2 filter rows, NPL planes each.
     // Masked lanes (padding tap, row past M, channels past Cin, filter row past N) get an out-of-range offset: the hardware
     // writes zeros for them.
-    char* const dstA = lds + (32 * wave) * ROW;              // + stage * STAGE + plane * BM * ROW + 16 i * ROW
-    char* const dstB = lds + OFF_B + (16 * BI * wave) * ROW;
+    char* const dstA = lds + (32 * wave) * ROW;              // + stage * STAGE + plane * BM * ROW + RPI i * ROW
+    char* const dstB = lds + OFF_B + (RPI * BI * wave) * ROW;
     auto issue = [&](int stage) {
         advance();
         const int dh = a.dh0 + ld_tr * a.dh_step, dw = a.dw0 + ld_ts * a.dw_step;
         const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
-        const bool cok = ld_chunk * BK + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
-        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * BK) * 2);      // wave-uniform, may be "negative"
-        const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2);
+        const bool cok = ld_chunk * KS + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2);      // wave-uniform, may be "negative"
+        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2);
         char* const sa = dstA + stage * STAGE;
         char* const sb = dstB + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AI; ++i) {
             const bool ok = cok & ((unsigned)(rowh[i] + dh) < (unsigned)a.IH) & ((unsigned)(roww[i] + dw) < (unsigned)a.IW);      // no short-circuit: branch-free
             const unsigned vo = ok ? xoff[i] + tapdelta : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)(sa + 16 * i * ROW), 16, vo, 0, 0, 0);
-            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(sa + BM * ROW + 16 * i * ROW), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)(sa + RPI * i * ROW), 16, vo, 0, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(sa + BM * ROW + RPI * i * ROW), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const unsigned vo = cok ? woff_row[i] : OOB;
             const unsigned vo1 = cok ? woff_row[i] + plane1_w : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + 16 * i * ROW), 16, vo, so, 0, 0);
-            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + BN * ROW + 16 * i * ROW), 16, vo1, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + RPI * i * ROW), 16, vo, so, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + BN * ROW + RPI * i * ROW), 16, vo1, so, 0, 0);
         }
     };
-    // fragment reads: lane l = row (l & 15) of a 16-row fragment, reduction elements 8 (l >> 4) .. +7 of the 32-deep step
-    const int koff = 16 * ((lane >> 4) ^ (((lane >> 2) & 1) << 1));
+    // fragment reads: lane l = row (l & 15) of a 16-row fragment, reduction elements 8 (l >> 4) .. +7 of a 32-deep (sub-)step
+    const int koff = ROW == 64 ? 16 * ((lane >> 4) ^ (((lane >> 2) & 1) << 1)) : 16 * ((lane >> 4) ^ ((lane >> 1) & 3));
     const char* const ra_base = lds + (wave_m * WM + (lane & 15)) * ROW + koff;
     const char* const rb_base = lds + OFF_B + (wave_n * WN + (lane & 15)) * ROW + koff;
     auto compute = [&](int stage) {
-        const char* pa = ra_base + stage * STAGE;
-        const char* pb = rb_base + stage * STAGE;
-        f16x8 fb[AT][NPL];
 #pragma unroll
-        for (int j = 0; j < AT; ++j)
+        for (int u = 0; u < KS / 32; ++u) {                 // 128-byte rows: two 32-deep sub-steps, the second in the rows' upper 64 bytes
+            const char* pa = ra_base + stage * STAGE + 64 * u;
+            const char* pb = rb_base + stage * STAGE + 64 * u;
+            f16x8 fb[AT][NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+            for (int j = 0; j < AT; ++j)
 #pragma unroll
-        for (int i = 0; i < AM; ++i) {
-            f16x8 fa[NPL];
+                for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
+            for (int i = 0; i < AM; ++i) {
+                f16x8 fa[NPL];
 #pragma unroll
-            for (int j = 0; j < AT; ++j) {
-                // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels
-                // 4 (l >> 4) .. +3) -> 16-byte epilogue stores.  Same term order as conv_igemm.hip (bit-identical sums).
-                if constexpr (NTERMS == 3) {
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
+#pragma unroll
+                for (int j = 0; j < AT; ++j) {
+                    // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels
+                    // 4 (l >> 4) .. +3) -> 16-byte epilogue stores.  Same term order as conv_igemm.hip (bit-identical sums).
+                    if constexpr (NTERMS == 3) {
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -638,8 +656,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             for (int s = 0; s < S; ++s) {
                 PL_STAMP();
                 if (s + 1 < S) {
-                    if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    static_assert(NDMA == 6, "256-row tiles: 6 DMA instructions per wave and K-step (f16x3: (2 + 1) x 2 planes; one plane, 128-byte rows: 4 + 2)");
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
