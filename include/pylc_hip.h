@@ -32,6 +32,7 @@ extern "C" {
 #define PYLC_ERR_ARG 1
 #define PYLC_ERR_HIP 2
 #define PYLC_ERR_WORKSPACE 3
+#define PYLC_ERR_UNSUPPORTED 4   /* an optional run-time dependency is absent (pylc_comm_*: no loadable librccl) */
 
 const char* pylc_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -625,6 +626,21 @@ int pylc_debug_wgrad_acc1(int on);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */
 int pylc_debug_pp_stamps(unsigned long long* buf);
+
+/* ---- data-parallel exchange over RCCL / xGMI, one process per GPU ------------------------------------------
+ * The reference has no working multi-GPU path: nn.DataParallel is commented out (models/model.py:186-188) and the vendored
+ * SynchronizedBatchNorm2d (models/sync_batchnorm/batchnorm.py:48-125 + comm.py's master / slave queues: reduce [sum, sumsq, count] on
+ * the master, broadcast mean / inv_std) is never constructed.  These entries are that exchange as collectives: communicator set-up, an
+ * in-place SUM all-reduce (gradient buckets of the flat arena, loss-head partial sums, BatchNorm backward sums) and the SyncBN moment
+ * exchange.  RCCL is resolved at run time (the librccl.so.1 already in the process, else the system's); without one the calls return
+ * PYLC_ERR_UNSUPPORTED.  Everything is enqueued on the caller's stream.  pylc_amd uses them when PYLC_COMM=native (default: the same
+ * collectives through torch.distributed's RCCL backend). */
+#define PYLC_COMM_ID_BYTES 128
+int pylc_comm_unique_id(void* id_out);                                   /* PYLC_COMM_ID_BYTES bytes; one rank makes it, the caller hands it to all */
+int pylc_comm_init(const void* id, int rank, int world, void** comm_out);   /* collective; the current HIP device is this rank's GPU */
+int pylc_comm_allreduce(void* comm, void* buf, long long count, int dtype, void* stream);      /* in-place SUM; dtype 0 = fp32, 1 = fp64 */
+int pylc_comm_syncbn_reduce(void* comm, double* moments, int channels, void* stream);          /* [sum | sumsq | n]: 2 C + 1 doubles, in place */
+int pylc_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,30 @@ def init_from_env(backend=None):
     separate = backend == 'nccl' and os.environ.get('PYLC_SEPARATE_GRAD_COMM') == '1'
     runtime.grad_group = dist.new_group(backend=backend) if separate else dist.group.WORLD
     runtime.manual_seed(runtime.seed, rank)
+    if backend == 'nccl' and os.environ.get('PYLC_COMM') == 'native':
+        init_native_comm(rank, world)
     return rank, world
+
+
+def init_native_comm(rank, world):
+    """PYLC_COMM=native: the SyncBN / loss / gradient collectives go through the C ABI's own RCCL communicator (include/pylc_hip.h
+    pylc_comm_*) instead of torch.distributed's: a collective is then ONE ctypes call that enqueues ncclAllReduce on the stream the kernels
+    run on -- no Python work object, no hop to a communication stream and back.  torch.distributed stays the side channel that carries the
+    128-byte communicator id from rank 0 (and the barrier / parameter broadcast at set-up)."""
+    import ctypes as C
+    from .lib import lib, check
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        check(lib.pylc_comm_unique_id(buf))
+        ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(ident, 0)
+    raw = bytes(ident.cpu().numpy().tobytes())
+    handle = C.c_void_p()
+    check(lib.pylc_comm_init(raw, rank, world, C.byref(handle)))
+    runtime.comm = handle
 
 
 class GradBucketer:
@@ -105,14 +128,22 @@ class GradBucketer:
         # told to wait for the compute stream's current position -- the compute stream itself never waits here.
         from . import ops
         side = ops.side_stream_if_any(self.arena.g.device)
+        native = runtime.comm is not None and self.arena.g.is_cuda
         if side is None:
-            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if native:
+                runtime.native_all_reduce(self.arena.g[lo:hi])          # on the compute stream, behind the kernels that wrote the bucket
+            else:
+                self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         ev = torch.cuda.Event()
         ev.record()
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if native:
+                runtime.native_all_reduce(self.arena.g[lo:hi])          # on the side stream; finish() makes the compute stream wait for it
+                self._native_side = side
+            else:
+                self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Launch whatever did not complete on its own (parameters without a gradient this step) and wait for all."""
@@ -122,6 +153,10 @@ class GradBucketer:
         for w in self.works:
             w.wait()
         self.works = []
+        side = getattr(self, '_native_side', None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)           # the optimiser reads the reduced arena on the compute stream
+            self._native_side = None
 
 
 def bucket_ranges(numel, bucket=BUCKET_FLOATS):
@@ -170,6 +205,8 @@ def init_single_rank_group():
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', dev))
     runtime.sync_group = dist.group.WORLD
     runtime.grad_group = dist.group.WORLD
+    if os.environ.get('PYLC_COMM') == 'native':
+        init_native_comm(0, 1)
 
 
 def rank():

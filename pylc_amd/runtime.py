@@ -65,16 +65,30 @@ class _Runtime:
         self.dropout_enabled = True   # parity runs switch dropout off (RNG streams differ from torch's)
         # PYLC_NO_PLANES=1: keep every activation fp32 (the conv kernels split operands themselves) -- A/B and bit-identity tests
         self.no_planes = bool(os.environ.get('PYLC_NO_PLANES'))
+        self.comm = None              # native RCCL communicator handle (pylc_comm_init) when PYLC_COMM=native; None: torch.distributed carries the collectives
         self.shard_check = None       # (reduced [sum b, sum b^2] device pair, world) of the last data-parallel loss exchange (ops.check_equal_shards)
         self.collectives = 0          # SyncBN / loss collectives issued (diagnostics: bench.py collectives_per_step)
         self.seed = 0x5EED
         self._counter = itertools.count(1)
 
     def sync_all_reduce(self, t, group):
-        """The SUM all-reduce of a SyncBN / loss statistics message (counted)."""
-        import torch.distributed as dist
+        """The SUM all-reduce of a SyncBN / loss statistics message (counted).  With a native communicator (PYLC_COMM=native,
+        parallel.init_native_comm) the message goes through the C ABI -- pylc_comm_allreduce, enqueued on the CURRENT stream: no work
+        object, no stream hop --, else through torch.distributed."""
         self.collectives += 1
+        if self.comm is not None and t.is_cuda and group is self.sync_group:
+            self.native_all_reduce(t)
+            return
+        import torch.distributed as dist
         dist.all_reduce(t, group=group)
+
+    def native_all_reduce(self, t):
+        """In-place SUM all-reduce of a contiguous fp32 / fp64 device tensor on the current stream through pylc_comm_allreduce."""
+        import torch
+        from .lib import lib, check, ptr, stream
+        if not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64):
+            raise ValueError('native all-reduce takes contiguous fp32 / fp64 tensors, got %s %s' % (t.dtype, tuple(t.stride())))
+        check(lib.pylc_comm_allreduce(self.comm, ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, stream()))
 
     def next_seed(self):
         """Distinct, reproducible seed per dropout call (rank-offset so data-parallel ranks draw different masks)."""

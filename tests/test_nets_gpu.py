@@ -255,12 +255,14 @@ if runtime.sync_group is not None:
     parallel.broadcast_parameters(m.arena)
 for _ in range(2):
     m.train(x, y)
+import os
+assert (runtime.comm is not None) == (os.environ.get('PYLC_COMM') == 'native')
 print('RESULT', runtime.sync_group is not None, float(m.crit.ce), float(m.crit.dsc), float(m.crit.fl), float(m.optim.norm[0]))
 print('COLLECTIVES', runtime.collectives // 2)
 ''' % root
     res = {}
-    for force in ('', '1'):
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYLC_FORCE_PG=force)
+    for force in ('', '1', 'native'):       # no group / torch.distributed RCCL / the C ABI's own communicator (pylc_comm_*, PYLC_COMM=native)
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYLC_FORCE_PG='1' if force else '', PYLC_COMM='native' if force == 'native' else '')
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
         assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-2000:]
@@ -270,8 +272,8 @@ print('COLLECTIVES', runtime.collectives // 2)
         # SyncBN + loss collectives per step: 113 BatchNorm layers x 2 directions, the ASPP's five parallel layers sharing one message per
         # direction (ops.GroupBnActFn: 10 -> 2), + 1 for the loss statistics
         assert ncoll == (113 * 2 - 10 + 2 + 1 if force else 0), ncoll
-    assert res[''][0] == 'False' and res['1'][0] == 'True'
-    assert res[''][1] == res['1'][1], res
+    assert res[''][0] == 'False' and res['1'][0] == 'True' and res['native'][0] == 'True'
+    assert res[''][1] == res['1'][1] == res['native'][1], res
 
 
 @pytest.mark.parametrize('world', [2, 4])
