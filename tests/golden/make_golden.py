@@ -364,7 +364,8 @@ def golden_fp64(tag, arch, backbone, b, ch, hw, n_classes, out_dir):
     """fp64 TRUTH for the fixture of `tag`: the reference's own modules cast to double, on the same (fp32-valued) weights and inputs --
     eval logits and the clipped step-0 gradients of the tensors <tag>_grads.json names.  Stored next to them: how far the reference's
     fp32 results (the committed fixtures) are from this truth, per tensor (max and rms), which is the yardstick of
-    tests/test_nets_gpu.py::test_error_against_fp64_truth -- |HIP - fp64| <= 2 x |reference_fp32 - fp64|."""
+    tests/test_nets_gpu.py::test_error_against_fp64_truth -- |HIP - fp64| <= 1.25 x |reference_fp32 - fp64| on the logits, <= 5 x per gradient
+    tensor and <= 2.5 x on their median (why not a flat 2 x: DESIGN.md section 3 (v), the ReLU-mask flips of either fp32-grade arithmetic)."""
     import oracle
     from oracle import step as ostep
     from tests import _data as D
