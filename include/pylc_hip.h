@@ -623,6 +623,9 @@ int pylc_debug_ps(int on);
 int pylc_debug_dw_tiles(int on);
 /* wgrad_pl.hip: 1 runs the 128 x 128 f16x3 wgrad with one accumulator set under 128 registers per wave (A/B knob) */
 int pylc_debug_wgrad_acc1(int on);
+/* wgrad_pl.hip rasterisation experiments (tools/wgrad_traffic.py): bit 0 = blocks in plain blockIdx order (no XCD remap), bit 1 = split
+ * index fastest (the blocks that share a pixel chunk far apart).  0 = the product's order. */
+int pylc_debug_wgrad_flags(int flags);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */
 int pylc_debug_pp_stamps(unsigned long long* buf);

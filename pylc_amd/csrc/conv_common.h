@@ -189,6 +189,7 @@ struct WgradArgs {
     const void* dy_planes;
     long long x_plane_stride, dy_plane_stride;
     int nterms;                    // 3 = f16x3, 1 = plain fp16 (plane 0 only)
+    int dbg_flags;                 // wgrad_pl.hip rasterisation experiments (pylc_debug_wgrad_flags): 1 = no XCD remap, 2 = split index fastest
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -220,6 +221,7 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st);
 int conv_pl_init();
 
 extern int g_conv_precision;
+extern int g_wg_flags;
 extern int g_pp_flags;
 
 }  // namespace pylc

@@ -42,11 +42,22 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     char* sB = sA + NPL * PLA;                               // NPL planes of gathered x
 
     const int T = a.TR * a.TS;
-    int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tc = id % a.tiles_c; id /= a.tiles_c;
-    const int tn = id % a.tiles_n; id /= a.tiles_n;
-    const int tap = id % T; id /= T;
-    const int split = id;
+    // Rasterisation: (channel tile, cout tile, tap) fastest, split slowest, every XCD a contiguous range -- the blocks resident on an XCD at
+    // one time are the tiles of the SAME few pixel chunks, so a chunk of x / dy is fetched once and served to its other readers by that
+    // XCD's L2.  (debug flags, tools/wgrad_traffic.py: 1 = plain blockIdx order, 2 = split index fastest: the sharers far apart)
+    int id = (a.dbg_flags & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    int tc, tn, tap, split;
+    if (a.dbg_flags & 2) {
+        split = id % a.splits; id /= a.splits;
+        tc = id % a.tiles_c; id /= a.tiles_c;
+        tn = id % a.tiles_n; id /= a.tiles_n;
+        tap = id;
+    } else {
+        tc = id % a.tiles_c; id /= a.tiles_c;
+        tn = id % a.tiles_n; id /= a.tiles_n;
+        tap = id % T; id /= T;
+        split = id;
+    }
     const int n0 = tn * BN, c0 = tc * BC;
     const int m_begin = split * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
@@ -260,6 +271,8 @@ constexpr size_t wgpl_smem() { return (size_t)(NTERMS == 3 ? 2 : 1) * 32 * (wg_r
 // Measured (tools/acc1_ab.sh): the BatchNorm kernels do speed up next to it, but the matrix-bound dgrads of the main stream, which now
 // share their SIMDs with wgrad waves instead of alternating with whole wgrad blocks, lose far more (3x3 dgrad 319 -> 204 TFLOP/s, 1x1
 // 159 -> 98): 352-354 vs 376 tiles/s; raising the conv kernels' wave priority (s_setprio 3) does not change that.  OFF by default.
+int g_wg_flags = 0;          // rasterisation experiments (WgradArgs::dbg_flags)
+extern "C" int pylc_debug_wgrad_flags(int flags) { g_wg_flags = flags; return PYLC_OK; }
 int g_wg_acc1 = 0;        // 1: the 128 x 128 f16x3 wgrad runs its one-accumulator, <= 128-register form (pylc_debug_wgrad_acc1)
 extern "C" int pylc_debug_wgrad_acc1(int on) { g_wg_acc1 = on; return PYLC_OK; }
 constexpr size_t kAcc1LdsReserve = 72 * 1024;      // two blocks per CU, not four: the other half of the register file is for other kernels
@@ -290,6 +303,7 @@ static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
 }
 
 int launch_wg_pl(WgradArgs& a, int cfg, long long grid, hipStream_t st) {
+    a.dbg_flags = g_wg_flags;
     PYLC_REQUIRE(grid > 0 && grid < (1ll << 31), "wgrad grid out of range");
     PYLC_REQUIRE(a.x_planes && a.dy_planes && a.amax_dy && a.amax_x, "wgrad (fp16-plane operands): null planes / ranges");
     PYLC_REQUIRE(a.Q >= 16 && a.Cin % 8 == 0 && a.N_ld % 8 == 0 && a.x_pitch % 8 == 0 && a.dy_pitch % 8 == 0,

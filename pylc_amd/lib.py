@@ -75,6 +75,7 @@ SIGNATURES = {
     'pylc_debug_pp_flags': (_I, [_I]),
     'pylc_debug_stagger': (_I, [_I]),
     'pylc_debug_p1': (_I, [_I]),
+    'pylc_debug_wgrad_flags': (_I, [_I]),
     'pylc_comm_unique_id': (_I, [_P]),
     'pylc_comm_init': (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
     'pylc_comm_allreduce': (_I, [_P, _P, _LL, _I, _P]),

@@ -133,7 +133,9 @@ class BnActFn(torch.autograd.Function):
         if training and relu and residual is not None and c % 8 == 0 and drop_p == 0 and any(ctx.needs_input_grad) and not _runtime.no_relu_bits:
             mask = torch.empty(m * c // 8, dtype=torch.uint8, device=dev)
         tm = _bn_time('apply%s%s%s' % ('+res' if residual is not None else '', '+bits' if mask is not None else '', '+drop' if drop_p > 0 else ''), m, c,
-                      m * c * (4 + 4 + (4 if residual is not None else 0) + (0.125 if mask is not None else 0)))
+                      # algorithmic bytes: 4 B per fp32 / two-plane element, 2 B per one-plane (precision mode 3) element, 1/8 B per mask bit
+                      m * c * ((2 if y_bound is not None else 4) + (2 * nplanes() if out_planes else 4)
+                               + (0 if residual is None else (2 * nplanes() if res_pl is not None else 4)) + (0.125 if mask is not None else 0)))
         tm.__enter__()
         if out_planes or res_pl is not None or drop_p > 0 or mask is not None or y_bound is not None:
             ex = _bn_extra(drop_p=drop_p, drop_seed=drop_seed)
@@ -218,7 +220,8 @@ class BnActFn(torch.autograd.Function):
         msrc = 0.125 if mask is not None else (4 if (relu and out is not None) else 0)         # bytes per element read for the ReLU mask
         pre = getattr(ctx, 'pre_sums', None)
         ctx.pre_sums = None
-        tm = _bn_time('bwd_sums(from dgrad)' if pre is not None else 'bwd_reduce(+sums)', m, c, m * c * (8 + msrc) if pre is None else 0)
+        e_in = (2 if a_bound is not None else 4) + (2 if y_bound is not None else 4)          # dout + y: one fp16 plane each in precision mode 3
+        tm = _bn_time('bwd_sums(from dgrad)' if pre is not None else 'bwd_reduce(+sums)', m, c, m * c * (e_in + msrc) if pre is None else 0)
         tm.__enter__()
         if pre is not None:
             # the conv dgrad that produced `dout` took the per-tile sums in its epilogue: only the combine (and the dy bound) is left
@@ -285,7 +288,8 @@ class BnActFn(torch.autograd.Function):
                        and lk.masked is None and a_bound is None and pitch_of(dout) == c and _runtime.fuse_res_grad)
         g_out = empty_nhwc(b, c, h, w, dev) if (want_res and not res_is_dout and not park_masked) else None
         amax_dy = amax_slot(dev) if (ctx.want_amax and not dy_pl) else None
-        tm = _bn_time('bwd_apply%s' % ('+gres' if g_out is not None else ''), m, c, m * c * (12 + msrc + (4 if g_out is not None else 0)))
+        tm = _bn_time('bwd_apply%s' % ('+gres' if g_out is not None else ''), m, c,
+                      m * c * (e_in + (2 * nplanes() if dy_pl else 4) + msrc + (4 if g_out is not None else 0)))
         tm.__enter__()
         if use_ex:
             if dy_pl:
