@@ -626,6 +626,9 @@ int pylc_debug_wgrad_acc1(int on);
 /* wgrad_pl.hip rasterisation experiments (tools/wgrad_traffic.py): bit 0 = blocks in plain blockIdx order (no XCD remap), bit 1 = split
  * index fastest (the blocks that share a pixel chunk far apart).  0 = the product's order. */
 int pylc_debug_wgrad_flags(int flags);
+/* Longest reduction, in K-steps of 32 pixels, of one block of a multi-tap wgrad (default 256; 0 = no cap, the round-3 plan): shorter
+ * blocks start together round after round, so that the blocks sharing a pixel chunk stay within the L2's reach of each other. */
+int pylc_debug_wgrad_max_steps(int steps);
 /* The next forward convs that take the ping-pong kernel record s_memtime stamps of block 0 (waves 0 and 4) at every
  * segment boundary into buf (2 x 256 uint64, device memory); NULL switches it off (tools/pp_stamps.py). */
 int pylc_debug_pp_stamps(unsigned long long* buf);

@@ -1958,6 +1958,9 @@ extern "C" int pylc_conv2d_dgrad_bn(const PylcConvDesc* d, const float* dy, cons
 namespace {
 struct WgradPlan { int cfg; int tiles_n, tiles_c, splits, m_per_split; long long slab; bool cin4; };
 // cfg 0: 128x128, 1: 64x64, 2: 32(cout)x128(cin), 3: cin4 64x64
+int g_wg_max_steps = 256;       // longest reduction (K-steps of 32 pixels) of one block of a multi-tap wgrad (pylc_debug_wgrad_max_steps; 0: no cap)
+extern "C" int pylc_debug_wgrad_max_steps(int steps) { g_wg_max_steps = steps; return PYLC_OK; }
+
 WgradPlan plan_wgrad(const PylcConvDesc* d) {
     WgradPlan p{};
     const int T = d->R * d->S;
@@ -1978,9 +1981,18 @@ WgradPlan plan_wgrad(const PylcConvDesc* d) {
     long long max_splits = cdiv<long long>(M, 512);
     if (max_splits > 256) max_splits = 256;
     if (max_splits < 1) max_splits = 1;
-    long long s = 1;
+    // Multi-tap filters: the 9 x tiles_n x tiles_c blocks of a split re-read the same pixel rows and only the XCD's 4 MB L2 makes that
+    // one HBM fetch -- which holds while the blocks stay within a few tens of K-steps of each other.  Blocks that run for a thousand
+    // K-steps drift apart (measured, tools/wgrad_traffic.py: the decoder's 256 -> 256 3x3 at 128^2 x 32 with 14 splits of 1170 steps
+    // fetched 4.3 GB for 1.07 GB of operands); blocks of at most g_wg_max_steps K-steps start together round after round and stay together.
+    long long min_splits = 1;
+    if (T > 1 && !p.cin4 && g_wg_max_steps > 0) {
+        min_splits = cdiv<long long>(M, 32ll * g_wg_max_steps);
+        if (min_splits > max_splits) min_splits = max_splits;
+    }
+    long long s = min_splits;
     double best = -1.0;
-    for (long long c = 1; c <= max_splits; ++c) {
+    for (long long c = min_splits; c <= max_splits; ++c) {
         const long long blocks = tiles * c;
         const double eff = (double)blocks / (double)(cdiv<long long>(blocks, slots) * slots);
         if (eff > best + 0.04) { best = eff; s = c; }      // prefer the smallest split within 4 % of the best fill

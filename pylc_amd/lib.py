@@ -76,6 +76,7 @@ SIGNATURES = {
     'pylc_debug_stagger': (_I, [_I]),
     'pylc_debug_p1': (_I, [_I]),
     'pylc_debug_wgrad_flags': (_I, [_I]),
+    'pylc_debug_wgrad_max_steps': (_I, [_I]),
     'pylc_comm_unique_id': (_I, [_P]),
     'pylc_comm_init': (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
     'pylc_comm_allreduce': (_I, [_P, _P, _LL, _I, _P]),
@@ -228,6 +229,8 @@ def init():
             lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
+        if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)
+            lib.pylc_debug_wgrad_max_steps(int(os.environ['PYLC_WG_MAX_STEPS']))
         if os.environ.get('PYLC_PS') is not None:        # bit 0: plain 1x1 launches on the specialised-wave kernel of conv_ps.hip, bit 1: + masked-residual dgrads
             lib.pylc_debug_ps(int(os.environ['PYLC_PS']))
         if os.environ.get('PYLC_DW_TILES') is not None:  # 0: half depthwise convs on the strip kernels (A/B)
