@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         tc = id % a.tiles_c; id /= a.tiles_c;
         tn = id % a.tiles_n; id /= a.tiles_n;
         tap = id;
+    } else if (a.dbg_flags & 4) {                  // taps fastest: the nine blocks of one (channel tile, cout tile) adjacent
+        tap = id % T; id /= T;
+        tc = id % a.tiles_c; id /= a.tiles_c;
+        tn = id % a.tiles_n; id /= a.tiles_n;
+        split = id;
     } else {
         tc = id % a.tiles_c; id /= a.tiles_c;
         tn = id % a.tiles_n; id /= a.tiles_n;

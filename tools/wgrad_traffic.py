@@ -34,8 +34,8 @@ reps = 6
 dev = torch.device('cuda:0')
 L.init()
 check(lib.pylc_set_conv_precision(2))
-lib.pylc_debug_wgrad_flags(flags & 3)
-lib.pylc_debug_wgrad_max_steps(flags >> 2)          # flags = raster | (max K-steps << 2)
+lib.pylc_debug_wgrad_flags(flags & 7)
+lib.pylc_debug_wgrad_max_steps(flags >> 3)          # flags = raster | (max K-steps << 3)
 for (B, H, cin, cout, k, pad) in SHAPES:
     torch.manual_seed(1)
     conv = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
