@@ -624,7 +624,8 @@ int pylc_debug_dw_tiles(int on);
 /* wgrad_pl.hip: 1 runs the 128 x 128 f16x3 wgrad with one accumulator set under 128 registers per wave (A/B knob) */
 int pylc_debug_wgrad_acc1(int on);
 /* wgrad_pl.hip rasterisation experiments (tools/wgrad_traffic.py): bit 0 = blocks in plain blockIdx order (no XCD remap), bit 1 = split
- * index fastest (the blocks that share a pixel chunk far apart).  0 = the product's order. */
+ * index fastest (the blocks that share a pixel chunk far apart), bit 2 = taps slowest (the round-3 order).  0 = the product's order
+ * (taps fastest, split slowest, XCD-contiguous). */
 int pylc_debug_wgrad_flags(int flags);
 /* Longest reduction, in K-steps of 32 pixels, of one block of a multi-tap wgrad (default 256; 0 = no cap, the round-3 plan): shorter
  * blocks start together round after round, so that the blocks sharing a pixel chunk stay within the L2's reach of each other. */

@@ -42,9 +42,13 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     char* sB = sA + NPL * PLA;                               // NPL planes of gathered x
 
     const int T = a.TR * a.TS;
-    // Rasterisation: (channel tile, cout tile, tap) fastest, split slowest, every XCD a contiguous range -- the blocks resident on an XCD at
-    // one time are the tiles of the SAME few pixel chunks, so a chunk of x / dy is fetched once and served to its other readers by that
-    // XCD's L2.  (debug flags, tools/wgrad_traffic.py: 1 = plain blockIdx order, 2 = split index fastest: the sharers far apart)
+    // Rasterisation: taps fastest, then (channel tile, cout tile), split slowest, every XCD a contiguous range.  The blocks resident on an
+    // XCD at one time are then the nine taps of a few (channel tile, cout tile) pairs of the SAME pixel chunk: a chunk of x / dy is
+    // fetched from HBM once and served to its other readers by that XCD's 4 MB L2.  Measured per launch (tools/wgrad_traffic.py,
+    // profiles/r04_wgrad_traffic.txt; L2-miss bytes / operand bytes): 256 -> 256 3x3 @128^2 x 32: 4.02 x with taps slowest and 1170-step
+    // blocks, 1.86 x with taps fastest and blocks capped at 256 K-steps (plan_wgrad); 512 -> 512 @32^2: 4.97 -> 3.13; 256 -> 256 @32^2: 1.66 -> 1.36.
+    // (debug flags, pylc_debug_wgrad_flags: 1 = plain blockIdx order, 2 = split index fastest -- the sharers far apart --, 4 = the
+    // round-3 order, taps slowest)
     int id = (a.dbg_flags & 1) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     int tc, tn, tap, split;
     if (a.dbg_flags & 2) {
@@ -52,15 +56,15 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         tc = id % a.tiles_c; id /= a.tiles_c;
         tn = id % a.tiles_n; id /= a.tiles_n;
         tap = id;
-    } else if (a.dbg_flags & 4) {                  // taps fastest: the nine blocks of one (channel tile, cout tile) adjacent
-        tap = id % T; id /= T;
+    } else if (a.dbg_flags & 4) {
         tc = id % a.tiles_c; id /= a.tiles_c;
         tn = id % a.tiles_n; id /= a.tiles_n;
+        tap = id % T; id /= T;
         split = id;
     } else {
+        tap = id % T; id /= T;
         tc = id % a.tiles_c; id /= a.tiles_c;
         tn = id % a.tiles_n; id /= a.tiles_n;
-        tap = id % T; id /= T;
         split = id;
     }
     const int n0 = tn * BN, c0 = tc * BC;

@@ -229,6 +229,8 @@ def init():
             lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
+        if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)
+            lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
         if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)
             lib.pylc_debug_wgrad_max_steps(int(os.environ['PYLC_WG_MAX_STEPS']))
         if os.environ.get('PYLC_PS') is not None:        # bit 0: plain 1x1 launches on the specialised-wave kernel of conv_ps.hip, bit 1: + masked-residual dgrads
