@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         tn = id % a.tiles_n; id /= a.tiles_n;
         tap = id % T; id /= T;
         split = id;
+    } else if (a.Cin > a.N && !(a.dbg_flags & 8)) {
+        // more input than output channels: x is the larger operand, so the blocks that share an x slice (same channel tile, all cout
+        // tiles, all taps) are the adjacent ones (debug flag 8: channel tiles inner regardless)
+        tap = id % T; id /= T;
+        tn = id % a.tiles_n; id /= a.tiles_n;
+        tc = id % a.tiles_c; id /= a.tiles_c;
+        split = id;
     } else {
         tap = id % T; id /= T;
         tc = id % a.tiles_c; id /= a.tiles_c;

@@ -7,7 +7,7 @@ import csv, glob, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SHAPES = [  # B, H, Cin, Cout, k, pad
-    (32, 32, 256, 256, 3, 1), (32, 128, 256, 256, 3, 1), (32, 128, 304, 256, 3, 1), (32, 64, 128, 128, 3, 1), (32, 128, 64, 64, 3, 1), (32, 32, 512, 512, 3, 1),
+    (32, 32, 256, 256, 3, 1), (32, 128, 256, 256, 3, 1), (32, 128, 304, 256, 3, 1), (32, 64, 128, 128, 3, 1), (32, 128, 64, 64, 3, 1), (32, 32, 512, 512, 3, 1), (32, 32, 2048, 256, 3, 1), (32, 32, 1024, 256, 1, 0), (32, 32, 256, 1024, 1, 0), (32, 32, 2048, 512, 1, 0),
 ]
 
 if len(sys.argv) > 2 and sys.argv[1] == '--parse':
@@ -34,8 +34,8 @@ reps = 6
 dev = torch.device('cuda:0')
 L.init()
 check(lib.pylc_set_conv_precision(2))
-lib.pylc_debug_wgrad_flags(flags & 7)
-lib.pylc_debug_wgrad_max_steps(flags >> 3)          # flags = raster | (max K-steps << 3)
+lib.pylc_debug_wgrad_flags(flags & 15)
+lib.pylc_debug_wgrad_max_steps(flags >> 4)          # flags = raster | (max K-steps << 4)
 for (B, H, cin, cout, k, pad) in SHAPES:
     torch.manual_seed(1)
     conv = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
