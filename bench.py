@@ -69,56 +69,66 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` ('a<..,*> + b<..>': every instantiation with one of those prefixes) from the committed
-    rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950
-    correction, WRITE_SIZE exact).  PMC collection needs the profiler, so it cannot be measured live here: the value comes with its
-    provenance -- the profile file, the kernel-source fingerprint it was taken on and whether that is THIS build's.  (None, None) if no
-    profile is committed."""
+def _family_matcher(kernel):
+    """Predicate over rocprofv3 kernel names for a family label such as 'gg_pl_kernel<3,*> + gg_plh_kernel<3>': a member is any
+    instantiation of one of the named templates whose FIRST template argument (NTERMS) is the label's -- matched on the name before the
+    template list plus that argument, never on a substring of the whole argument list (round 4's substring match silently dropped
+    'gg_plh_kernel<3, false, false>')."""
+    import re
+    pats = []
+    for part in kernel.split('+'):
+        m = re.match(r'\s*(\w+)\s*<\s*(\d+)', part)
+        if m is None:
+            raise ValueError('kernel family label %r: expected name<NTERMS...>' % part)
+        pats.append(re.compile(r'(?<![\w])%s<%s[,>]' % (re.escape(m.group(1)), m.group(2))))
+    return lambda name: any(p.search(''.join(name.split())) for p in pats)
+
+
+def _pmc_family(pattern, kernel, per_launch_key, launches_per_step, need_key=None):
+    """Launch-weighted mean of `per_launch_key` over the family's rows of the newest committed profile matching `pattern`, with its
+    provenance.  Fails loudly if the family's launch count in the profile is not a whole number of steps of `launches_per_step` launches
+    (i.e. if the name match and the live launch count of the KernelTimer disagree about what the family is)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     if not files:
         return None, None
     prof = json.load(open(files[-1]))
-    wants = [''.join(k.split()).split('*')[0] for k in kernel.split('+')]
-    tot_bytes = tot_n = 0.0
+    member = _family_matcher(kernel)
+    tot = n = 0.0
+    rows = []
     for name, v in prof.items():
-        if name.startswith('_'):
+        if name.startswith('_') or (need_key is not None and need_key not in v) or not member(name):
             continue
-        flat = ''.join(name.split())
-        if any(w in flat for w in wants):
-            tot_bytes += v['hbm_bytes_per_launch'] * v['launches']
-            tot_n += v['launches']
+        tot += v[per_launch_key] * v['launches']
+        n += v['launches']
+        rows.append(name)
     meta = prof.get('_meta', {})
     src = {'file': os.path.relpath(files[-1], ROOT), 'measured_on_csrc_sha256': meta.get('csrc_sha256'),
-           'this_build_csrc_sha256': csrc_fingerprint(), 'launches_in_profile': int(tot_n)}
+           'this_build_csrc_sha256': csrc_fingerprint(), 'launches_in_profile': int(n), 'rows': len(rows)}
     src['same_build'] = src['measured_on_csrc_sha256'] == src['this_build_csrc_sha256']
-    return (tot_bytes / tot_n if tot_n else None), src
+    if launches_per_step:
+        steps = n / launches_per_step
+        src['profile_steps'] = steps
+        if n == 0 or abs(steps - round(steps)) > 1e-9:
+            raise RuntimeError('%s: the family %r has %d launches in the profile, not a multiple of the %g launches per step the live timer '
+                               'counted -- the name match and the timer disagree (rows: %s)' % (src['file'], kernel, n, launches_per_step, rows))
+    return (tot / n if n else None), src
 
 
-def pmc_mfma(kernel):
-    """Matrix-pipe busy fraction of `kernel` (launch-weighted over its instantiations) from the committed SQ-counter pass of this same
+def pmc_traffic(kernel, launches_per_step=None):
+    """HBM bytes per launch of the kernel family `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact).  PMC collection
+    needs the profiler, so it cannot be measured live here: the value comes with its provenance -- the profile file, the kernel-source
+    fingerprint it was taken on and whether that is THIS build's.  (None, None) if no profile is committed."""
+    return _pmc_family('*_pmc_traffic.json', kernel, 'hbm_bytes_per_launch', launches_per_step)
+
+
+def pmc_mfma(kernel, launches_per_step=None):
+    """Matrix-pipe busy fraction of the family (launch-weighted over its instantiations) from the committed SQ-counter pass of this same
     command (tools/pmc_mfma.sh -> profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES over kernel cycles x 256 CUs x 4 SIMDs), with the
     same provenance fields as pmc_traffic().  The counters serialise the kernels, so this is the kernels' ISOLATED matrix-pipe
     occupancy at the clock the board holds, not a share of the overlapped step.  (None, None) if no profile is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_mfma.json')))
-    if not files:
-        return None, None
-    prof = json.load(open(files[-1]))
-    wants = [''.join(k.split()).split('*')[0] for k in kernel.split('+')]
-    busy = n = 0.0
-    for name, v in prof.items():
-        if name.startswith('_') or 'mfma_busy_frac' not in v:
-            continue
-        if any(w in ''.join(name.split()) for w in wants):
-            busy += v['mfma_busy_frac'] * v['launches']
-            n += v['launches']
-    meta = prof.get('_meta', {})
-    src = {'file': os.path.relpath(files[-1], ROOT), 'measured_on_csrc_sha256': meta.get('csrc_sha256'),
-           'this_build_csrc_sha256': csrc_fingerprint(), 'launches_in_profile': int(n)}
-    src['same_build'] = src['measured_on_csrc_sha256'] == src['this_build_csrc_sha256']
-    return (busy / n if n else None), src
+    return _pmc_family('*_pmc_mfma.json', kernel, 'mfma_busy_frac', launches_per_step, need_key='mfma_busy_frac')
 
 
 def cpu_baseline(hw, n_cls, budget_s=25.0):
@@ -403,6 +413,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     losses = model.loss.flush()
+    # which transport the collectives of the TIMED steps went through (read before the group is torn down)
+    dist_backend = torch.distributed.get_backend() if (world > 1 and torch.distributed.is_initialized()) else None
+    comm_kind = None if world == 1 else ('native' if pylc_amd.runtime.comm is not None else 'torch')
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -424,7 +437,11 @@ def main():
                    # data-parallel diagnostics (so that a scaling run is checkable): ranks on RCCL, collectives issued per step and rank
                    # (SyncBN forward + backward per BatchNorm layer, loss statistics, gradient buckets), and at N = 1 the cost of that
                    # code path at world size 1
-                   'rccl_ranks': world if (world > 1 and torch.distributed.is_available()) else 0,
+                   # rccl_ranks = ranks whose collectives ran on RCCL (0 for a gloo rehearsal or a single process); dist_backend = the
+                   # torch.distributed backend of the timed steps; comm = who issued the SyncBN / loss / bucket collectives ('torch':
+                   # torch.distributed work objects; 'native': the C ABI's own RCCL communicator, pylc_comm_*)
+                   'rccl_ranks': world if (dist_backend == 'nccl' or comm_kind == 'native') else 0,
+                   'dist_backend': dist_backend, 'comm': comm_kind,
                    'sync_bn': bool(pylc_amd.runtime.sync_bn),
                    'collectives_per_step': collectives if world > 1 else dp_collectives,
                    'dp_codepath_overhead': dp_overhead,
@@ -443,8 +460,10 @@ def main():
                                     'steps without these HIP-event brackets; instrumented_ms_per_step is this block)' % n_instr)
         out['roofline']['hbm'] = hbm_roofline(bn_records, n_instr)
         if args.config in ('c3', 'c4'):        # the committed PMC profiles are of the DeepLab/R101 workload: not attached to other networks' lines
-            out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic(out['roofline']['kernel'])
-            out['roofline']['mfma_busy_frac'], out['roofline']['mfma_busy_source'] = pmc_mfma(out['roofline']['kernel'])
+            per_step = out['roofline']['launches'] / n_instr
+            out['roofline']['launches_per_step'] = per_step
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = pmc_traffic(out['roofline']['kernel'], per_step)
+            out['roofline']['mfma_busy_frac'], out['roofline']['mfma_busy_source'] = pmc_mfma(out['roofline']['kernel'], per_step)
         else:
             out['roofline']['traffic'] = None
     if world == 1 and not args.no_cpu_baseline and args.config == 'c3':
