@@ -63,6 +63,12 @@ __device__ __forceinline__ float pow2_scale_for(unsigned amax_bits) {
     return __uint_as_float((unsigned)se << 23);
 }
 
+// 1 / s for a power of two s in [2^-126, 2^127] by exponent arithmetic (2^-127 is the subnormal 0x00400000)
+__device__ __forceinline__ float pow2_inv(float s) {
+    const unsigned e = (__float_as_uint(s) >> 23) & 0xFFu;
+    return __uint_as_float(e >= 254u ? 0x00400000u : (254u - e) << 23);
+}
+
 constexpr int BK = 32;    // reduction depth per LDS stage
 constexpr int LDT = 36;   // padded LDS row (floats): 144 B rows -> conflict-free ds_read_b128 of k-slices
 

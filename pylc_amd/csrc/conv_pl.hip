@@ -57,6 +57,135 @@ constexpr int pl_stages() { return BM == 256 ? 3 : 2; }
 template <int NTERMS, int BM>
 constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, BM>() + BM * 4 + 64; }
 
+// ---- the LEAN epilogue: what a tile of the training step almost always is ----------------------------------------------------------
+// Round 4's ablation (profiles/r04_ps_ab.txt) put the short-K class's time outside the MFMAs on the epilogue's ARITHMETIC: ~1500 vector
+// instructions per wave and tile -- as long as the 384 MFMAs of a K = 256 tile.  Most of them served cases a ResNet / Xception tile never is:
+// a per-element bias add and subtract, rows or channels past the tensor's edge (16 `stored` selects per element group), and they applied
+// the two unscale factors and the bias BEFORE taking the statistics.  This path is taken, wave by wave, when the tile has no edge:
+//     t   = acc + 2^-11 lo                      one fma (two per instruction where PYLC_EPI_PK packs them; done by pl_epilogue for both paths)
+//     sum += t,  sumsq += t t                   on the RAW accumulators; the scale c = 1 / (s_x s_w) is a power of two, so
+//                                               c sum(t) == sum(c t) and c^2 sum(t t) == sum((c t)^2) bit for bit (same order of additions)
+//                                               and it is applied to the 8 reduced column sums of a 16-row fragment instead of to 64 elements
+//     y   = c t (+ masked residual gradient)    one multiply, unconditional 16-byte stores
+// One-plane output (precision mode 3): h = rn16((c s_y) t) is formed ONCE, stored as it is, and the statistics the following BatchNorm
+// needs -- those of the ROUNDED tensor -- are taken from h by mixed-precision fmas (h h is exact in fp32), scaled by 1 / s_y at the end.
+// Everything else (ragged tiles, accumulate + statistics, the BatchNorm-backward and inference epilogues) takes the general path
+// below, unchanged.  Results are bit-identical to it (tests/test_planes_gpu.py pins both against the fp32-operand kernels).
+#ifndef PYLC_EPI_PK
+#define PYLC_EPI_PK 0      // 1: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 forms (A/B: tools/epi_ab.sh)
+#endif
+// (vector-typed f32 arithmetic is legalised into v_pk_* instructions on gfx950 whatever -fno-slp-vectorize says, so the scalar forms
+// are written out element by element)
+__device__ __forceinline__ f32x4v epi_fma(f32x4v a, float b, f32x4v c) {
+#if PYLC_EPI_PK
+    const f32x4v bb = {b, b, b, b};
+    return __builtin_elementwise_fma(a, bb, c);
+#else
+    return f32x4v{__builtin_fmaf(a[0], b, c[0]), __builtin_fmaf(a[1], b, c[1]), __builtin_fmaf(a[2], b, c[2]), __builtin_fmaf(a[3], b, c[3])};
+#endif
+}
+__device__ __forceinline__ f32x4v epi_mul(f32x4v a, float b) {
+#if PYLC_EPI_PK
+    return a * b;
+#else
+    return f32x4v{a[0] * b, a[1] * b, a[2] * b, a[3] * b};
+#endif
+}
+__device__ __forceinline__ f32x4v epi_sq(f32x4v a) {
+#if PYLC_EPI_PK
+    return a * a;
+#else
+    return f32x4v{a[0] * a[0], a[1] * a[1], a[2] * a[2], a[3] * a[3]};
+#endif
+}
+__device__ __forceinline__ f32x4v epi_add(f32x4v a, f32x4v b) {
+#if PYLC_EPI_PK
+    return a + b;
+#else
+    return f32x4v{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+#endif
+}
+
+// STATS: 0 none, 1 column sums / sums of squares.  PREV: 0 none, 1 `extra` added (accumulate / residual-gradient source), 2 ... under the
+// 1-bit mask `amask`.  HALF: one-plane fp16 output (NTERMS == 1 launches only).
+template <int AM, int STATS, int PREV, bool HALF>
+__device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], const int* rowoff,
+                                                 float* sdst, int nb, int wave_m, int lane, float c, float hscale,
+                                                 const float* extra, const unsigned char* amask, const float* bias) {
+    constexpr int AT = 4, WM = 16 * AM;
+    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    unsigned offs[AM];                                      // element offsets of this lane's channel quad in its AM rows (all valid here)
+#pragma unroll
+    for (int i = 0; i < AM; ++i) offs[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nb);
+    const float k = HALF ? c * hscale : c;                  // powers of two: exact
+    const float post = HALF ? pow2_inv(hscale) : c;         // what the column sums are multiplied with (sums of squares: twice)
+    const bool odd_row = (lane >> 4) & 1;
+#pragma unroll
+    for (int j = 0; j < AT; ++j) {
+        f32x4v prev[PREV ? AM : 1];
+        if constexpr (PREV != 0) {
+            unsigned mb[AM];
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                prev[i] = *reinterpret_cast<const f32x4v*>(extra + (offs[i] + j * 16));
+                if constexpr (PREV == 2) mb[i] = amask[(offs[i] + j * 16) >> 3];
+            }
+            if constexpr (PREV == 2) {
+#pragma unroll
+                for (int i = 0; i < AM; ++i) {
+                    // the quad's four mask bits -> all-ones / zero words (v_bfe_i32), ANDed onto the residual gradient
+                    const int nib = (int)(mb[i] >> ((((offs[i] + j * 16) >> 2) & 1u) * 4u));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        prev[i][r] = __uint_as_float(__float_as_uint(prev[i][r]) & (unsigned)__builtin_amdgcn_sbfe(nib, r, 1));
+                }
+            }
+        }
+        // a bias (the U-Net's convs) rides in the fma that applies the scale: c t is exact, so fma(t, c, b) == c t + b in one rounding, as the
+        // general path's mul-then-add; the statistics are those of (value - bias) = c t either way
+        f32x4v bv = {0.f, 0.f, 0.f, 0.f};
+        if (!HALF && bias != nullptr) bv = *reinterpret_cast<const f32x4v*>(bias + nb + j * 16);
+        f32x4v cs = {0.f, 0.f, 0.f, 0.f}, css = cs;
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            const f32x4v t = acc[i][j];                      // (cross terms already folded in by the caller)
+            if constexpr (HALF) {
+                const f32x4v v = epi_mul(t, k);
+                const f16x4_ h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                if constexpr (STATS != 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {            // v_fma_mix_f32: (float)h is exact, h h is exact -> the sums of the rounded tensor
+                        cs[r] = i == 0 ? (float)h[r] : __builtin_fmaf((float)h[r], 1.f, cs[r]);
+                        css[r] = i == 0 ? (float)h[r] * (float)h[r] : __builtin_fmaf((float)h[r], (float)h[r], css[r]);
+                    }
+                }
+                // lanes l and l + 16 (same pixel, the next channel quad) swap halves: even DPP rows store 8 channels = 16 bytes
+                const uint2 hu = __builtin_bit_cast(uint2, h);
+                const u32x2_ sx = __builtin_amdgcn_permlane16_swap(hu.x, hu.x, false, false);
+                const u32x2_ sy = __builtin_amdgcn_permlane16_swap(hu.y, hu.y, false, false);
+                if (!odd_row) *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(a.y) + (offs[i] + j * 16)) = uint4{hu.x, hu.y, sx.y, sy.y};
+            } else {
+                if constexpr (STATS != 0) {
+                    cs = i == 0 ? t : epi_add(cs, t);        // (0 + t == t: the general path's order of additions)
+                    css = i == 0 ? epi_sq(t) : epi_add(css, epi_sq(t));
+                }
+                f32x4v v = epi_fma(t, k, bv);
+                if constexpr (PREV != 0) v = epi_add(v, prev[i]);
+                *reinterpret_cast<f32x4v*>(a.y + (offs[i] + j * 16)) = v;
+            }
+        }
+        if constexpr (STATS != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r] * post; sdst[(j * 16 + r) * 2 + 1] = css[r] * post * post; }
+            }
+        }
+    }
+}
+
 // Epilogue shared by the planes kernels (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic,
 // then stores): fold the cross-term accumulator, undo the operand scales, bias, optional accumulation into y, BatchNorm statistics
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
@@ -64,7 +193,7 @@ constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, B
 // first 64 columns: the NARROW launches for at most 64 output channels)
 template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false>
 __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
-                                            const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid) {
+                                            const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid, bool rows_full) {
     constexpr int BN = PL_BN, WM = 16 * AM, WN = 64, AT = 4;
     typedef f32x4v f32x4v_;
     // ---- epilogue (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic, then stores) ----
@@ -72,7 +201,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     const bool do_stats = a.stats != nullptr;
     const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
     const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
-    const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
+    const float unscale_a = pow2_inv(scale_a), unscale_b = pow2_inv(scale_b);      // exact (bit arithmetic; the IEEE division costs ~10 instructions each)
     float hscale = 1.f;                                  // out_half / out_planes2: the output leaves as one / two fp16 planes
     if (a.out_half || (EP && a.out_planes2)) {
         float b;
@@ -89,8 +218,45 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     }
     const float* extra = a.add_src != nullptr ? a.add_src : (a.accumulate ? a.y : ((EP && a.ep_res_fmt == 0) ? a.ep_res : nullptr));
     const bool res_planes = EP && a.ep_res != nullptr && a.ep_res_fmt != 0;      // residual as fp16 planes (y's geometry, dense)
-    const float res_unscale = res_planes ? 1.f / pow2_scale_for(*a.ep_res_scale) : 1.f;
+    const float res_unscale = res_planes ? pow2_inv(pow2_scale_for(*a.ep_res_scale)) : 1.f;
     const unsigned char* amask = a.add_mask;         // (with add_src; y_pitch == N_store: element offset / 4 = the mask's vector index)
+    // fold the cross-term accumulator (both paths; acc_lo is dead from here on): acc + 2^-11 lo in one rounding, as (acc + lo / 2048)
+    if constexpr (NTERMS == 3) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < AT; ++j) acc[i][j] = epi_fma(acc_lo[i][j], 1.f / 2048.f, acc[i][j]);
+    }
+    // the lean path (above): a tile without an edge and without a combination the general path alone knows -- decided per wave
+    bool done = false;
+    if constexpr (!EP && !BNB) {
+        // (a bias vector holds N entries: with a bias the wave's 64 columns must lie inside N, not just inside the padded N_store; the
+        //  one-plane output takes a bias only in the inference epilogue)
+        const bool cols_full = n0 + wave_n * WN + WN <= (a.bias != nullptr ? a.N : a.N_store);
+        if ((a.bias == nullptr || ((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && !a.out_half)) && rows_full && cols_full && !(do_stats && extra != nullptr) && (NTERMS == 1 || !a.out_half) &&
+            !(a.out_half && extra != nullptr) && !(a.dbg_flags & 8)) {
+            done = true;
+            float* const sd = smem + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+            const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
+            const float c = unscale_a * unscale_b;
+#define PYLC_LEAN(ST, PV, HF) pl_epilogue_lean<AM, ST, PV, HF>(a, acc, rowoff, sd, nb, wave_m, lane, c, hscale, extra, amask, a.bias)
+            if constexpr (NTERMS == 1) {
+                if (a.out_half) {
+                    if (do_stats) PYLC_LEAN(1, 0, true); else PYLC_LEAN(0, 0, true);
+                } else if (extra != nullptr) {
+                    if (amask != nullptr) PYLC_LEAN(0, 2, false); else PYLC_LEAN(0, 1, false);
+                } else if (do_stats) PYLC_LEAN(1, 0, false);
+                else PYLC_LEAN(0, 0, false);
+            } else {
+                if (extra != nullptr) {
+                    if (amask != nullptr) PYLC_LEAN(0, 2, false); else PYLC_LEAN(0, 1, false);
+                } else if (do_stats) PYLC_LEAN(1, 0, false);
+                else PYLC_LEAN(0, 0, false);
+            }
+#undef PYLC_LEAN
+        }
+    }
+    if (!done) {
     int eoff[AM][AT];
     float bv[AT][4];
     float esc[EP ? AT : 1][4], esh[EP ? AT : 1][4];          // fused inference epilogue: eval-BatchNorm scale / shift of this lane's channels
@@ -124,13 +290,12 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
         for (int j = 0; j < AT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if constexpr (NTERMS == 3) acc[i][j][r] = (acc[i][j][r] + acc_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
-                else acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
+                acc[i][j][r] = acc[i][j][r] * unscale_a * unscale_b;
             }
     // one-plane fp16 output: the BatchNorm that follows normalises the ROUNDED tensor, so its statistics (and nothing else differs: the store
     // below reproduces the same halves exactly, hscale being a power of two) are taken from the rounded values, not from the accumulators
     if (!EP && a.out_half) {
-        const float inv_h = 1.f / hscale;
+        const float inv_h = pow2_inv(hscale);
 #pragma unroll
         for (int i = 0; i < AM; ++i)
 #pragma unroll
@@ -365,6 +530,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     }
     if (bn && a.bn_gmax != nullptr) amax_commit(gmax, a.bn_gmax);
     if (EP && a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
+    }          // general path
     if (do_stats) {
         __syncthreads();
         if (tid < BN) {
@@ -679,7 +845,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     PL_STAMP();
     __syncthreads();          // LDS stage 0 is reused for the statistics; orders the row table when S == 0
 
-    pl_epilogue<NTERMS, BM, BNB, AM, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tile / a.tiles_n, n0, wave_m, wave_n, lane, tid);
+    pl_epilogue<NTERMS, BM, BNB, AM, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tile / a.tiles_n, n0, wave_m, wave_n, lane, tid, m0 + BM <= a.M);
     if constexpr (STAMPS) {
         __builtin_amdgcn_sched_barrier(0);
         PL_STAMP();
@@ -871,7 +1037,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // LDS is reused for the statistics; orders the row table
-    pl_epilogue<NTERMS, BM, BNB, 4, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid);
+    pl_epilogue<NTERMS, BM, BNB, 4, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q);
 }
 
 template __global__ void gg_plh_kernel<3>(const GatherGemmArgs);
