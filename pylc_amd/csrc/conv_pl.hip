@@ -615,21 +615,25 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     const bool stamper = STAMPS && (int)blockIdx.x == (a.dbg_flags >> 16) && lane == 0 && (wave == 0 || wave == NW - 1);
     PL_STAMP();
 
+    // TIMING EXPERIMENT (pylc_debug_pp_flags 512; results are garbage): address both operands as if they were stored chunk-interleaved
+    // ([row][32-channel chunk][plane][32 halves]): the two planes of a K-step row are the two halves of ONE 128-byte line
+    const bool il = NPL == 2 && (a.dbg_flags & 512);
+    const unsigned ilm = il ? 2u : 1u;
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * (il ? 2 : 1)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + (il ? 32 : a.x_plane_stride) * 2), 0, (int)(a.x_bytes * (il ? 2 : 1) - (il ? 64 : 0)), 0x00020000);
 
     // ---- filter rows of this thread: no geometry needed, so their first DMA goes out before anything else ----
     unsigned woff_row[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
         const int n = n0 + RPI * BI * wave + RPI * i + lrow;
-        woff_row[i] = n < a.N ? ((unsigned)n * (unsigned)a.w_row_stride + 8u * lc) * 2u : OOB;
+        woff_row[i] = n < a.N ? ((unsigned)n * (unsigned)a.w_row_stride * ilm + 8u * lc) * 2u : OOB;
     }
-    const unsigned plane1_w = (unsigned)(a.w_plane_stride * 2);
+    const unsigned plane1_w = il ? 64u : (unsigned)(a.w_plane_stride * 2);
 
     // ---- pixel rows of this thread ----
     int rowh[AI], roww[AI];
@@ -641,14 +645,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         if (ident) {                       // 1x1, stride 1, no padding: input pixel == output pixel, no decode
             rowh[i] = ok ? 0 : -(1 << 28);
             roww[i] = 0;
-            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch + 8u * lc) * 2u;
+            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u;
         } else {
             const int mm = ok ? m : 0;
             const int q = mm % a.Q, t = mm / a.Q;
             const int p = t % a.P, b = t / a.P;
             rowh[i] = ok ? p * a.in_sh : -(1 << 28);          // invalid rows fail every bounds check
             roww[i] = q * a.in_sw;
-            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * lc) * 2u;      // garbage for invalid rows (masked)
+            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u;      // garbage for invalid rows (masked)
         }
     }
     // output row table (read by the epilogue; the first barrier of the main loop orders it)
@@ -732,8 +736,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         const int dh = a.dh0 + ld_tr * a.dh_step, dw = a.dw0 + ld_ts * a.dw_step;
         const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
         const bool cok = ld_chunk * KS + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
-        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2);      // wave-uniform, may be "negative"
-        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2);
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2) * ilm;      // wave-uniform, may be "negative"
+        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2) * ilm;
         char* const sa = dstA + stage * STAGE;
         char* const sb = dstB + stage * STAGE;
 #pragma unroll
@@ -912,16 +916,18 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     const int hmin_h = a.dh_step > 0 ? a.dh0 : a.dh0 + 2 * a.dh_step;          // smallest tap offset = origin of the halo
     const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
 
+    const bool il = NPL == 2 && (a.dbg_flags & 512);          // TIMING EXPERIMENT, as in gg_pl_kernel
+    const unsigned ilm = il ? 2u : 1u;
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * (il ? 2 : 1)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + (il ? 32 : a.x_plane_stride) * 2), 0, (int)(a.x_bytes * (il ? 2 : 1) - (il ? 64 : 0)), 0x00020000);
 
     // filter row of this thread (one 16-row piece per wave)
     const int nrow = n0 + 16 * wave + (lane >> 2);
-    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride + 8u * lc) * 2u : OOB;
-    const unsigned plane1_w = (unsigned)(a.w_plane_stride * 2);
+    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride * ilm + 8u * lc) * 2u : OOB;
+    const unsigned plane1_w = il ? 64u : (unsigned)(a.w_plane_stride * 2);
     // halo rows of this thread: pieces wave, wave + 8, wave + 16 -> rows 16 g + (lane >> 2); input pixel or padding (zeros)
     unsigned hoff[3];
 #pragma unroll
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int hy = h / PLH_HW, hx = h - hy * PLH_HW;
         const int yy = y0 + hmin_h + hy, xx = x0 + hmin_w + hx;
         const bool ok = (h < PLH_HW * PLH_HW) & ((unsigned)yy < (unsigned)a.IH) & ((unsigned)xx < (unsigned)a.IW);
-        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch + 8u * lc) * 2u : OOB;
+        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u : OOB;
     }
     // output rows: patch pixel (py, px) = (row >> 4, row & 15)
     if (tid < BM) {
@@ -955,7 +961,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     auto issue_halo = [&](int c) {                            // chunk c -> halo buffer c & 1
         char* const dst = lds + (c & 1) * HALO + (16 * wave) * ROW;
         const bool cok = c * BK + 8 * lc < a.Cin;
-        const unsigned cb = (unsigned)(c * BK * 2);
+        const unsigned cb = (unsigned)(c * BK * 2) * ilm;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned vo = (cok & (hoff[j] != OOB)) ? hoff[j] + cb : OOB;
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int c = s / 9, t = s - 9 * c;
         const int tr = t / 3, ts = t - 3 * tr;
         const bool cok = c * BK + 8 * lc < a.Cin;
-        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2);
+        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilm;
         const unsigned vo = cok ? woff_row : OOB;
         const unsigned vo1 = cok ? woff_row + plane1_w : OOB;
         char* const d = ldsB + slot * BST + (16 * wave) * ROW;

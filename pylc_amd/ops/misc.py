@@ -388,17 +388,56 @@ def _shard_pair(b, dev):
     return _shard_pairs[key]
 
 
+SHARD_PAIRS_MAX = 64        # pending pairs folded into one device scalar beyond this many (runs that never call Model.log)
+
+
+def note_shard_pair(pair, world):
+    """Remember the reduced [sum b, sum b^2] pair of ONE data-parallel loss exchange until the host next looks (check_equal_shards).  Every
+    step's pair is kept -- a short final batch on some ranks that is followed by full-size steps before the next Model.log() must still be
+    reported (the pair used to be overwritten, so only the last step before a log was ever checked).  No host synchronisation
+    here: the pairs are views of the steps' statistics messages; past SHARD_PAIRS_MAX of them they are folded on the device into the
+    largest violation seen."""
+    pend = _runtime.shard_check
+    if pend is None:
+        pend = _runtime.shard_check = {'pairs': [], 'world': world, 'worst': None}
+    pend['pairs'].append(pair)
+    pend['world'] = world
+    if len(pend['pairs']) >= SHARD_PAIRS_MAX:
+        _fold_shard_pairs(pend)
+
+
+def _shard_violation(pairs, world):
+    """max over steps of |world * sum b^2 - (sum b)^2| (zero iff every rank held the same count), with the offending (sum b, sum b^2)"""
+    p = torch.stack([q.double() for q in pairs])
+    viol = (p[:, 1] * world - p[:, 0] * p[:, 0]).abs()
+    k = torch.argmax(viol)
+    return torch.stack([viol[k], p[k, 0], p[k, 1]])
+
+
+def _fold_shard_pairs(pend):
+    v = _shard_violation(pend['pairs'], pend['world'])
+    pend['pairs'] = []
+    pend['worst'] = v if pend['worst'] is None else torch.where(v[0] > pend['worst'][0], v, pend['worst'])      # (no host read)
+
+
 def check_equal_shards():
-    """Raise if the last data-parallel loss exchange saw different tile counts on different ranks (the pair that rode on it, see
-    MultiLossFn.forward).  One tiny D2H copy: called where the host reads the loss log anyway (Model.log)."""
-    chk, _runtime.shard_check = _runtime.shard_check, None
-    if chk is None:
+    """Raise if ANY data-parallel loss exchange since the last call saw different tile counts on different ranks (the pairs that rode on
+    them, see MultiLossFn.forward / note_shard_pair).  One tiny D2H copy: called where the host reads the loss log anyway (Model.log)."""
+    pend, _runtime.shard_check = _runtime.shard_check, None
+    if pend is None:
         return
-    pair, world = chk
-    sb, sb2 = (float(v) for v in pair.cpu().tolist())
-    if abs(sb2 * world - sb * sb) > 0.5:
-        raise RuntimeError('data-parallel ranks hold different batch sizes (sum b = %g, sum b^2 = %g over %d ranks): SyncBN and the loss '
-                           'head need equal shards -- use a drop_last loader' % (sb, sb2, world))
+    if isinstance(pend, tuple):          # (pair, world): the one-pair form (kept for callers that set it directly)
+        pend = {'pairs': [pend[0]], 'world': pend[1], 'worst': None}
+    world = pend['world']
+    cands = [] if pend['worst'] is None else [pend['worst']]
+    if pend['pairs']:
+        cands.append(_shard_violation(pend['pairs'], world))
+    if not cands:
+        return
+    viol, sb, sb2 = max((tuple(float(x) for x in c.cpu().tolist()) for c in cands), key=lambda t: t[0])
+    if viol > 0.5:
+        raise RuntimeError('data-parallel ranks hold different batch sizes (sum b = %g, sum b^2 = %g over %d ranks in one of the steps since the '
+                           'last check): SyncBN and the loss head need equal shards -- use a drop_last loader' % (sb, sb2, world))
 
 
 class MultiLossFn(torch.autograd.Function):
@@ -428,7 +467,7 @@ class MultiLossFn(torch.autograd.Function):
             stats[k:].copy_(_shard_pair(b, dev), non_blocking=True)
             _runtime.sync_all_reduce(stats, group)   # Dice / weighted CE are not shard-decomposable
             n_global = float(n) * dist.get_world_size(group)
-            _runtime.shard_check = (stats[k:], dist.get_world_size(group))
+            note_shard_pair(stats[k:], dist.get_world_size(group))
         losses = torch.empty(4, device=dev)
         check(lib.pylc_multiloss_finalize(ptr(stats), n_global, c, w_ce, w_dice, w_focal, ptr(losses), st))
         ctx.save_for_backward(logits, target, stats, class_weights)

@@ -66,7 +66,7 @@ class _Runtime:
         # PYLC_NO_PLANES=1: keep every activation fp32 (the conv kernels split operands themselves) -- A/B and bit-identity tests
         self.no_planes = bool(os.environ.get('PYLC_NO_PLANES'))
         self.comm = None              # native RCCL communicator handle (pylc_comm_init) when PYLC_COMM=native; None: torch.distributed carries the collectives
-        self.shard_check = None       # (reduced [sum b, sum b^2] device pair, world) of the last data-parallel loss exchange (ops.check_equal_shards)
+        self.shard_check = None       # pending equal-shard evidence: the reduced [sum b, sum b^2] pairs of EVERY data-parallel loss exchange since the host last looked (ops.note_shard_pair / ops.check_equal_shards)
         self.collectives = 0          # SyncBN / loss collectives issued (diagnostics: bench.py collectives_per_step)
         self.seed = 0x5EED
         self._counter = itertools.count(1)

@@ -94,16 +94,23 @@ assert all(torch.equal(g[0], torch.arange(2 * c + 1, dtype=torch.float32) * tri)
 # --- 3. equal shards ride on the loss exchange (ops.MultiLossFn appends [b, b^2] to its 3+3C statistics; ops.check_equal_shards compares
 #        the reduced pair where the host reads the loss log): no collective of its own, so a rank-local condition cannot desynchronise
 #        the ranks -- every rank raises, none hangs ---------------------------------------------------------------------------------
-for b_local, ok in ((4, True), (4 + (rank == world - 1), False)):
+def exchange(b_local):
     msg = torch.cat([torch.zeros(3 + 3 * 9), ops._shard_pair(b_local, torch.device('cpu'))])
     runtime.sync_all_reduce(msg, runtime.sync_group)
-    runtime.shard_check = (msg[3 + 3 * 9:], world)
+    ops.note_shard_pair(msg[3 + 3 * 9:], world)          # what MultiLossFn.forward does with its reduced message
+short = 4 - (rank == world - 1)                          # the last rank's loader runs out one tile early
+# equal steps only; a mismatched step alone; a mismatched step FOLLOWED by equal steps before the host looks (ADVICE r4: the pair used to be
+# overwritten per step, so this case passed); the same with enough steps in between that the pending pairs are folded on the device
+for steps, ok in (([4, 4, 4], True), ([short], False), ([4, short, 4, 4], False), ([short] + [4] * (ops.SHARD_PAIRS_MAX + 3), False),
+                  ([4] * (2 * ops.SHARD_PAIRS_MAX + 1), True)):
+    for b_local in steps:
+        exchange(b_local)
     try:
         ops.check_equal_shards()
-        assert ok, 'unequal shards were accepted'
+        assert ok, 'unequal shards were accepted: ' + str(steps[:6])
     except RuntimeError as e:
         assert not ok and 'equal shards' in str(e)
-assert runtime.shard_check is None
+    assert runtime.shard_check is None
 
 # --- 4. multi-GPU inference replicas (test.py:69-84 walks the tile batches of an image serially; here they are dealt round-robin
 #        over the ranks and the logit tiles are gathered to rank 0 in image order) -----------------------------------------------

@@ -71,29 +71,45 @@ CONV_FULL = [
     ('unet 64->64 3x3 valid @510^2 bs16 (unet.py:110)', 64, 64, 3, 1, 0, 1, 16, 510, 510, True),
     ('unet 128->128 3x3 valid, ragged @252^2 bs16 (unet.py:115)', 128, 128, 3, 1, 0, 1, 16, 252, 252, True),
     ('resnet layer1 64->256 1x1 @128^2 bs32 (resnet.py:26)', 64, 256, 1, 1, 0, 1, 32, 128, 128, False),
+    # round 5: the instantiations the stride-1 list left out -- stride 2 (one dgrad launch per output parity class),
+    # the strided 1x1 projection, the thin-input 7x7 stem, the other ASPP rates (per-tile tap skipping), the 304-channel decoder input
+    ('resnet layer2 128->128 3x3 stride 2 128^2->64^2 bs32 (resnet.py:22-23)', 128, 128, 3, 2, 1, 1, 32, 128, 128, False),
+    ('resnet layer2 projection 256->512 1x1 stride 2 128^2->64^2 bs32 (resnet.py:90-94)', 256, 512, 1, 2, 0, 1, 32, 128, 128, False),
+    ('resnet stem 3->64 7x7 stride 2 512^2->256^2 bs32 (resnet.py:72)', 3, 64, 7, 2, 3, 1, 32, 512, 512, False),
+    ('aspp 2048->256 3x3 d=6 @32^2 bs32 (aspp.py:18,61)', 2048, 256, 3, 1, 6, 6, 32, 32, 32, False),
+    ('aspp 2048->256 3x3 d=18 @32^2 bs32 (aspp.py:18,67)', 2048, 256, 3, 1, 18, 18, 32, 32, 32, False),
+    ('deeplab decoder 304->256 3x3 @128^2 bs32 (decoder.py:30)', 304, 256, 3, 1, 1, 1, 32, 128, 128, False),
 ]
 
 
-@pytest.mark.parametrize('case', CONV_FULL, ids=[c[0].split(' (')[0] for c in CONV_FULL])
-def test_conv_fwd_dgrad_wgrad_sampled_fp64(dev, f16x3_full, case):
+def _conv_case_sampled(dev, case, tol_fwd, tol_dx, tol_dw):
+    """One layer at true size through layers.Conv2d -> the C ABI; sampled outputs of y, dx, dw against float64 from gathered receptive
+    fields, errors relative to sum |a||b| of the same products.  Any stride (dgrad: the taps whose output coordinate is integral)."""
     from pylc_amd import ops, layers, optim
     name, cin, cout, k, st, pad, dil, B, H, W, bias = case
-    assert st == 1
     torch.manual_seed(7)
     conv = layers.Conv2d(cin, cout, k, st, pad, dil, bias=bias, init='kaiming').to(dev)
     arena = optim.FlatArena(conv)
-    x = _nhwc(11, B, cin, H, W, dev, scale=1.5).requires_grad_(True)
+    thin = cin % 4 != 0                       # the stem: the product feeds the 4-channel image pack (pylc_image_pack); no input gradient
+    xc = 4 if thin else cin
+    x = _nhwc(11, B, xc, H, W, dev, scale=1.5)
+    if not thin:
+        x.requires_grad_(True)
     planes0 = ops.planes_marked[0]
     y = conv(x)
     OH, OW = y.shape[2], y.shape[3]
+    assert (OH, OW) == ((H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1)
     dy = _nhwc(12, B, cout, OH, OW, dev)
     y.backward(dy)
     ops.sync_side_streams()
     torch.cuda.synchronize()
-    assert ops.planes_marked[0] > planes0, 'the layer did not take the fp16-plane kernels it takes in the training step'
-    yv, dx, dw = y.detach(), x.grad, conv.weight.grad.detach()
+    if not thin:
+        assert ops.planes_marked[0] > planes0, 'the layer did not take the fp16-plane kernels it takes in the training step'
+    yv, dw = y.detach(), conv.weight.grad.detach()
     xv, w = x.detach(), conv.weight.detach()
     w64 = w.double()
+    if thin:                                  # reference filter zero-padded to the pack's channel count
+        w64 = torch.cat([w64, torch.zeros(cout, xc - cin, k, k, dtype=torch.float64, device=dev)], 1)
     taps = torch.arange(k, device=dev)
 
     # ---- forward: gather [n, cin, k, k] receptive fields ----
@@ -101,7 +117,7 @@ def test_conv_fwd_dgrad_wgrad_sampled_fp64(dev, f16x3_full, case):
     ih = p[:, None] * st - pad + taps[None, :] * dil                           # [n, k]
     iw = q[:, None] * st - pad + taps[None, :] * dil
     okh, okw = (ih >= 0) & (ih < H), (iw >= 0) & (iw < W)
-    patch = xv[b[:, None, None, None], torch.arange(cin, device=dev)[None, :, None, None],
+    patch = xv[b[:, None, None, None], torch.arange(xc, device=dev)[None, :, None, None],
                ih.clamp(0, H - 1)[:, None, :, None], iw.clamp(0, W - 1)[:, None, None, :]].double()
     patch = patch * (okh[:, None, :, None] & okw[:, None, None, :])
     wsel = w64[o]                                                              # [n, cin, k, k]
@@ -112,22 +128,28 @@ def test_conv_fwd_dgrad_wgrad_sampled_fp64(dev, f16x3_full, case):
         mag = mag + conv.bias.detach().double().abs()[o]
     err = ((yv[b, o, p, q].double() - ref).abs() / mag).max().item()
     print('%s: fwd  max |y - fp64| / sum|ab| = %.3g over %d samples' % (name, err, N_SAMPLES))
-    assert err < 1e-6
+    assert err < tol_fwd
 
-    # ---- dgrad (stride 1): dx[b,c,h,w] = sum_{o,r,s} dy[b,o,h+pad-r d,w+pad-s d] w[o,c,r,s] ----
-    b, c, h, wq = _samples(22, N_SAMPLES, dev, B, cin, H, W)
-    oh = h[:, None] + pad - taps[None, :] * dil
-    ow = wq[:, None] + pad - taps[None, :] * dil
-    okh, okw = (oh >= 0) & (oh < OH), (ow >= 0) & (ow < OW)
-    gp = dy[b[:, None, None, None], torch.arange(cout, device=dev)[None, :, None, None],
-            oh.clamp(0, OH - 1)[:, None, :, None], ow.clamp(0, OW - 1)[:, None, None, :]].double()
-    gp = gp * (okh[:, None, :, None] & okw[:, None, None, :])
-    wsel = w64[:, c].permute(1, 0, 2, 3)                                       # [n, cout, k, k]
-    ref = (gp * wsel).sum((1, 2, 3))
-    mag = (gp.abs() * wsel.abs()).sum((1, 2, 3)) + 1e-30
-    err = ((dx[b, c, h, wq].double() - ref).abs() / mag).max().item()
-    print('%s: dgrad max |dx - fp64| / sum|ab| = %.3g' % (name, err))
-    assert err < 1e-6
+    # ---- dgrad: dx[b,c,h,w] = sum_{o,r,s} dy[b,o,(h+pad-r d)/st,(w+pad-s d)/st] w[o,c,r,s] over the taps with integral coordinates ----
+    if not thin:
+        dx = x.grad
+        b, c, h, wq = _samples(22, N_SAMPLES, dev, B, cin, H, W)
+        nh = h[:, None] + pad - taps[None, :] * dil
+        nw = wq[:, None] + pad - taps[None, :] * dil
+        oh, ow = torch.div(nh, st, rounding_mode='floor'), torch.div(nw, st, rounding_mode='floor')
+        okh = (nh >= 0) & (nh % st == 0) & (oh < OH)
+        okw = (nw >= 0) & (nw % st == 0) & (ow < OW)
+        gp = dy[b[:, None, None, None], torch.arange(cout, device=dev)[None, :, None, None],
+                oh.clamp(0, OH - 1)[:, None, :, None], ow.clamp(0, OW - 1)[:, None, None, :]].double()
+        gp = gp * (okh[:, None, :, None] & okw[:, None, None, :])
+        wsel = w64[:, c].permute(1, 0, 2, 3)                                   # [n, cout, k, k]
+        ref = (gp * wsel).sum((1, 2, 3))
+        mag = (gp.abs() * wsel.abs()).sum((1, 2, 3))
+        live = mag > 0                        # (stride 2, 1x1: three of four input pixels receive no gradient at all -- exact zeros)
+        assert (dx[b, c, h, wq][~live] == 0).all()
+        err = ((dx[b, c, h, wq].double() - ref).abs()[live] / mag[live]).max().item()
+        print('%s: dgrad max |dx - fp64| / sum|ab| = %.3g (%d live samples)' % (name, err, int(live.sum())))
+        assert err < tol_dx
 
     # ---- wgrad: 16 output x 16 input channels (first, last and random ones) x all taps, each a sum over all B*OH*OW pixels ----
     g = torch.Generator().manual_seed(23)
@@ -138,16 +160,105 @@ def test_conv_fwd_dgrad_wgrad_sampled_fp64(dev, f16x3_full, case):
     worst = 0.0
     for r in range(k):
         for s in range(k):
-            xw = xs[:, :, r * dil:r * dil + OH, s * dil:s * dil + OW]
+            xw = xs[:, :, r * dil:r * dil + (OH - 1) * st + 1:st, s * dil:s * dil + (OW - 1) * st + 1:st]
             ref = torch.einsum('bopq,bcpq->oc', dys, xw)
             mag = torch.einsum('bopq,bcpq->oc', dys.abs(), xw.abs())
             got = dw[osel][:, csel][:, :, r, s].double()
             worst = max(worst, ((got - ref).abs() / mag).max().item())
     print('%s: wgrad max |dw - fp64| / sum|ab| = %.3g over %d elements' % (name, worst, len(osel) * len(csel) * k * k))
-    assert worst < 2e-6
+    assert worst < tol_dw
     if bias:      # bias gradient = column sums of dy
         ref = dy.double().sum((0, 2, 3))
         assert ((conv.bias.grad.double() - ref).abs() / dy.double().abs().sum((0, 2, 3))).max().item() < 1e-6
+    del arena
+
+
+@pytest.mark.parametrize('case', CONV_FULL, ids=[c[0].split(' (')[0] for c in CONV_FULL])
+def test_conv_fwd_dgrad_wgrad_sampled_fp64(dev, f16x3_full, case):
+    _conv_case_sampled(dev, case, 1e-6, 1e-6, 2e-6)
+
+
+# precision mode 3 (BASELINE configs[4]: Xception, 1024^2 tiles, bs 8): ONE fp16 plane per operand.  Each operand element carries a relative
+# rounding of at most 2^-12 (round to nearest, 11 significant bits, scaled per tensor so that nothing is subnormal near the maximum), so
+# every product is off by at most (2^-11 + 2^-24) |a||b| and a sum by that times sum|a||b| -- a strict bound, not a statistical one
+# (test_planes_gpu.py::test_conv_mode3_single_plane_against_fp64 measures 1e-4..3.7e-4 of the largest output at small sizes); fp32 accumulation
+# and the split-K slabs add the f16x3 bound on top.
+MODE3_TOL = 2.0 ** -11 * 1.01 + 2e-6
+CONV_FULL_MODE3 = [
+    ('xception middle-flow pointwise 728->728 1x1 @64^2 bs8 (xception.py:25-39)', 728, 728, 1, 1, 0, 1, 8, 64, 64, False),
+    ('deeplab decoder 256->256 3x3 @256^2 bs8 (decoder.py:30 at 1024^2 tiles)', 256, 256, 3, 1, 1, 1, 8, 256, 256, False),
+    ('xception entry pointwise 128->128 1x1 @512^2 bs8 (xception.py:32,122)', 128, 128, 1, 1, 0, 1, 8, 512, 512, False),
+    ('xception exit pointwise 1536->2048 1x1 @64^2 bs8 (xception.py:157)', 1536, 2048, 1, 1, 0, 1, 8, 64, 64, False),
+]
+
+
+@pytest.fixture
+def mode3_full(dev):
+    from pylc_amd.lib import lib, check
+    from pylc_amd import runtime
+    prev, prev_drop = lib.pylc_get_conv_precision(), runtime.dropout_enabled
+    check(lib.pylc_set_conv_precision(3))
+    runtime.dropout_enabled = False
+    yield
+    runtime.dropout_enabled = prev_drop
+    check(lib.pylc_set_conv_precision(prev))
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('case', CONV_FULL_MODE3, ids=[c[0].split(' (')[0] for c in CONV_FULL_MODE3])
+def test_conv_mode3_fwd_dgrad_wgrad_sampled_fp64(dev, mode3_full, case):
+    """gg_pl_kernel<1,*> / gg_plh_kernel<1> (128-byte LDS rows) and wgrad_pl's one-plane instantiations at configs[4]'s sizes."""
+    from pylc_amd import ops
+    assert ops.nplanes() == 1
+    _conv_case_sampled(dev, case, MODE3_TOL, MODE3_TOL, MODE3_TOL)
+
+
+@pytest.mark.parametrize('c,b,h,w,stride,dil', [(128, 8, 512, 512, 1, 1), (128, 8, 512, 512, 2, 1), (1536, 8, 64, 64, 1, 2), (728, 8, 64, 64, 1, 1)],
+                         ids=['entry 128 @512^2 stride 1', 'entry 128 @512^2 stride 2', 'exit 1536 @64^2 dilation 2', 'middle 728 @64^2'])
+def test_half_depthwise_tiled_kernels_fullsize(dev, c, b, h, w, stride, dil):
+    """dw_tile_kernel / dw_tileg_kernel (one-plane fp16 tensors: stride 1, stride 2, dilation 2; xception.py:25-39 SeparableConv2d with
+    fixed_padding) at the sizes of configs[4] (bs 8, 1024^2 tiles) -- the complete check of tests/test_round3_gpu.py (forward + statistics,
+    fresh / accumulating / fp32 / masked-residual data gradients, filter gradient, all against a float64 depthwise conv on the device of the
+    values the kernels see), run at true size."""
+    from tests.test_round3_gpu import test_half_depthwise_kernels_against_fp64 as dw_case
+    dw_case(dev, c, b, h, w, stride, dil, 3)
+    torch.cuda.empty_cache()
+
+
+def test_dgrad_with_masked_residual_gradient_fullsize(dev, f16x3_full):
+    """pylc_conv2d_dgrad_add at the size of a layer3 block's first conv (1024 -> 256 1x1 @32^2 bs 32, resnet.py:20,36-51): the data gradient of
+    the conv PLUS the block's residual gradient relu'(out) * dout, formed in the dgrad epilogue from dout and the 1-bit ReLU mask that the
+    block's last BatchNorm parked on the gradient link (ops.ResidualLink.masked).  2048 sampled elements against float64."""
+    from pylc_amd import ops, layers, optim
+    B, cin, cout, H, W = 32, 1024, 256, 32, 32
+    torch.manual_seed(9)
+    conv = layers.Conv2d(cin, cout, 1, 1, 0, 1, init='kaiming').to(dev)
+    arena = optim.FlatArena(conv)
+    x = ops.to_planes(_nhwc(61, B, cin, H, W, dev, scale=1.5)).requires_grad_(True)
+    link = ops.ResidualLink()
+    y = ops.conv2d(x, conv.weight, None, 1, 0, 1, res_link=link)
+    assert link.armed
+    dy = _nhwc(62, B, cout, H, W, dev)
+    dout = ops.empty_nhwc(B, cin, H, W, dev)
+    dout.copy_(_nhwc(63, B, cin, H, W, dev))
+    keep = torch.rand(B, H, W, cin, generator=torch.Generator(device=dev).manual_seed(64), device=dev) > 0.45      # NHWC element order
+    mask = (keep.view(-1, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(1).to(torch.uint8)   # element e -> bit e & 7 of byte e >> 3
+    link.masked = (dout, mask)
+    y.backward(ops.to_planes(dy))
+    ops.sync_side_streams()
+    torch.cuda.synchronize()
+    assert link.masked is None, 'the dgrad did not consume the parked (dout, mask) pair in its epilogue'
+    dx = x.grad
+    assert dx is not None and not ops.is_planes(dx)
+    w64 = conv.weight.detach().double()[:, :, 0, 0]                            # [cout, cin]
+    b, c, h, wq = _samples(65, N_SAMPLES, dev, B, cin, H, W)
+    g = dy[b, :, h, wq].double()                                               # [n, cout]
+    ref = (g * w64[:, c].t()).sum(1)
+    mag = (g.abs() * w64[:, c].t().abs()).sum(1)
+    res = dout[b, c, h, wq].double() * keep[b, h, wq, c]
+    err = ((dx[b, c, h, wq].double() - (ref + res)).abs() / (mag + res.abs())).max().item()
+    print('dgrad + masked residual 1024<-256 @32^2 bs32: max |dx - fp64| / (sum|ab| + |res|) = %.3g' % err)
+    assert err < 1e-6
     del arena
 
 

@@ -325,11 +325,14 @@ if world > 1:
     m.meta.report = 10 ** 9
     xs, ys = (x[:per - 1], y[:per - 1]) if rank == world - 1 else (x, y)
     m.train(xs, ys)
+    m.train(x, y)            # ... and a full-size step follows BEFORE the host looks: the short step must still be reported (ADVICE r4)
     try:
         m.log()
         raise SystemExit('unequal shards were accepted')
     except RuntimeError as e:
         assert 'equal shards' in str(e), e
+    m.train(x, y)            # equal steps only since the last look: nothing to report
+    m.log()
     parallel.barrier()
 if rank == 0:
     print('RESULT', *out, rm, ncoll + (len(m._bucketer.buckets) if world > 1 else 0))
