@@ -8,7 +8,7 @@ int conv_init();
 
 extern "C" const char* pylc_last_error(void) { return pylc::g_err; }
 
-extern "C" int pylc_abi_version(void) { return 10; }
+extern "C" int pylc_abi_version(void) { return 11; }
 
 extern "C" int pylc_init(void) {
     int ndev = 0;

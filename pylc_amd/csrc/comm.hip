@@ -10,6 +10,7 @@
 // PYLC_ERR_UNSUPPORTED with the loader's message.  Every call is enqueued on the caller's stream; nothing here synchronises.
 #include "common.h"
 #include <dlfcn.h>
+#include <mutex>
 
 namespace pylc {
 namespace {
@@ -28,11 +29,16 @@ struct Rccl {
     char why[256] = "";
 };
 
+void rccl_resolve(Rccl& r);
+
 Rccl& rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static std::once_flag once;          // two host threads may enter their first pylc_comm_* call together
+    std::call_once(once, [] { rccl_resolve(r); });
+    return r;
+}
+
+void rccl_resolve(Rccl& r) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);      // the copy already in the process (torch's), if any
@@ -44,18 +50,17 @@ Rccl& rccl() {
     }
     if (!r.handle) {
         snprintf(r.why, sizeof(r.why), "librccl.so.1 not loadable: %s", dlerror());
-        return r;
+        return;
     }
 #define PYLC_SYM(field, name)                                                       \
     *reinterpret_cast<void**>(&r.field) = dlsym(r.handle, name);                   \
-    if (!r.field) { snprintf(r.why, sizeof(r.why), "RCCL symbol %s missing", name); r.handle = nullptr; return r; }
+    if (!r.field) { snprintf(r.why, sizeof(r.why), "RCCL symbol %s missing", name); r.handle = nullptr; return; }
     PYLC_SYM(GetUniqueId, "ncclGetUniqueId")
     PYLC_SYM(CommInitRank, "ncclCommInitRank")
     PYLC_SYM(AllReduce, "ncclAllReduce")
     PYLC_SYM(CommDestroy, "ncclCommDestroy")
     PYLC_SYM(GetErrorString, "ncclGetErrorString")
 #undef PYLC_SYM
-    return r;
 }
 
 struct Comm { NcclComm comm; int rank, world; };

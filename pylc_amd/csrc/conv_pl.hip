@@ -1116,8 +1116,10 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
                       (a.bias == nullptr || a.ep_scale != nullptr) && a.y_pitch == a.N_store && a.N_store % 8 == 0),
                  "conv with an fp16-plane output: needs out_bound, the operand ranges and a dense y of a multiple of 8 channels; no accumulation, residual-gradient source or BatchNorm sums "
                  "(a bias only with the fused inference epilogue)");
-    PYLC_REQUIRE(a.ep_res == nullptr || a.ep_res_fmt == 0 || (a.ep_res_scale != nullptr && a.y_pitch == a.N_store && a.N_store % 4 == 0),
-                 "conv with a fused fp16-plane residual: needs the residual's scale bound and a dense y");
+    // (fetch_res pairs lanes l / l + 16 -- adjacent channel quads -- through permlane16_swap and reads 16 bytes = 8 channels per pair: with
+    //  N_store % 8 == 4 the last quad would have no partner and its load would run past the row)
+    PYLC_REQUIRE(a.ep_res == nullptr || a.ep_res_fmt == 0 || (a.ep_res_scale != nullptr && a.y_pitch == a.N_store && a.N_store % 8 == 0),
+                 "conv with a fused fp16-plane residual: needs the residual's scale bound and a dense y of a multiple of 8 channels");
     PYLC_REQUIRE(!(a.ep_scale != nullptr || a.out_planes2 || a.ep_res != nullptr) || (a.stats == nullptr && !a.accumulate && a.add_src == nullptr && a.bn_y == nullptr),
                  "conv with the fused inference epilogue: no statistics, accumulation or backward fusions");
     PYLC_REQUIRE(a.add_src == nullptr || (a.y_pitch == a.N_store && a.N_store % 8 == 0 && !a.accumulate),

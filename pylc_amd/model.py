@@ -90,6 +90,7 @@ class LossLog:
         """RunningLoss.load (loss.py:253-268): with resume, take up train / valid / test / best_dice from the file (the reference does not
         restore `lr`); without, an existing file is deleted and tracking restarts.  Returns True if a file was resumed from."""
         import os
+        import pickle
         if not os.path.exists(path):
             return False
         if not resume:
@@ -103,9 +104,16 @@ class LossLog:
             res = load_losses_file(path)
             rows = {k: [(int(row[0]),) + tuple(float(v) for v in row[1:]) for row in res.get(k, [])] for k in ('train', 'valid', 'test')}
             best = float(res['best_dice'])
-        except Exception as e:      # an unreadable log must not abort the resume of the weights: restart the log
+        except (pickle.UnpicklingError, EOFError, ValueError, KeyError, TypeError, IndexError, RuntimeError) as e:      # (torch raises RuntimeError for a torn zip)
+            # A damaged or foreign-format log.  The reference fails here (torch.load raises, loss.py:259); restarting the log silently would
+            # reset best_dice to 1.0 and let the first validation overwrite the best-model file with a possibly worse model.  So: fail like the
+            # reference unless the caller opted in (PYLC_RESTART_LOSS_LOG=1), and never swallow anything but read / format errors -- an
+            # allow-list miss of the tolerant unpickler is an UnpicklingError whose text names the class, a format-compat regression signal.
+            if os.environ.get('PYLC_RESTART_LOSS_LOG') != '1':
+                raise RuntimeError('losses.pth at %s is unreadable (%s: %s); fix or remove it, or set PYLC_RESTART_LOSS_LOG=1 to restart the '
+                                   'loss log (best-Dice tracking restarts with it)' % (path, type(e).__name__, e)) from e
             import warnings
-            warnings.warn('losses.pth at %s is unreadable (%s: %s); the loss log restarts' % (path, type(e).__name__, e))
+            warnings.warn('losses.pth at %s is unreadable (%s: %s); the loss log restarts (PYLC_RESTART_LOSS_LOG=1)' % (path, type(e).__name__, e))
             return False
         self.train, self.valid, self.test = rows['train'], rows['valid'], rows['test']
         self.best_dice = best

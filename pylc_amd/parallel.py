@@ -56,15 +56,35 @@ def init_from_env(backend=None):
     runtime.grad_group = dist.new_group(backend=backend) if separate else dist.group.WORLD
     runtime.manual_seed(runtime.seed, rank)
     if backend == 'nccl' and os.environ.get('PYLC_COMM') == 'native':
-        init_native_comm(rank, world)
+        try_native_comm(rank, world)
     return rank, world
 
 
-def init_native_comm(rank, world):
-    """PYLC_COMM=native: the SyncBN / loss / gradient collectives go through the C ABI's own RCCL communicator (include/pylc_hip.h
-    pylc_comm_*) instead of torch.distributed's: a collective is then ONE ctypes call that enqueues ncclAllReduce on the stream the kernels
-    run on -- no Python work object, no hop to a communication stream and back.  torch.distributed stays the side channel that carries the
-    128-byte communicator id from rank 0 (and the barrier / parameter broadcast at set-up)."""
+def try_native_comm(rank, world):
+    """PYLC_COMM=native with a fall-back: if the C ABI's communicator cannot be brought up (no loadable RCCL, ncclCommInitRank failing),
+    the run continues on the torch.distributed path -- the decision is taken by ALL ranks together (a MIN all-reduce of the local outcome: one
+    rank on native and its peers on torch.distributed would wait for each other forever) and the reason is logged once per rank."""
+    ok, why = 1, ''
+    try:
+        init_native_comm(rank, world)
+    except Exception as e:          # PylcError (PYLC_ERR_UNSUPPORTED: RCCL not loadable; PYLC_ERR_HIP: RCCL error) or a ctypes failure
+        ok, why = 0, '%s: %s' % (type(e).__name__, e)
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_ok = int(flag.item()) == 1
+    else:
+        all_ok = bool(ok)
+    if not all_ok:
+        import sys
+        destroy_native_comm()
+        print('[pylc_amd] rank %d: PYLC_COMM=native unavailable (%s); collectives stay on torch.distributed'
+              % (rank, why or 'another rank could not create its communicator'), file=sys.stderr, flush=True)
+    return all_ok
+
+
+def _native_communicator(rank, world):
+    """One RCCL communicator behind the C ABI (pylc_comm_init); torch.distributed is the side channel for rank 0's 128-byte id."""
     import ctypes as C
     from .lib import lib, check
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -78,7 +98,35 @@ def init_native_comm(rank, world):
     raw = bytes(ident.cpu().numpy().tobytes())
     handle = C.c_void_p()
     check(lib.pylc_comm_init(raw, rank, world, C.byref(handle)))
-    runtime.comm = handle
+    return handle
+
+
+def init_native_comm(rank, world):
+    """PYLC_COMM=native: the SyncBN / loss / gradient collectives go through the C ABI's own RCCL communicators (include/pylc_hip.h
+    pylc_comm_*) instead of torch.distributed's: a collective is then ONE ctypes call that enqueues ncclAllReduce on a stream of ours -- no
+    Python work object, no hop to a communication stream and back.  TWO communicators (PYLC_SEPARATE_GRAD_COMM=0: one):
+      * runtime.comm       SyncBN and loss messages, enqueued on the COMPUTE stream (they sit on the critical chain);
+      * runtime.grad_comm  the 64 MB gradient buckets, enqueued on a dedicated communication stream (GradBucketer) behind events of both
+                           producers of a bucket -- on one communicator a 2 KB SyncBN message would queue behind a 64 MB bucket that itself
+                           waits for the wgrads (stream-ordered RCCL serialises a communicator's collectives in enqueue order).
+    Every rank enqueues each communicator's collectives in the same program order; the two never wait for each other on the host, and the
+    compute stream waits for the bucket stream only in GradBucketer.finish(), before the optimiser.  torch.distributed stays the side
+    channel that carries the communicator ids from rank 0 (and the barrier / parameter broadcast at set-up)."""
+    runtime.comm = _native_communicator(rank, world)
+    if os.environ.get('PYLC_SEPARATE_GRAD_COMM', '1') != '0':
+        runtime.grad_comm = _native_communicator(rank, world)
+    else:
+        runtime.grad_comm = runtime.comm
+
+
+def destroy_native_comm():
+    from .lib import lib
+    for h in {id(h): h for h in (runtime.comm, runtime.grad_comm) if h is not None}.values():
+        try:
+            lib.pylc_comm_destroy(h)
+        except Exception:
+            pass
+    runtime.comm = runtime.grad_comm = None
 
 
 class GradBucketer:
@@ -123,27 +171,42 @@ class GradBucketer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.pending[b] = -1
-        # The bucket holds conv gradients written on the wgrad side stream and BatchNorm gradients written on the compute
-        # stream.  The collective is ordered after BOTH by enqueueing it from the side stream once that stream has been
-        # told to wait for the compute stream's current position -- the compute stream itself never waits here.
+        # The bucket holds conv gradients written on the wgrad side stream and BatchNorm gradients written on the compute stream; the
+        # collective must be ordered after BOTH, and neither producer stream may wait for it.
         from . import ops
         side = ops.side_stream_if_any(self.arena.g.device)
-        native = runtime.comm is not None and self.arena.g.is_cuda
-        if side is None:
-            if native:
-                runtime.native_all_reduce(self.arena.g[lo:hi])          # on the compute stream, behind the kernels that wrote the bucket
-            else:
-                self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        native = runtime.grad_comm is not None and self.arena.g.is_cuda
+        if native:
+            # native communicator: ncclAllReduce is stream-ordered, so it goes on a communication stream of its own that first waits for
+            # an event of each producer -- on the wgrad stream itself (round 4) every later wgrad queued behind a 64 MB exchange
+            cs = self._comm_stream()
+            ev = torch.cuda.Event()
+            ev.record()                                     # compute stream: BatchNorm / bias gradients of the bucket
+            cs.wait_event(ev)
+            if side is not None:
+                ev2 = torch.cuda.Event()
+                ev2.record(side)                            # wgrad stream: the conv gradients of the bucket
+                cs.wait_event(ev2)
+            with torch.cuda.stream(cs):
+                runtime.native_all_reduce(self.arena.g[lo:hi], runtime.grad_comm)
+            self._native_pending = True
             return
+        if side is None:
+            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # torch.distributed: the work object orders the collective (on RCCL's own stream) after the stream it is issued from -- the side
+        # stream, once that has been told to wait for the compute stream's current position
         ev = torch.cuda.Event()
         ev.record()
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            if native:
-                runtime.native_all_reduce(self.arena.g[lo:hi])          # on the side stream; finish() makes the compute stream wait for it
-                self._native_side = side
-            else:
-                self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _comm_stream(self):
+        cs = getattr(self, '_cs', None)
+        if cs is None:
+            cs = self._cs = torch.cuda.Stream(device=self.arena.g.device)
+        return cs
 
     def finish(self):
         """Launch whatever did not complete on its own (parameters without a gradient this step) and wait for all."""
@@ -153,10 +216,9 @@ class GradBucketer:
         for w in self.works:
             w.wait()
         self.works = []
-        side = getattr(self, '_native_side', None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)           # the optimiser reads the reduced arena on the compute stream
-            self._native_side = None
+        if getattr(self, '_native_pending', False):
+            torch.cuda.current_stream().wait_stream(self._cs)           # the optimiser reads the reduced arena on the compute stream
+            self._native_pending = False
 
 
 def bucket_ranges(numel, bucket=BUCKET_FLOATS):
@@ -206,7 +268,7 @@ def init_single_rank_group():
     runtime.sync_group = dist.group.WORLD
     runtime.grad_group = dist.group.WORLD
     if os.environ.get('PYLC_COMM') == 'native':
-        init_native_comm(0, 1)
+        try_native_comm(0, 1)
 
 
 def rank():

@@ -66,6 +66,7 @@ class _Runtime:
         # PYLC_NO_PLANES=1: keep every activation fp32 (the conv kernels split operands themselves) -- A/B and bit-identity tests
         self.no_planes = bool(os.environ.get('PYLC_NO_PLANES'))
         self.comm = None              # native RCCL communicator handle (pylc_comm_init) when PYLC_COMM=native; None: torch.distributed carries the collectives
+        self.grad_comm = None         # ... and the second one, for the gradient buckets (parallel.init_native_comm)
         self.shard_check = None       # pending equal-shard evidence: the reduced [sum b, sum b^2] pairs of EVERY data-parallel loss exchange since the host last looked (ops.note_shard_pair / ops.check_equal_shards)
         self.collectives = 0          # SyncBN / loss collectives issued (diagnostics: bench.py collectives_per_step)
         self.seed = 0x5EED
@@ -74,21 +75,27 @@ class _Runtime:
     def sync_all_reduce(self, t, group):
         """The SUM all-reduce of a SyncBN / loss statistics message (counted).  With a native communicator (PYLC_COMM=native,
         parallel.init_native_comm) the message goes through the C ABI -- pylc_comm_allreduce, enqueued on the CURRENT stream: no work
-        object, no stream hop --, else through torch.distributed."""
+        object, no stream hop --, else (or for a message the C ABI does not take: not fp32 / fp64, not contiguous) through torch.distributed."""
         self.collectives += 1
-        if self.comm is not None and t.is_cuda and group is self.sync_group:
+        if self.comm is not None and t.is_cuda and group is self.sync_group and self.native_takes(t):
             self.native_all_reduce(t)
             return
         import torch.distributed as dist
         dist.all_reduce(t, group=group)
 
-    def native_all_reduce(self, t):
-        """In-place SUM all-reduce of a contiguous fp32 / fp64 device tensor on the current stream through pylc_comm_allreduce."""
+    @staticmethod
+    def native_takes(t):
+        import torch
+        return t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+
+    def native_all_reduce(self, t, comm=None):
+        """In-place SUM all-reduce of a contiguous fp32 / fp64 device tensor on the current stream through pylc_comm_allreduce
+        (`comm`: the communicator; default the SyncBN / loss one)."""
         import torch
         from .lib import lib, check, ptr, stream
-        if not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64):
+        if not self.native_takes(t):
             raise ValueError('native all-reduce takes contiguous fp32 / fp64 tensors, got %s %s' % (t.dtype, tuple(t.stride())))
-        check(lib.pylc_comm_allreduce(self.comm, ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, stream()))
+        check(lib.pylc_comm_allreduce(comm if comm is not None else self.comm, ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, stream()))
 
     def next_seed(self):
         """Distinct, reproducible seed per dropout call (rank-offset so data-parallel ranks draw different masks)."""

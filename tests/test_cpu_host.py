@@ -240,7 +240,7 @@ def test_reference_written_loss_log_resumes(tmp_path):
     `.cpu().numpy()` values, models/model.py:360-363, loss.py:284-304), which torch.load(weights_only=True) refuses.
     tests/golden/ref_losses_tiny.pth was written by the reference's RunningLoss.save (make_checkpoint_fixture.py); LossLog.load must take
     it through the allow-listed unpickler, coerce every entry to python floats, and `load_into(..., resume=True)` must not raise for a
-    reference directory that holds a losses.pth.  An unreadable file restarts the log with a warning instead of aborting the resume."""
+    reference directory that holds a losses.pth.  An unreadable file raises (the reference's behaviour) unless PYLC_RESTART_LOSS_LOG=1."""
     import json
     import shutil
     import warnings
@@ -257,14 +257,23 @@ def test_reference_written_loss_log_resumes(tmp_path):
     out = str(tmp_path / 'again.pth')
     log.save(out)                                               # and what we write back stays loadable by the strict loader
     assert torch.load(out, weights_only=True)['best_dice'] == want['best_dice']
-    # a torn / foreign file: warn, restart the log, keep going
+    # a torn / foreign file fails loudly, like the reference (torch.load raises at loss.py:259): silently restarting would reset best_dice and
+    # let the first validation overwrite the best-model file ...
     bad = str(tmp_path / 'losses.pth')
     open(bad, 'wb').write(b'not a zip')
     fresh = LossLog()
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-        assert fresh.load(bad, resume=True) is False and fresh.train == [] and fresh.best_dice == 1.0
-    assert any('loss log restarts' in str(x.message) for x in w)
+    with pytest.raises(RuntimeError, match='unreadable'):
+        fresh.load(bad, resume=True)
+    assert fresh.train == [] and fresh.best_dice == 1.0
+    # ... unless the caller opts in to restarting the log
+    os.environ['PYLC_RESTART_LOSS_LOG'] = '1'
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            assert fresh.load(bad, resume=True) is False and fresh.train == [] and fresh.best_dice == 1.0
+        assert any('loss log restarts' in str(x.message) for x in w)
+    finally:
+        del os.environ['PYLC_RESTART_LOSS_LOG']
     # checkpoint.load_into(resume=True) next to a reference-written losses.pth (the tiny stem checkpoint needs a matching net)
     from torch import nn
     from pylc_amd import checkpoint as ck, layers, optim
