@@ -79,6 +79,13 @@ typedef struct PylcConvDesc {
      * no bias, no accumulation. */
     int out_fmt;
     unsigned int* out_bound;
+    /* Layout of the prepared filter planes (round 5): bit 0 = w_planes, bit 1 = w_planes_t are CHUNK-INTERLEAVED -- the flat element
+     * index e of the [rows][R*S][channels] filter maps to halves (e >> 5) * 64 + (e & 31) for plane 0 and + 32 for plane 1, i.e. the two
+     * planes of a 32-channel chunk (one K-step of the conv kernels) share ONE 128-byte line; 0 = two separate plane arrays.  What
+     * pylc_weight_prepare(..., interleave = 1) writes for a filter whose channel count (w_planes: Cin; w_planes_t: roundup4(Cout)) is a
+     * multiple of 32.  Why: LDS-DMA moves 64-byte pieces of a row per K-step; with separate planes each piece is HALF a cache line and the
+     * L2 -> LDS path delivers 21.8 TB/s, with both halves of a line requested back to back 31.7 TB/s (profiles/r04_dma_piece.txt). */
+    int w_planes_fmt;
 } PylcConvDesc;
 
 /* Arithmetic of the dense conv kernels (process-wide):
@@ -118,8 +125,11 @@ typedef struct PylcWPrepEntry {
  * receives max |w_out| as float bits, the filter range of the f16x3 arithmetic.  Done once per set of weights, not per batch. */
 int pylc_conv1x1_fold_input_affine(const float* w, const float* scale, const float* shift, const float* bias_in, int Cout, int Cin,
                                    float* w_out, float* bias_out, unsigned int* amax_out, void* stream);
+/* interleave != 0: filters whose channel count is a multiple of 32 are written chunk-interleaved (PylcConvDesc.w_planes_fmt), per layout:
+ * the forward planes if C % 32 == 0, the dgrad planes if roundup4(K) % 32 == 0; the others (and everything with interleave = 0) as two
+ * separate plane arrays. */
 int pylc_weight_prepare(const float* base, const PylcWPrepEntry* table, int count, long long total_tiles,
-                        const unsigned int* amax, void* planes, void* stream);
+                        const unsigned int* amax, void* planes, int interleave, void* stream);
 /* out = bits(factor * float(a) * float(b) [+ float(add)]): a range BOUND for a tensor that is bilinear in two ranged operands -- a depthwise
  * 3x3 output, |y| <= 9 max|w| max|x|; a conv output with bias, |y| <= Cin R S max|w| max|x| + max|bias| (add_bits, may be NULL) -- instead of
  * a read pass over it (the f16x3 arithmetic needs a float >= max|element| within 2^29 of the small elements that matter, not the maximum) */

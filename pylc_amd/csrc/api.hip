@@ -8,7 +8,7 @@ int conv_init();
 
 extern "C" const char* pylc_last_error(void) { return pylc::g_err; }
 
-extern "C" int pylc_abi_version(void) { return 11; }
+extern "C" int pylc_abi_version(void) { return 11; }      // r5: pylc_comm_*, PylcFwdEp, PylcConvDesc.w_planes_fmt, pylc_weight_prepare(interleave)
 
 extern "C" int pylc_init(void) {
     int ndev = 0;

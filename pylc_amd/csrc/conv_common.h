@@ -146,6 +146,7 @@ struct GatherGemmArgs {
     const void* w_planes;         // optional: the filter already split into two fp16 planes (pylc_weight_prepare), same
                                   // indexing as w, plane 1 at + w_plane_stride halves; scaled with the amax behind amax_w
     long long w_plane_stride;
+    int w_il;                     // the filter planes are chunk-interleaved (PylcConvDesc.w_planes_fmt): plane 1 at + 32 halves, a 32-channel chunk every 64 halves
     const void* x_planes;         // optional: the A operand (activations / incoming gradient) already split into two fp16 planes by its
                                   // producer with the scale behind amax_x: plane p at + p * x_plane_stride halves, element (pixel, c) at
                                   // pixel * x_pitch + c (conv_pl.hip takes these launches)

@@ -584,8 +584,10 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
     for (int i = 0; i < 2; ++i)       // byte offset of (row's pixel at tap offset (0,0), channel 8v); garbage for invalid rows (masked by rowh)
         xoff[i] = ((unsigned)(rowpix[i] + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * v) * 4u;
     const int bn = n0 + brow;
-    const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride + 8u * v) * (BPL ? 2u : 4u) : OOB;
-    const unsigned plane1 = (unsigned)(a.w_plane_stride * 2);
+    // (chunk-interleaved filter planes, a.w_il: row and chunk offsets double, plane 1 sits 64 bytes behind plane 0)
+    const unsigned wil = (BPL && a.w_il) ? 2u : 1u;
+    const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride * wil + 8u * v) * (BPL ? 2u : 4u) : OOB;
+    const unsigned plane1 = (BPL && a.w_il) ? 64u : (unsigned)(a.w_plane_stride * 2);
     auto ldx = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4& lo, f32x4& hi) {
         lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
         hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0));
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             ldx(rx, ok ? xoff[i] + tapdelta : OOB, 0u, R.a[i][0], R.a[i][1]);
         }
         if constexpr (BPL) {       // 8 halves of plane 0 and of plane 1
-            const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2);
+            const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2) * wil;
             R.b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row : OOB, so, 0));
             if constexpr (!ONE) R.b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row + plane1 : OOB, so, 0));
         } else {
@@ -1787,6 +1789,7 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     a.x_bytes = (((long long)d->B * d->H * d->W - 1) * d->x_pitch + d->Cin) * 4;
     a.w_bytes = (long long)d->Cout * d->R * d->S * d->Cin * 4;
     a.w_planes = d->w_planes; a.w_plane_stride = (long long)d->Cout * d->R * d->S * d->Cin;
+    a.w_il = (d->w_planes != nullptr && (d->w_planes_fmt & 1)) ? 1 : 0;
     if (d->x_fmt == 1) {                     // x points at plane 0 of an fp16-plane tensor
         a.x_planes = x; a.x = nullptr;
         a.x_plane_stride = (long long)d->B * d->H * d->W * d->x_pitch;
@@ -1885,6 +1888,7 @@ extern "C" int pylc_conv2d_dgrad_bn(const PylcConvDesc* d, const float* dy, cons
     a.x_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + Kp) * 4;
     a.w_bytes = (long long)d->Cin * d->R * d->S * Kp * 4;
     a.w_planes = d->w_planes_t; a.w_plane_stride = (long long)d->Cin * d->R * d->S * Kp;
+    a.w_il = (d->w_planes_t != nullptr && (d->w_planes_fmt & 2)) ? 1 : 0;
     if (d->dy_fmt == 1) {
         a.x_planes = dy; a.x = nullptr;
         a.x_plane_stride = (long long)d->B * d->OH * d->OW * d->y_pitch;

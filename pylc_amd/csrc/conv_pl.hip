@@ -186,6 +186,87 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
     }
 }
 
+// The BatchNorm-backward mode (BNB kernels, pylc_conv2d_dgrad_bn: the tile being stored is the gradient `dout` of a BatchNorm OUTPUT, so the
+// sums that BatchNorm's backward needs first -- sum g and sum g xhat with g = relu'(dout), xhat = (y_bn - mean) invstd -- are taken here, from
+// the registers, instead of by a read pass over (dout, y_bn) (bn.hip bn_reduce_kernel<1>).  The y_bn tile has the output's geometry (dense).
+// Per element: y = c t (+ masked residual gradient), g = relu' y, sum g xhat, sum g, max |g| (the range bound of the dy to come).  Partial row
+// layout = bn_reduce_kernel<1>'s: [sum g xhat | sum g].  ReLU by the 1-bit mask of bn.hip, or recomputed as y_bn scale + shift > 0 (the
+// forward's own expression), or none.  EDGE: rows / channel quads past the tensor's edge are neither loaded, stored nor counted.
+// Returns max |g| of this lane.
+template <int AM, int PREV, bool EDGE>
+__device__ __forceinline__ float pl_epilogue_bn(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], const int* rowoff, float* sdst, int nb, int wave_m,
+                                                int lane, float c, const float* extra, const unsigned char* amask) {
+    constexpr int AT = 4, WM = 16 * AM;
+    int offs[AM];                       // element offset of this lane's channel quad in row i (< 0: no such row)
+#pragma unroll
+    for (int i = 0; i < AM; ++i) {
+        const int ro = rowoff[wave_m * WM + i * 16 + (lane & 15)];
+        offs[i] = (EDGE && ro < 0) ? -(1 << 30) : ro + nb;
+    }
+    float gmax = 0.f;
+    const bool relu = a.bn_relu != 0, bits = a.bn_mask != nullptr;
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < AT; ++j) {
+        const bool cok = !EDGE || nb + j * 16 < a.N_store;          // N_store % 4 == 0: all four channels or none
+        f32x4v mu = zero, is = zero, sc = zero, sf = zero;
+        if (cok) {
+            mu = *reinterpret_cast<const f32x4v*>(a.bn_mean + nb + j * 16);
+            is = *reinterpret_cast<const f32x4v*>(a.bn_invstd + nb + j * 16);
+            if (relu && !bits) { sc = *reinterpret_cast<const f32x4v*>(a.bn_scale + nb + j * 16); sf = *reinterpret_cast<const f32x4v*>(a.bn_shift + nb + j * 16); }
+        }
+        f32x4v prev[PREV ? AM : 1], yv[AM];
+        unsigned mb[PREV == 2 ? AM : 1], ym[AM];
+        bool ok[AM];
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            ok[i] = !EDGE || (cok && offs[i] >= 0);
+            const unsigned e = (unsigned)(offs[i] + j * 16);
+            yv[i] = ok[i] ? *reinterpret_cast<const f32x4v*>(a.bn_y + e) : zero;
+            ym[i] = (relu && bits && ok[i]) ? (unsigned)a.bn_mask[e >> 3] : 0xFFu;
+            if constexpr (PREV != 0) prev[i] = ok[i] ? *reinterpret_cast<const f32x4v*>(extra + e) : zero;
+            if constexpr (PREV == 2) mb[i] = ok[i] ? amask[e >> 3] : 0u;
+        }
+        f32x4v cs = zero, css = zero;
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            const unsigned e = (unsigned)(offs[i] + j * 16);
+            const unsigned sh = ((e >> 2) & 1u) * 4u;
+            f32x4v v = epi_mul(acc[i][j], c);
+            if constexpr (PREV == 2) {
+                const int nib = (int)(mb[i] >> sh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) prev[i][r] = __uint_as_float(__float_as_uint(prev[i][r]) & (unsigned)__builtin_amdgcn_sbfe(nib, r, 1));
+            }
+            if constexpr (PREV != 0) v = epi_add(v, prev[i]);
+            if (ok[i]) *reinterpret_cast<f32x4v*>(a.y + e) = v;
+            int on = (int)(ym[i] >> sh);
+            if (relu && !bits) {
+                on = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) on |= (yv[i][r] * sc[r] + sf[r] > 0.f) ? (1 << r) : 0;
+            }
+            if (EDGE && !ok[i]) on = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = __uint_as_float(__float_as_uint(v[r]) & (unsigned)__builtin_amdgcn_sbfe(on, r, 1));
+                const float gx = g * ((yv[i][r] - mu[r]) * is[r]);
+                cs[r] = i == 0 ? gx : cs[r] + gx;          // sum g xhat (0 + x == x)
+                css[r] = i == 0 ? g : css[r] + g;          // sum g
+                gmax = fmaxf(gmax, fabsf(g));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r]; sdst[(j * 16 + r) * 2 + 1] = css[r]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one column group's loads at a time (hoisting all four spills)
+    }
+    return gmax;
+}
+
 // Epilogue shared by the planes kernels (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic,
 // then stores): fold the cross-term accumulator, undo the operand scales, bias, optional accumulation into y, BatchNorm statistics
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
@@ -256,6 +337,28 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
 #undef PYLC_LEAN
         }
     }
+    constexpr bool bn = BNB;                 // (its own instantiations, gg_pl*_kernel<..., BNB = true>: the other launches keep their registers)
+    float gmax = 0.f;
+    if constexpr (!EP && BNB) {
+        // BatchNorm-backward mode (its own instantiations; launch_gg_pl guarantees a dense fp32 output, statistics, no bias): pl_epilogue_bn
+        // is the whole epilogue, with or without edges
+        done = true;
+        const bool cols_full = n0 + wave_n * WN + WN <= a.N_store;
+        float* const sd = smem + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+        const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
+        const float c = unscale_a * unscale_b;
+        const int pv = extra == nullptr ? 0 : (amask == nullptr ? 1 : 2);
+        if (rows_full && cols_full) {
+            gmax = pv == 0 ? pl_epilogue_bn<AM, 0, false>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask)
+                 : pv == 1 ? pl_epilogue_bn<AM, 1, false>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask)
+                           : pl_epilogue_bn<AM, 2, false>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask);
+        } else {
+            gmax = pv == 0 ? pl_epilogue_bn<AM, 0, true>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask)
+                 : pv == 1 ? pl_epilogue_bn<AM, 1, true>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask)
+                           : pl_epilogue_bn<AM, 2, true>(a, acc, rowoff, sd, nb, wave_m, lane, c, extra, amask);
+        }
+    }
+    if constexpr (!BNB) {
     if (!done) {
     int eoff[AM][AT];
     float bv[AT][4];
@@ -305,31 +408,14 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     }
     __builtin_amdgcn_sched_barrier(0);
     float* sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
-    // BatchNorm-backward mode (dgrad launches, a.bn_y != NULL): the tile being stored is the gradient `dout` of a BatchNorm OUTPUT, so the
-    // sums that BatchNorm's backward needs first -- sum g and sum g xhat with g = relu'(dout), xhat = (y - mean) invstd -- are taken here,
-    // from the registers, instead of by a read pass over (dout, y) (bn.hip bn_reduce_kernel<1>).  The y tile has the output's geometry.
-    // partial row layout = bn_reduce_kernel<1>'s: [sum g xhat | sum g].  max |g| goes to a.bn_gmax (range bound of the dy to come).
-    constexpr bool bn = BNB;                 // (its own instantiations, gg_pl*_kernel<..., BNB = true>: the other launches keep their registers)
-    float gmax = 0.f;
-    // (the y tile is fetched PJ columns at a time, like `prev`: requesting all of it at once -- before the accumulators are folded, one
-    // exposed round trip instead of two -- needs 64 more registers than the kernel has and spills: measured 376 vs 382 tiles/s)
-    auto finish = [&](auto has_prev, auto has_y, auto j0c, const f32x4v_ (&prev)[AM][PJ], const auto& yv, const auto& ym) {
+    auto finish = [&](auto has_prev, auto j0c, const f32x4v_ (&prev)[AM][PJ]) {
         constexpr int j0 = decltype(j0c)::value;
-        constexpr bool phased = decltype(has_prev)::value || decltype(has_y)::value;
+        constexpr bool phased = decltype(has_prev)::value;
         constexpr int NJ = phased ? PJ : AT;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             const int j = j0 + jj;
             float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
-            f32x4v_ mu = {0.f, 0.f, 0.f, 0.f}, is = mu, sc = mu, sh = mu;
-            if constexpr (decltype(has_y)::value) {
-                const int n4 = n0 + wave_n * WN + j * 16 + 4 * (lane >> 4);
-                if (n4 < a.N_store) {
-                    mu = *reinterpret_cast<const f32x4v_*>(a.bn_mean + n4);
-                    is = *reinterpret_cast<const f32x4v_*>(a.bn_invstd + n4);
-                    if (a.bn_scale != nullptr) { sc = *reinterpret_cast<const f32x4v_*>(a.bn_scale + n4); sh = *reinterpret_cast<const f32x4v_*>(a.bn_shift + n4); }
-                }
-            }
 #pragma unroll
             for (int i = 0; i < AM; ++i) {
                 const bool stored = eoff[i][j] >= 0;
@@ -343,19 +429,9 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                         ep_max = fmaxf(ep_max, stored ? fabsf(val) : 0.f);
                     }
                     acc[i][j][r] = val;
-                    if constexpr (decltype(has_y)::value) {
-                        const float yy = yv[i][jj][r];      // (jj indexes the columns held: j - j0)
-                        bool on = stored;
-                        if (a.bn_relu) on = on && (a.bn_mask != nullptr ? ((ym[i][jj] >> r) & 1u) != 0u : (yy * sc[r] + sh[r]) > 0.f);      // bits, or the forward's own expression
-                        const float g = on ? val : 0.f;
-                        cs[r] += g * ((yy - mu[r]) * is[r]);        // sum g xhat  (first half of the row: dgamma)
-                        css[r] += g;                                 // sum g       (second half: dbeta)
-                        gmax = fmaxf(gmax, fabsf(g));
-                    } else {
-                        const float cv = stored ? val - bv[j][r] : 0.f;      // statistics of (value - bias): conv_igemm.hip's epilogue
-                        cs[r] += cv;
-                        css[r] += cv * cv;
-                    }
+                    const float cv = stored ? val - bv[j][r] : 0.f;      // statistics of (value - bias): conv_igemm.hip's epilogue
+                    cs[r] += cv;
+                    css[r] += cv * cv;
                 }
             }
             if (do_stats) {
@@ -413,7 +489,6 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     };
     __builtin_amdgcn_sched_barrier(0);
     const f32x4v_ none[AM][PJ] = {};
-    const unsigned nomask[AM][PJ] = {};
     f32x4v_ prev[AM][PJ];
     auto fetch = [&](int j0) {
 #pragma unroll
@@ -440,19 +515,6 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                     prev[i][jj][3] = (nib & 8u) ? prev[i][jj][3] : 0.f;
                 }
         }
-    };
-    // the BatchNorm's input tile (and its ReLU's 1-bit mask): the output's geometry, dense
-    auto fetch_y = [&](auto& yv, auto& ym, auto j0c, auto nc) {
-        constexpr int j0 = decltype(j0c)::value, NC = decltype(nc)::value;
-#pragma unroll
-        for (int i = 0; i < AM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NC; ++jj) {
-                const f32x4v_ zero = {0.f, 0.f, 0.f, 0.f};
-                const int e = eoff[i][j0 + jj];
-                yv[i][jj] = e >= 0 ? *reinterpret_cast<const f32x4v_*>(a.bn_y + e) : zero;
-                ym[i][jj] = (a.bn_mask != nullptr && e >= 0) ? (unsigned)a.bn_mask[e >> 3] >> (((e >> 2) & 1) * 4) : 0u;
-            }
     };
     // residual of the fused inference epilogue arriving as fp16 planes: element = (h0 + 2^-11 h1) / s
     auto fetch_res = [&](int j0) {
@@ -485,52 +547,29 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                 prev[i][jj] = v;
             }
     };
-    if constexpr (!bn) {
-        if (res_planes) {
-            fetch_res(0);
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 0>{}, prev, none, nomask);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_res(2);
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 2>{}, prev, none, nomask);
-        } else if (extra == nullptr) {
-            finish(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{}, none, none, nomask);
-        } else {
-            fetch(0);
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 0>{}, prev, none, nomask);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(2);
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::false_type{}, std::integral_constant<int, 2>{}, prev, none, nomask);
-        }
+    if (res_planes) {
+        fetch_res(0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_res(2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
+    } else if (extra == nullptr) {
+        finish(std::false_type{}, std::integral_constant<int, 0>{}, none);
     } else {
-        if (extra == nullptr) {
-            f32x4v_ yv[AM][PJ];
-            unsigned ym[AM][PJ];
-            fetch_y(yv, ym, std::integral_constant<int, 0>{}, std::integral_constant<int, PJ>{});
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::false_type{}, std::true_type{}, std::integral_constant<int, 0>{}, none, yv, ym);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_y(yv, ym, std::integral_constant<int, 2>{}, std::integral_constant<int, PJ>{});
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::false_type{}, std::true_type{}, std::integral_constant<int, 2>{}, none, yv, ym);
-        } else {
-            f32x4v_ yv[AM][PJ];
-            unsigned ym[AM][PJ];
-            fetch(0); fetch_y(yv, ym, std::integral_constant<int, 0>{}, std::integral_constant<int, PJ>{});
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}, prev, yv, ym);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(2); fetch_y(yv, ym, std::integral_constant<int, 2>{}, std::integral_constant<int, PJ>{});
-            __builtin_amdgcn_sched_barrier(0);
-            finish(std::true_type{}, std::true_type{}, std::integral_constant<int, 2>{}, prev, yv, ym);
-        }
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 0>{}, prev);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(std::true_type{}, std::integral_constant<int, 2>{}, prev);
     }
-    if (bn && a.bn_gmax != nullptr) amax_commit(gmax, a.bn_gmax);
     if (EP && a.ep_amax != nullptr) amax_commit(ep_max, a.ep_amax);
     }          // general path
+    }          // !BNB
+    if (bn && a.bn_gmax != nullptr) amax_commit(gmax, a.bn_gmax);
     if (do_stats) {
         __syncthreads();
         if (tid < BN) {
@@ -615,25 +654,27 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     const bool stamper = STAMPS && (int)blockIdx.x == (a.dbg_flags >> 16) && lane == 0 && (wave == 0 || wave == NW - 1);
     PL_STAMP();
 
-    // TIMING EXPERIMENT (pylc_debug_pp_flags 512; results are garbage): address both operands as if they were stored chunk-interleaved
-    // ([row][32-channel chunk][plane][32 halves]): the two planes of a K-step row are the two halves of ONE 128-byte line
-    const bool il = NPL == 2 && (a.dbg_flags & 512);
-    const unsigned ilm = il ? 2u : 1u;
+    // chunk-interleaved filter planes (a.w_il, PylcConvDesc.w_planes_fmt): the two planes of a 32-channel chunk are the two halves of ONE
+    // 128-byte line, requested back to back below -- row and chunk offsets double, plane 1 sits 64 bytes behind plane 0
+    const unsigned ilmb = a.w_il ? 2u : 1u;
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * (il ? 2 : 1)), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + (il ? 32 : a.x_plane_stride) * 2), 0, (int)(a.x_bytes * (il ? 2 : 1) - (il ? 64 : 0)), 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
 
     // ---- filter rows of this thread: no geometry needed, so their first DMA goes out before anything else ----
     unsigned woff_row[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
         const int n = n0 + RPI * BI * wave + RPI * i + lrow;
-        woff_row[i] = n < a.N ? ((unsigned)n * (unsigned)a.w_row_stride * ilm + 8u * lc) * 2u : OOB;
+        // (one-plane kernels, 128-byte LDS rows: lc counts eight 16-byte pieces = two chunks; an interleaved filter keeps a chunk's plane 0
+        //  in the first 64 bytes of its line)
+        const unsigned lcb = a.w_il ? ((unsigned)(lc >> 2) * 128u + (unsigned)(lc & 3) * 16u) : 16u * lc;
+        woff_row[i] = n < a.N ? (unsigned)n * (unsigned)a.w_row_stride * ilmb * 2u + lcb : OOB;
     }
-    const unsigned plane1_w = il ? 64u : (unsigned)(a.w_plane_stride * 2);
+    const unsigned plane1_w = a.w_il ? 64u : (unsigned)(a.w_plane_stride * 2);
 
     // ---- pixel rows of this thread ----
     int rowh[AI], roww[AI];
@@ -645,14 +686,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         if (ident) {                       // 1x1, stride 1, no padding: input pixel == output pixel, no decode
             rowh[i] = ok ? 0 : -(1 << 28);
             roww[i] = 0;
-            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u;
+            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch + 8u * lc) * 2u;
         } else {
             const int mm = ok ? m : 0;
             const int q = mm % a.Q, t = mm / a.Q;
             const int p = t % a.P, b = t / a.P;
             rowh[i] = ok ? p * a.in_sh : -(1 << 28);          // invalid rows fail every bounds check
             roww[i] = q * a.in_sw;
-            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u;      // garbage for invalid rows (masked)
+            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * lc) * 2u;      // garbage for invalid rows (masked)
         }
     }
     // output row table (read by the epilogue; the first barrier of the main loop orders it)
@@ -736,8 +777,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         const int dh = a.dh0 + ld_tr * a.dh_step, dw = a.dw0 + ld_ts * a.dw_step;
         const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
         const bool cok = ld_chunk * KS + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
-        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2) * ilm;      // wave-uniform, may be "negative"
-        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2) * ilm;
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2);      // wave-uniform, may be "negative"
+        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2) * ilmb;
         char* const sa = dstA + stage * STAGE;
         char* const sb = dstB + stage * STAGE;
 #pragma unroll
@@ -916,18 +957,17 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     const int hmin_h = a.dh_step > 0 ? a.dh0 : a.dh0 + 2 * a.dh_step;          // smallest tap offset = origin of the halo
     const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
 
-    const bool il = NPL == 2 && (a.dbg_flags & 512);          // TIMING EXPERIMENT, as in gg_pl_kernel
-    const unsigned ilm = il ? 2u : 1u;
+    const unsigned ilmb = a.w_il ? 2u : 1u;                   // chunk-interleaved filter planes, as in gg_pl_kernel
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * (il ? 2 : 1)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + (il ? 32 : a.x_plane_stride) * 2), 0, (int)(a.x_bytes * (il ? 2 : 1) - (il ? 64 : 0)), 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
 
     // filter row of this thread (one 16-row piece per wave)
     const int nrow = n0 + 16 * wave + (lane >> 2);
-    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride * ilm + 8u * lc) * 2u : OOB;
-    const unsigned plane1_w = il ? 64u : (unsigned)(a.w_plane_stride * 2);
+    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride * ilmb + 8u * lc) * 2u : OOB;
+    const unsigned plane1_w = a.w_il ? 64u : (unsigned)(a.w_plane_stride * 2);
     // halo rows of this thread: pieces wave, wave + 8, wave + 16 -> rows 16 g + (lane >> 2); input pixel or padding (zeros)
     unsigned hoff[3];
 #pragma unroll
@@ -936,7 +976,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int hy = h / PLH_HW, hx = h - hy * PLH_HW;
         const int yy = y0 + hmin_h + hy, xx = x0 + hmin_w + hx;
         const bool ok = (h < PLH_HW * PLH_HW) & ((unsigned)yy < (unsigned)a.IH) & ((unsigned)xx < (unsigned)a.IW);
-        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch * ilm + 8u * lc) * 2u : OOB;
+        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch + 8u * lc) * 2u : OOB;
     }
     // output rows: patch pixel (py, px) = (row >> 4, row & 15)
     if (tid < BM) {
@@ -961,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     auto issue_halo = [&](int c) {                            // chunk c -> halo buffer c & 1
         char* const dst = lds + (c & 1) * HALO + (16 * wave) * ROW;
         const bool cok = c * BK + 8 * lc < a.Cin;
-        const unsigned cb = (unsigned)(c * BK * 2) * ilm;
+        const unsigned cb = (unsigned)(c * BK * 2);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned vo = (cok & (hoff[j] != OOB)) ? hoff[j] + cb : OOB;
@@ -974,7 +1014,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int c = s / 9, t = s - 9 * c;
         const int tr = t / 3, ts = t - 3 * tr;
         const bool cok = c * BK + 8 * lc < a.Cin;
-        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilm;
+        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilmb;
         const unsigned vo = cok ? woff_row : OOB;
         const unsigned vo1 = cok ? woff_row + plane1_w : OOB;
         char* const d = ldsB + slot * BST + (16 * wave) * ROW;

@@ -23,8 +23,12 @@ __device__ __forceinline__ void wsplit(float w, float s, f16& h0, f16& h1) {
 
 // One block per 32(k) x 32(c) tile of one (filter, tap): read coalesced along c, write the forward planes in the same order
 // and the dgrad planes transposed through LDS (coalesced along k).  Blocks find their filter by bisection over tile_begin.
+// `il`: chunk-interleaved layout (include/pylc_hip.h PylcConvDesc.w_planes_fmt) for the layouts whose channel count is a multiple of 32:
+// flat element e -> halves (e >> 5) * 64 + (e & 31), plane 1 at + 32 -- both planes of a K-step chunk in one 128-byte line.
+__device__ __forceinline__ long long il_phys(long long e) { return ((e >> 5) << 6) + (e & 31); }
+
 __global__ __launch_bounds__(256) void weight_prepare_kernel(const float* __restrict__ base, const PylcWPrepEntry* __restrict__ table,
-                                                             int count, const unsigned* __restrict__ amax, f16* __restrict__ planes) {
+                                                             int count, const unsigned* __restrict__ amax, f16* __restrict__ planes, int il) {
     __shared__ f16 t0s[32][34], t1s[32][34];
     int lo = 0, hi = count - 1;
     const long long tile = blockIdx.x;
@@ -46,14 +50,20 @@ __global__ __launch_bounds__(256) void weight_prepare_kernel(const float* __rest
     f16* f0 = planes + e.fwd_offset;                 // [2][K][RS][C]
     f16* t0 = planes + e.t_offset;                   // [2][C][RS][Kp]
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const bool il_f = il && e.C % 32 == 0, il_t = il && Kp % 32 == 0;
     for (int i = ty; i < 32; i += 8) {
         const int k = k0 + i, c = c0 + tx;
         f16 h0 = (f16)0.f, h1 = (f16)0.f;
         if (k < e.K && c < e.C) {
             const long long src = ((long long)k * e.RS + rs) * e.C + c;
             wsplit(w[src], s, h0, h1);
-            f0[src] = h0;
-            f0[n + src] = h1;
+            if (il_f) {
+                f0[il_phys(src)] = h0;
+                f0[il_phys(src) + 32] = h1;
+            } else {
+                f0[src] = h0;
+                f0[n + src] = h1;
+            }
         }
         t0s[i][tx] = h0;                              // zeros outside the filter: they become the Kp padding
         t1s[i][tx] = h1;
@@ -63,8 +73,13 @@ __global__ __launch_bounds__(256) void weight_prepare_kernel(const float* __rest
         const int c = c0 + i, k = k0 + tx;
         if (c < e.C && k < Kp) {
             const long long dst = ((long long)c * e.RS + rs) * Kp + k;
-            t0[dst] = t0s[tx][i];
-            t0[nt + dst] = t1s[tx][i];
+            if (il_t) {
+                t0[il_phys(dst)] = t0s[tx][i];
+                t0[il_phys(dst) + 32] = t1s[tx][i];
+            } else {
+                t0[dst] = t0s[tx][i];
+                t0[nt + dst] = t1s[tx][i];
+            }
         }
     }
 }
@@ -114,10 +129,10 @@ extern "C" int pylc_conv1x1_fold_input_affine(const float* w, const float* scale
 }
 
 extern "C" int pylc_weight_prepare(const float* base, const PylcWPrepEntry* table, int count, long long total_tiles,
-                                   const unsigned int* amax, void* planes, void* stream) {
+                                   const unsigned int* amax, void* planes, int interleave, void* stream) {
     PYLC_REQUIRE(base && table && amax && planes && count > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "weight_prepare: bad arguments");
     hipLaunchKernelGGL(weight_prepare_kernel, dim3((unsigned)total_tiles), dim3(256), 0, as_stream(stream), base, table, count, amax,
-                       static_cast<f16*>(planes));
+                       static_cast<f16*>(planes), interleave);
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }

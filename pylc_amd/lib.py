@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                                        'OH', 'OW', 'x_pitch', 'y_pitch')] + \
                [(n, C.c_void_p) for n in ('x_amax', 'w_amax', 'dy_amax',      # operand ranges (precision mode 2)
                                           'w_planes', 'w_planes_t')] + \
-               [(n, C.c_int) for n in ('x_fmt', 'dy_fmt', 'out_fmt')] + [('out_bound', C.c_void_p)]      # operand / output formats: 0 fp32, 1 fp16 planes
+               [(n, C.c_int) for n in ('x_fmt', 'dy_fmt', 'out_fmt')] + [('out_bound', C.c_void_p)] + \
+               [('w_planes_fmt', C.c_int)]      # operand / output formats: 0 fp32, 1 fp16 planes; filter-plane layout bits (chunk-interleaved)
 
 
 class WPrepEntry(C.Structure):
@@ -96,7 +97,7 @@ SIGNATURES = {
     'pylc_from_planes': (_I, [_P, _I, _LL, _P, _I, _LL, _I, _P, _I, _P]),
     'pylc_planes_colsum_workspace_floats': (C.c_size_t, [_I]),
     'pylc_planes_colsum': (_I, [_P, _I, _LL, _I, _P, _LL, _I, _P, _P, _P]),
-    'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _P]),
+    'pylc_weight_prepare': (_I, [_P, _P, _I, _LL, _P, _P, _I, _P]),
     'pylc_conv2d_dgrad_needs_f32_weights': (_I, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     'pylc_conv2d_fwd_bnact': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),

@@ -69,7 +69,7 @@ class SeparableConv2d(nn.Module):
                 entry = L.WPrepEntry(0, 0, n_fwd, 0, cout, 1, cin, 0)
                 table = torch.frombuffer(bytearray(bytes(entry)), dtype=torch.uint8).clone().to(w.device)
                 tiles = ((cout + 31) // 32) * ((cin + 31) // 32)
-                check(lib.pylc_weight_prepare(ptr(w2), ptr(table), 1, tiles, ptr(amax), ptr(planes), stream()))
+                check(lib.pylc_weight_prepare(ptr(w2), ptr(table), 1, tiles, ptr(amax), ptr(planes), 0, stream()))      # (separate plane arrays)
                 w2._pylc_planes = (planes[:n_fwd], planes[n_fwd:n_fwd + n_t])
                 self._fold_table = table               # (read by the launch above: kept until the cache is dropped)
             self._fold, self._fold_key = (w2, b2), key

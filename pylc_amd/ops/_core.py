@@ -88,6 +88,12 @@ def half_dw():
     return half_acts() and _runtime.half_dw
 
 
+def filter_planes_fmt(planes):
+    """PylcConvDesc.w_planes_fmt of a parameter's prepared filter planes (optim.FlatArena: `_pylc_planes` = forward planes, dgrad planes,
+    the layouts that CAN be chunk-interleaved, the arena's switch saying whether the last prepare launch wrote them so)."""
+    return planes[2] if (len(planes) > 3 and planes[3][0]) else 0
+
+
 def planes_ok(c, pixels):
     """Can an activation of `c` channels x `pixels` pixels be kept as fp16 planes (16-byte rows per 8 channels, one plane below 2 GiB)?"""
     return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)

@@ -94,7 +94,7 @@ class Conv2dFn(torch.autograd.Function):
             d.out_fmt, d.out_bound = 1, ptr(y_bound)
         planes = getattr(w, '_pylc_planes', None) if (w_amax is not None and w_k is w) else None
         if planes is not None:
-            d.w_planes = ptr(planes[0])
+            d.w_planes, d.w_planes_fmt = ptr(planes[0]), filter_planes_fmt(planes)
         ev = None
         if _core._timer is not None and (x_pl if _core._timer.planes else _is_dominant_tile(b * oh * ow, yp, cin, r * s)):
             ev = _core._timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd%dx%d' % (r, s),
@@ -170,7 +170,7 @@ class Conv2dFn(torch.autograd.Function):
             d.x_amax, d.w_amax, d.dy_amax = ptr(x_amax), ptr(w_amax), ptr(dy_amax)
             planes = getattr(w, '_pylc_planes', None) if w_k is w else None
             if planes is not None:
-                d.w_planes_t = ptr(planes[1])
+                d.w_planes_t, d.w_planes_fmt = ptr(planes[1]), filter_planes_fmt(planes)
         st = stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -466,6 +466,7 @@ def conv_bn_act_eval_planes(x, w, bias, stride, pad, dil, coef, coef_ranges, res
     d.x_fmt = 1
     w_amax = weight_amax(w)
     d.x_amax, d.w_amax, d.w_planes = ptr(planes_amax(x)), ptr(w_amax), ptr(planes[0])
+    d.w_planes_fmt = filter_planes_fmt(planes)
     true_amax = amax_slot(x.device)
     bound = None
     if out_planes:
@@ -535,7 +536,7 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
         d.x_amax, d.w_amax = ptr(keep[0]), ptr(keep[1])
         planes = getattr(w, '_pylc_planes', None)
         if planes is not None:
-            d.w_planes = ptr(planes[0])
+            d.w_planes, d.w_planes_fmt = ptr(planes[0]), filter_planes_fmt(planes)
         amax = amax_slot(x.device)
     st = stream()
     if coef is None:          # (coef: [scale | shift] a caller computed once for this set of weights, layers.BatchNorm2d.eval_coeffs)

@@ -53,6 +53,7 @@ class FlatArena:
         # prepared conv filters for the f16x3 arithmetic: two fp16 planes per filter in the forward (KRSC) and the dgrad
         # (CRSK) layout, rebuilt from the fp32 master weights by ONE launch whenever the ranges are refreshed
         entries, halves, tiles = [], 0, 0
+        self._planes_il = [0]            # 1: the prepared filter planes are chunk-interleaved where eligible (set by refresh_ranges)
         for i, (p, o) in enumerate(zip(params, offs)):
             if p.dim() == 4 and p.shape[1] % 4 == 0 and p.shape[1] > 1 and p.permute(0, 2, 3, 1).is_contiguous():
                 k, c, r, s_ = p.shape
@@ -71,8 +72,11 @@ class FlatArena:
             self._prep_table = raw.to(dev)
             for p, e in entries:
                 k, c, r, s_ = p.shape
+                # (forward planes, dgrad planes, which of the two CAN be chunk-interleaved -- channel count % 32 == 0 --, and the arena's
+                #  shared switch: whether the last prepare launch wrote them so; ops.filter_planes_fmt combines the two for PylcConvDesc)
                 p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
-                                  self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)])
+                                  self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)],
+                                  (1 if c % 32 == 0 else 0) | (2 if ((k + 3) & ~3) % 32 == 0 else 0), self._planes_il)
         self._index = {id(p): i for i, p in enumerate(params)}
         self._delivered = set()          # parameters whose gradient a backward kernel wrote since the last zero_grad()
         self._stale = False              # invalidate(): values changed through a path the version counters do not see
@@ -111,8 +115,13 @@ class FlatArena:
             if not ranges_current:
                 check(lib.pylc_amax_segments(ptr(self.p), ptr(self._segments), len(self.params), ptr(self.amax), stream()))
             if self._n_prep:
+                # f16x3 (precision mode 2): both planes of a K-step chunk in one cache line (include/pylc_hip.h PylcConvDesc.w_planes_fmt); the
+                # one-plane kernels of mode 3 read plane 0 only and want it contiguous.  The kernels read either layout (the flag travels in
+                # the conv descriptor), so a mode switch without a refresh stays correct.  PYLC_NO_FILTER_INTERLEAVE=1: A/B knob.
+                il = 1 if (lib.pylc_get_conv_precision() == 2 and not os.environ.get('PYLC_NO_FILTER_INTERLEAVE')) else 0
                 check(lib.pylc_weight_prepare(ptr(self.p), ptr(self._prep_table), self._n_prep, self._prep_tiles, ptr(self.amax),
-                                              ptr(self.planes), stream()))
+                                              ptr(self.planes), il, stream()))
+                self._planes_il[0] = il
 
     def zero_grad(self):
         self.g.zero_()

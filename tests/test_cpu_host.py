@@ -419,3 +419,24 @@ def test_arena_data_writes_need_invalidate_or_the_forced_refresh():
     assert arena.generation == g0 + 1
     arena.refresh_if_changed(force=True)               # what Model._refresh_for_inference does after a training step
     assert arena.generation == g0 + 2
+
+
+def test_native_comm_falls_back_with_a_logged_reason(monkeypatch, capsys):
+    """PYLC_COMM=native (parallel.try_native_comm): if the C ABI's RCCL communicator cannot be created the run continues on the
+    torch.distributed path and says why; a half-created pair of communicators is torn down."""
+    from pylc_amd import parallel
+    from pylc_amd.runtime import runtime
+
+    def boom(rank, world):
+        runtime.comm = object()           # the first communicator came up, the second did not
+        raise RuntimeError('pylc_comm: librccl.so.1 not loadable: test')
+    monkeypatch.setattr(parallel, 'init_native_comm', boom)
+    monkeypatch.setattr(parallel, 'destroy_native_comm', lambda: (setattr(runtime, 'comm', None), setattr(runtime, 'grad_comm', None)))
+    assert parallel.try_native_comm(0, 1) is False
+    assert runtime.comm is None and runtime.grad_comm is None
+    err = capsys.readouterr().err
+    assert 'PYLC_COMM=native unavailable' in err and 'not loadable' in err and 'torch.distributed' in err
+    # a message the C ABI does not take goes through torch.distributed instead of raising (ADVICE r4)
+    import torch
+    assert runtime.native_takes(torch.zeros(4)) and runtime.native_takes(torch.zeros(4, dtype=torch.float64))
+    assert not runtime.native_takes(torch.zeros(4, dtype=torch.int64)) and not runtime.native_takes(torch.zeros(4, 2)[:, 0])

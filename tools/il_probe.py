@@ -46,13 +46,13 @@ for (B, H, cin, cout, k, st, pad, dil) in SHAPES:
     xp = ops.to_planes(x)
     ts = []
     with torch.no_grad():
-        for flags in (0, 512, 0, 512):
+        for flags in (0, 512 | 4, 4, 512, 0, 512 | 4, 4, 512):
             lib.pylc_debug_pp_flags(flags)
             ts.append(timeit(lambda: ops.conv2d(xp, conv.weight, None, st, pad, dil, want_stats=True)))
     lib.pylc_debug_pp_flags(0)
-    t0, t1 = min(ts[0], ts[2]), min(ts[1], ts[3])
+    t0, t1, tb, ta = min(ts[0], ts[4]), min(ts[1], ts[5]), min(ts[2], ts[6]), min(ts[3], ts[7])
     fl = 2.0 * B * H * H * cout * k * k * cin
     tot[0] += t0; tot[1] += t1
-    print('B%d %3dx%-3d %4d->%4d k%d d%-2d | separate planes %7.1f us %4.0f TF/s | interleaved addressing %7.1f us %4.0f TF/s | %+5.1f %%'
-          % (B, H, H, cin, cout, k, dil, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9, 100 * (t0 / t1 - 1)), flush=True)
+    print('B%d %3dx%-3d %4d->%4d k%d d%-2d | separate planes %7.1f us %4.0f TF/s | interleaved addressing %7.1f us %4.0f TF/s | %+5.1f %% | filters only %+5.1f %% | pixels only %+5.1f %%'
+          % (B, H, H, cin, cout, k, dil, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9, 100 * (t0 / t1 - 1), 100 * (t0 / tb - 1), 100 * (t0 / ta - 1)), flush=True)
 print('sum %.1f -> %.1f us (%+.1f %%)' % (tot[0] * 1e3, tot[1] * 1e3, 100 * (tot[0] / tot[1] - 1)))
