@@ -37,6 +37,8 @@ extern "C" {
 const char* pylc_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int pylc_abi_version(void);
+/* 1 when the library was built with EXPERIMENTAL=1, i.e. the entry points inside #ifdef PYLC_EXPERIMENTAL below exist (pylc_amd/csrc/Makefile) */
+int pylc_experimental_build(void);
 /* One-time per-process kernel attribute setup (dynamic LDS opt-in). Idempotent. */
 int pylc_init(void);
 
@@ -215,6 +217,7 @@ int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crs
  * (dy_fmt = 1), stride 1, a dense dx (x_pitch == Cin, Cin % 8 == 0) and accumulate == 0; add_src == NULL is pylc_conv2d_dgrad. */
 int pylc_conv2d_dgrad_add(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                           const float* add_src, const void* add_mask, void* stream);
+#ifdef PYLC_EXPERIMENTAL      /* measured negative inside the step (the y tile is fetched in the epilogue, a latency chain): off, built with EXPERIMENTAL=1 only */
 /* pylc_conv2d_dgrad_add that ALSO takes the backward sums of the BatchNorm whose output this dgrad differentiates: dx is that
  * BatchNorm's `dout`, so sum g xhat and sum g (g = relu'(dout), xhat = (y - mean) invstd: what pylc_bn_bwd_reduce computes in a read
  * pass over dout and y, models/sync_batchnorm/batchnorm.py:113-125 / torch's batch_norm_backward) are taken from the output tile while
@@ -237,6 +240,7 @@ size_t pylc_conv2d_dgrad_bn_floats(const PylcConvDesc* d);
 int pylc_conv2d_dgrad_bn(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                          const float* add_src, const void* add_mask, const PylcBnBack* bn, float* sums_partial, int* sums_rows,
                          void* stream);
+#endif
 /* g_out = dout where the 1-bit mask is set, else 0 (the fallback of pylc_conv2d_dgrad_add when the dgrad that consumes a parked
  * (dout, mask) pair does not run on the fp16-plane kernels).  M rows x C channels, C % 8 == 0, dense. */
 int pylc_relu_bwd_bits(const float* dout, const void* mask, float* g_out, long long M, int C, void* stream);
@@ -441,10 +445,12 @@ int pylc_bn_bwd_reduce_ex(const float* dout, int dout_pitch, const float* out, i
                           unsigned int* dy_bound_out, void* stream);
 int pylc_bn_bwd_bound(const float* sums, const float* gamma, const float* invstd, double n, int C, const unsigned int* g_amax,
                       unsigned int* bound_out, void* stream);
+#ifdef PYLC_EXPERIMENTAL
 /* The combine stage of pylc_bn_bwd_reduce_ex alone, for per-tile partials that a conv dgrad emitted (pylc_conv2d_dgrad_bn):
  * sums = fp64 column sums of partial[rows][2C] in fixed order; dy_bound_out as in pylc_bn_bwd_reduce_ex (NULL: none). */
 int pylc_bn_bwd_sums_from_partial(const float* partial, int rows, int C, float* sums, const float* gamma, const float* invstd, double n,
                                   const unsigned int* g_amax, unsigned int* dy_bound_out, void* stream);
+#endif
 int pylc_bn_bwd_apply_ex(const float* dout, int dout_pitch, const float* out, int out_pitch, const float* y, int y_pitch,
                          const float* mean, const float* invstd, const float* gamma, const float* sums, double n, long long M,
                          int C, int relu, float* dy, int dy_pitch, float* g_out, int g_pitch, unsigned int* amax_dy,
@@ -596,6 +602,7 @@ int pylc_sgd_step(float* p, const float* g, float* buf, long long n, const float
 int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long long M, int C, float p,
                  uint64_t seed, void* stream);
 
+#ifdef PYLC_EXPERIMENTAL      /* measured: no gain from confining the wgrad stream (profiles/r03_cumask_ab.txt) */
 /* ---------------------------------------------------------------------------------------------
  * Streams confined to a subset of the compute units (no reference counterpart: the reference runs one CUDA stream).  The weight-gradient
  * kernels run on a second HIP stream beside the BatchNorm backward passes (pylc_amd/ops.py); created through this entry point that stream
@@ -605,6 +612,7 @@ int pylc_dropout(const float* x, int x_pitch, float* out, int out_pitch, long lo
  * --------------------------------------------------------------------------------------------- */
 int pylc_stream_create_cu_mask(int n_cus, int from_top, void** stream_out);
 int pylc_stream_destroy(void* stream);
+#endif
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling / A-B knobs (tools/, not needed by a caller)
@@ -621,6 +629,7 @@ int pylc_debug_pp_flags(int flags);
 /* conv_pl.hip, 128-row tiles: start delay of the second block of every CU in the first round of blocks, in units of 2048 cycles
  * (< 0: the launch heuristic, about half a tile; 0: none) -- A/B knob for tools/pl_stagger_ab.py */
 int pylc_debug_stagger(int units);
+#ifdef PYLC_EXPERIMENTAL
 /* conv_p1.hip: 1 sends plain 1x1 / stride-1 launches to the persistent kernel whose stores leave under the next tile (off by default:
  * measured neutral inside the step) */
 int pylc_debug_p1(int on);
@@ -628,6 +637,7 @@ int pylc_debug_p1(int on);
  * launches (nn.Conv2d 1x1 forward / backward: resnet.py:21-26,92, aspp.py:64,67, decoder.py:27).  Bit 0: forward and plain dgrad launches;
  * bit 1: also the dgrads that add a ReLU-masked residual gradient (pylc_conv2d_dgrad_add).  A/B knob, env PYLC_PS. */
 int pylc_debug_ps(int on);
+#endif
 /* dwconv.hip, one-plane fp16 depthwise convs (A/B knob, env PYLC_DW_TILES; default 3): bit 0 = LDS-tiled kernels for stride 1 / dilation 1
  * (else the strip kernels), bit 1 = LDS-tiled kernels for stride 2 and for dilation 2 (else those shapes are not half-eligible) */
 int pylc_debug_dw_tiles(int on);

@@ -10,6 +10,15 @@ extern "C" const char* pylc_last_error(void) { return pylc::g_err; }
 
 extern "C" int pylc_abi_version(void) { return 11; }      // r5: pylc_comm_*, PylcFwdEp, PylcConvDesc.w_planes_fmt, pylc_weight_prepare(interleave)
 
+// 1 when the library was built with EXPERIMENTAL=1 (include/pylc_hip.h: the #ifdef PYLC_EXPERIMENTAL entry points exist)
+extern "C" int pylc_experimental_build(void) {
+#ifdef PYLC_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int pylc_init(void) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -17,6 +26,7 @@ extern "C" int pylc_init(void) {
     return pylc::conv_init();
 }
 
+#ifdef PYLC_EXPERIMENTAL
 extern "C" int pylc_stream_create_cu_mask(int n_cus, int from_top, void** stream_out) {
     PYLC_REQUIRE(stream_out != nullptr && n_cus >= 8 && n_cus <= pylc::kNumCU && n_cus % 8 == 0,
                  "stream_create_cu_mask: n_cus must be a multiple of 8 in [8, %d]", pylc::kNumCU);
@@ -36,3 +46,4 @@ extern "C" int pylc_stream_destroy(void* stream) {
     PYLC_HIP(hipStreamDestroy(pylc::as_stream(stream)));
     return PYLC_OK;
 }
+#endif

@@ -945,6 +945,7 @@ __global__ void bn_bwd_bound_kernel(const float* __restrict__ sums, const float*
     atomicMax(bound_out, __float_as_uint(b));
 }
 
+#ifdef PYLC_EXPERIMENTAL
 extern "C" int pylc_bn_bwd_sums_from_partial(const float* partial, int rows, int C, float* sums, const float* gamma, const float* invstd, double n,
                                              const unsigned int* g_amax, unsigned int* dy_bound_out, void* stream) {
     PYLC_REQUIRE(partial && sums && rows > 0 && C > 0, "bn_bwd_sums_from_partial: bad arguments");
@@ -957,6 +958,7 @@ extern "C" int pylc_bn_bwd_sums_from_partial(const float* partial, int rows, int
     PYLC_LAUNCH_CHECK();
     return PYLC_OK;
 }
+#endif
 
 extern "C" int pylc_bn_bwd_bound(const float* sums, const float* gamma, const float* invstd, double n, int C, const unsigned int* g_amax,
                                  unsigned int* bound_out, void* stream) {

@@ -1631,8 +1631,10 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 
 int conv_init() {
     if (int rc = conv_pl_init()) return rc;
+#ifdef PYLC_EXPERIMENTAL
     if (int rc = conv_p1_init()) return rc;
     if (int rc = conv_ps_init()) return rc;
+#endif
     if (int rc = wgrad_pl_init()) return rc;
 #define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
@@ -1848,15 +1850,23 @@ extern "C" int pylc_conv2d_dgrad_needs_f32_weights(const PylcConvDesc* d) {
     return (big && takes_pp(a)) ? 0 : 1;
 }
 
+extern "C" int pylc_conv2d_dgrad_add(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                                     const float* add_src, const void* add_mask, void* stream);
 extern "C" int pylc_conv2d_dgrad(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate, void* stream) {
     return pylc_conv2d_dgrad_add(d, dy, w_crsk, dx, accumulate, nullptr, nullptr, stream);
 }
 
+// one implementation behind pylc_conv2d_dgrad, _dgrad_add and (EXPERIMENTAL builds) _dgrad_bn
+struct BnBackArgs { const float* y; const float* mean; const float* invstd; const float* scale; const float* shift; const void* relu_mask; int relu; unsigned int* g_amax; };
+static int conv2d_dgrad_impl(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                             const float* add_src, const void* add_mask, const BnBackArgs* bn, float* sums_partial, int* sums_rows, void* stream);
+
 extern "C" int pylc_conv2d_dgrad_add(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                                      const float* add_src, const void* add_mask, void* stream) {
-    return pylc_conv2d_dgrad_bn(d, dy, w_crsk, dx, accumulate, add_src, add_mask, nullptr, nullptr, nullptr, stream);
+    return conv2d_dgrad_impl(d, dy, w_crsk, dx, accumulate, add_src, add_mask, nullptr, nullptr, nullptr, stream);
 }
 
+#ifdef PYLC_EXPERIMENTAL
 extern "C" size_t pylc_conv2d_dgrad_bn_floats(const PylcConvDesc* d) {
     if (check_desc(d)) return 0;
     const long long M = (long long)d->B * d->H * d->W;
@@ -1866,6 +1876,14 @@ extern "C" size_t pylc_conv2d_dgrad_bn_floats(const PylcConvDesc* d) {
 extern "C" int pylc_conv2d_dgrad_bn(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
                                     const float* add_src, const void* add_mask, const PylcBnBack* bn, float* sums_partial, int* sums_rows,
                                     void* stream) {
+    if (bn == nullptr) return conv2d_dgrad_impl(d, dy, w_crsk, dx, accumulate, add_src, add_mask, nullptr, sums_partial, sums_rows, stream);
+    const BnBackArgs b{bn->y, bn->mean, bn->invstd, bn->scale, bn->shift, bn->relu_mask, bn->relu, bn->g_amax};
+    return conv2d_dgrad_impl(d, dy, w_crsk, dx, accumulate, add_src, add_mask, &b, sums_partial, sums_rows, stream);
+}
+#endif
+
+static int conv2d_dgrad_impl(const PylcConvDesc* d, const float* dy, const float* w_crsk, float* dx, int accumulate,
+                             const float* add_src, const void* add_mask, const BnBackArgs* bn, float* sums_partial, int* sums_rows, void* stream) {
     if (int rc = check_desc(d)) return rc;
     PYLC_REQUIRE(bn == nullptr || (d->dy_fmt == 1 && d->stride == 1 && d->x_pitch == d->Cin && d->Cin % 8 == 0 && sums_partial && sums_rows &&
                                    bn->y && bn->mean && bn->invstd && (!bn->relu || bn->relu_mask || (bn->scale && bn->shift))),

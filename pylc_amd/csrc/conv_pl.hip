@@ -1095,16 +1095,20 @@ template __global__ void gg_pl_kernel<1, 128>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 256>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 128, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 256, true>(const GatherGemmArgs);
+#ifdef PYLC_EXPERIMENTAL
 template __global__ void gg_pl_kernel<3, 128, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 256, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 128, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 256, false, true>(const GatherGemmArgs);
+#endif
 template __global__ void gg_pl_kernel<3, 128, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 256, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 128, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 256, false, false, true>(const GatherGemmArgs);
+#ifdef PYLC_EXPERIMENTAL
 template __global__ void gg_plh_kernel<3, true>(const GatherGemmArgs);
 template __global__ void gg_plh_kernel<1, true>(const GatherGemmArgs);
+#endif
 template __global__ void gg_pl_kernel<3, 128, false, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<3, 256, false, false, false, true>(const GatherGemmArgs);
 template __global__ void gg_pl_kernel<1, 128, false, false, false, true>(const GatherGemmArgs);
@@ -1140,7 +1144,9 @@ static void launch_pl(const GatherGemmArgs& a, unsigned grid, hipStream_t st) {
     const bool ep = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;      // fused inference epilogue
     if (ep && a.N_store <= 64 && !(g_pp_flags & 65536)) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, true, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
     else if (ep) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+#ifdef PYLC_EXPERIMENTAL
     else if (a.bn_y != nullptr) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
+#endif
     else if (a.N_store <= 64 && !(g_pp_flags & 65536)) hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM, false, false, true>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
     else hipLaunchKernelGGL((gg_pl_kernel<NTERMS, BM>), dim3(grid), dim3(BM * 2), lds_bytes, st, a);
 }
@@ -1166,8 +1172,12 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
                  "conv dgrad with a masked residual source needs a dense output (pitch == channels, channels %% 8 == 0) and no accumulation");
     PYLC_REQUIRE(a.bn_y == nullptr || (a.y_pitch == a.N_store && a.stats != nullptr && a.bn_mean && a.bn_invstd && (!a.bn_relu || a.bn_mask || (a.bn_scale && a.bn_shift))),
                  "conv dgrad with BatchNorm-backward sums needs a dense output, a partials buffer, mean / invstd and a mask source");
+#ifdef PYLC_EXPERIMENTAL
     if (!(g_pp_flags & (2048 | 8192)) && takes_ps(a)) return launch_gg_ps(a, st);      // 1x1: loader waves + compute waves, one persistent block per CU
     if (!(g_pp_flags & (2048 | 8192)) && a.add_src == nullptr && a.bn_y == nullptr && !a.out_half && takes_p1(a)) return launch_gg_p1(a, st);     // 1x1: the persistent kernel whose stores leave under the next tile's main loop
+#else
+    PYLC_REQUIRE(a.bn_y == nullptr, "conv dgrad with BatchNorm-backward sums: this library was built without EXPERIMENTAL=1");
+#endif
     // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
     // tile's prologue / epilogue) -- for long reductions on grids that still fill the chip.  128 rows: two blocks per CU.
     // 3x3 / unit steps / 16-aligned output: the halo kernel (A-operand DMA once per channel chunk instead of once per tap)
@@ -1188,9 +1198,11 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
         if (a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr) {
             if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1, false, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
             else hipLaunchKernelGGL((gg_plh_kernel<3, false, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
+#ifdef PYLC_EXPERIMENTAL
         } else if (a.bn_y != nullptr) {
             if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
             else hipLaunchKernelGGL((gg_plh_kernel<3, true>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
+#endif
         } else if (a.nterms == 1) hipLaunchKernelGGL((gg_plh_kernel<1>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<1>(), st, a);
         else hipLaunchKernelGGL((gg_plh_kernel<3>), dim3((unsigned)n_tiles), dim3(512), plh_lds_bytes<3>(), st, a);
         PYLC_LAUNCH_CHECK();
@@ -1236,16 +1248,20 @@ int conv_pl_init() {
     PYLC_HIP(opt_in(gg_pl_kernel<1, 256>, pl_lds_bytes<1, 256>()));
     PYLC_HIP(opt_in(gg_plh_kernel<3>, plh_lds_bytes<3>()));
     PYLC_HIP(opt_in(gg_plh_kernel<1>, plh_lds_bytes<1>()));
+#ifdef PYLC_EXPERIMENTAL
     PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, true>), pl_lds_bytes<3, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, true>), pl_lds_bytes<3, 256>()));
     PYLC_HIP(opt_in((gg_pl_kernel<1, 128, false, true>), pl_lds_bytes<1, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<1, 256, false, true>), pl_lds_bytes<1, 256>()));
+#endif
     PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, false, true>), pl_lds_bytes<3, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, false, true>), pl_lds_bytes<3, 256>()));
     PYLC_HIP(opt_in((gg_pl_kernel<1, 128, false, false, true>), pl_lds_bytes<1, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<1, 256, false, false, true>), pl_lds_bytes<1, 256>()));
+#ifdef PYLC_EXPERIMENTAL
     PYLC_HIP(opt_in((gg_plh_kernel<3, true>), plh_lds_bytes<3>()));
     PYLC_HIP(opt_in((gg_plh_kernel<1, true>), plh_lds_bytes<1>()));
+#endif
     PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, false, false, true>), pl_lds_bytes<3, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, false, false, true>), pl_lds_bytes<3, 256>()));
     PYLC_HIP(opt_in((gg_pl_kernel<1, 128, false, false, false, true>), pl_lds_bytes<1, 128>()));

@@ -69,6 +69,7 @@ _SZ = C.c_size_t
 SIGNATURES = {
     'pylc_last_error': (C.c_char_p, []),
     'pylc_abi_version': (_I, []),
+    'pylc_experimental_build': (_I, []),
     'pylc_init': (_I, []),
     'pylc_set_conv_precision': (_I, [_I]),
     'pylc_get_conv_precision': (_I, []),
@@ -188,13 +189,25 @@ SIGNATURES = {
 }
 
 
+# entry points that exist only in a library built with `make EXPERIMENTAL=1` (include/pylc_hip.h: #ifdef PYLC_EXPERIMENTAL): what was
+# measured neutral or negative and is off in the product -- the persistent 1x1 kernels, the dgrad epilogue that takes BatchNorm-backward
+# sums, CU-masked streams.  HAS_EXPERIMENTAL tells the callers (and the tests, which skip without it).
+EXPERIMENTAL = ('pylc_debug_p1', 'pylc_debug_ps', 'pylc_conv2d_dgrad_bn_floats', 'pylc_conv2d_dgrad_bn', 'pylc_bn_bwd_sums_from_partial',
+                'pylc_stream_create_cu_mask', 'pylc_stream_destroy')
+HAS_EXPERIMENTAL = False
+
+
 def _load():
+    global HAS_EXPERIMENTAL
     if not os.path.exists(LIB_PATH):
         raise PylcError(
             'libpylc_hip.so is not built (%s). Build it with `python __graft_entry__.py` or '
             '`make -C pylc_amd/csrc`; there is no CPU fallback.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    HAS_EXPERIMENTAL = hasattr(lib, 'pylc_experimental_build') and lib.pylc_experimental_build() == 1
     for name, (res, args) in SIGNATURES.items():
+        if name in EXPERIMENTAL and not HAS_EXPERIMENTAL:
+            continue
         fn = getattr(lib, name)           # AttributeError => header / library mismatch
         fn.restype = res
         fn.argtypes = args
@@ -210,6 +223,11 @@ _initialised = False
 def check(rc):
     if rc != 0:
         raise PylcError('libpylc_hip: %s (code %d)' % (lib.pylc_last_error().decode(), rc))
+
+
+def _need_experimental(what):
+    if not HAS_EXPERIMENTAL:
+        raise PylcError('%s needs a library built with `make -C pylc_amd/csrc EXPERIMENTAL=1` (this one holds the product kernels only)' % what)
 
 
 def init():
@@ -229,12 +247,14 @@ def init():
         if os.environ.get('PYLC_WGRAD_ACC1') is not None:     # 1: one-accumulator 128x128 wgrad under 128 registers (A/B)
             lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
+            _need_experimental('PYLC_P1')
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
         if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)
             lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
         if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)
             lib.pylc_debug_wgrad_max_steps(int(os.environ['PYLC_WG_MAX_STEPS']))
         if os.environ.get('PYLC_PS') is not None:        # bit 0: plain 1x1 launches on the specialised-wave kernel of conv_ps.hip, bit 1: + masked-residual dgrads
+            _need_experimental('PYLC_PS')
             lib.pylc_debug_ps(int(os.environ['PYLC_PS']))
         if os.environ.get('PYLC_DW_TILES') is not None:  # 0: half depthwise convs on the strip kernels (A/B)
             lib.pylc_debug_dw_tiles(int(os.environ['PYLC_DW_TILES']))

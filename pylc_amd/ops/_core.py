@@ -405,6 +405,7 @@ def cu_masked_stream(device, n_cus, from_top=False):
     L.init()
     h = C.c_void_p()
     with torch.cuda.device(device):
+        L._need_experimental('a CU-masked stream (PYLC_WGRAD_CUS)')
         check(lib.pylc_stream_create_cu_mask(int(n_cus), int(bool(from_top)), C.byref(h)))
     return torch.cuda.ExternalStream(h.value, device=device)
 

@@ -212,6 +212,7 @@ class Conv2dFn(torch.autograd.Function):
                     and getattr(bn, 'bn_emit_ok', False) and tuple(bn.y_shape) == tuple(x.shape)
                     and ((link is None and bn.sole) or (link is not None and link.pending == 1)))
             if emit:
+                L._need_experimental('PYLC_FUSE_BN_SUMS=1')
                 y_bn, _, coef, _, bmask, _ = bn.saved_tensors
                 cb = x.shape[1]
                 relu_bn = bn.cfg[0]

@@ -28,6 +28,7 @@ class _Runtime:
         # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)
         self.wgrad_side_stream = not os.environ.get('PYLC_NO_SIDE_STREAM')
         # confine the wgrad side stream to this many compute units (0 = all 256): PYLC_WGRAD_CUS, a multiple of 8 (A/B knob)
+        # (experimental: needs a library built with EXPERIMENTAL=1 -- pylc_stream_create_cu_mask)
         self.wgrad_cus = int(os.environ.get('PYLC_WGRAD_CUS', '0'))
         # PYLC_NO_RELU_BITS=1: BatchNorms behind a residual add re-read `out` for their ReLU mask in the backward instead of the 1-bit mask
         # their forward leaves (A/B knob)
@@ -51,6 +52,8 @@ class _Runtime:
         # PYLC_FUSE_BN_SUMS=1: a conv dgrad that writes the complete gradient of a BatchNorm output takes that BatchNorm's backward sums in its
         # epilogue (pylc_conv2d_dgrad_bn) and the BatchNorm skips its reduction pass.  Built, tested, measured NEGATIVE (the dgrad epilogue is the
         # exposed part of those kernels: BatchNorm passes 32.7 -> 28.7 ms per step, dgrads +5 ms; 381.6 vs 386.0 tiles/s): off by default.
+        # Re-measured in round 5 with the epilogue rewritten (pl_epilogue_bn): still negative, 409 vs 414 tiles/s -- the BatchNorm input tile is
+        # fetched in the epilogue, a chain of exposed round trips.  (experimental: needs a library built with EXPERIMENTAL=1.)
         self.fuse_bn_sums = os.environ.get('PYLC_FUSE_BN_SUMS', '0') == '1'
         # precision mode 3 only: the tensors between the kernels -- conv / depthwise outputs, the gradients handed back to BatchNorm -- travel as
         # ONE fp16 plane (2 bytes per element) wherever producer and consumer both support it; PYLC_HALF_ACTS=0 keeps them fp32 (A/B knob)

@@ -23,3 +23,10 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+def needs_experimental():
+    """Skip marker for the tests of what is built only with `make -C pylc_amd/csrc EXPERIMENTAL=1` (persistent 1x1 kernels, the dgrad epilogue
+    with BatchNorm-backward sums, CU-masked streams: measured neutral / negative, absent from the product library)."""
+    from pylc_amd import lib as L
+    return pytest.mark.skipif(not L.HAS_EXPERIMENTAL, reason='needs a library built with EXPERIMENTAL=1 (off in the product)')

@@ -18,13 +18,22 @@ def test_library_exports_every_header_symbol():
     from pylc_amd import lib as L
     hdr = open(os.path.join(ROOT, 'include', 'pylc_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = sorted(set(re.findall(r'\b(pylc_[a-z0-9_]+)\s*\(', hdr)))
+    # entry points inside `#ifdef PYLC_EXPERIMENTAL ... #endif` exist only in a library built with EXPERIMENTAL=1 (pylc_amd/csrc/Makefile)
+    experimental = sorted(set(n for blk in re.findall(r'#ifdef PYLC_EXPERIMENTAL(.*?)#endif', hdr, flags=re.S)
+                              for n in re.findall(r'\b(pylc_[a-z0-9_]+)\s*\(', blk)))
+    assert set(experimental) == set(L.EXPERIMENTAL)
+    core = re.sub(r'#ifdef PYLC_EXPERIMENTAL.*?#endif', '', hdr, flags=re.S)
+    declared = sorted(set(re.findall(r'\b(pylc_[a-z0-9_]+)\s*\(', core)))
     assert len(declared) >= 40
     dll = ctypes.CDLL(L.LIB_PATH)
-    for name in declared:
+    assert bool(dll.pylc_experimental_build()) == L.HAS_EXPERIMENTAL
+    for name in declared + (experimental if L.HAS_EXPERIMENTAL else []):
         assert hasattr(dll, name), 'libpylc_hip.so does not export %s' % name
         assert name in L.SIGNATURES, 'pylc_amd/lib.py has no binding for %s' % name
-    assert set(L.SIGNATURES) <= set(declared)
+    if not L.HAS_EXPERIMENTAL:
+        for name in experimental:
+            assert not hasattr(dll, name), 'the product library exports the experimental %s' % name
+    assert set(L.SIGNATURES) <= set(declared) | set(experimental)
     assert dll.pylc_abi_version() == L.ABI_VERSION
 
 

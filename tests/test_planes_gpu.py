@@ -9,6 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+from tests.conftest import needs_experimental      # noqa: E402
 
 
 def rnd(seed, *shape, scale=1.0):
@@ -251,6 +252,7 @@ def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
     assert max(e) < 1e-3, e
 
 
+@needs_experimental()
 @pytest.mark.parametrize('shape', [(2, 64, 256, 1024), (2, 64, 1024, 256), (1, 128, 64, 256), (2, 70, 256, 48), (1, 96, 72, 200)])
 @pytest.mark.parametrize('mode', [2, 3])
 def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
@@ -295,6 +297,7 @@ def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
         check(lib.pylc_set_conv_precision(prev))
 
 
+@needs_experimental()
 @pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('shape', [(8, 64, 256, 1024), (8, 61, 96, 200), (2, 128, 64, 256), (8, 64, 1024, 256)])
 def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
@@ -340,6 +343,7 @@ def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypa
         check(lib.pylc_set_conv_precision(prev))
 
 
+@needs_experimental()
 def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, monkeypatch):
     """The three launch kinds conv_ps.hip takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
     of gradient), and the dgrad that adds the ReLU-masked residual gradient in its epilogue (conv1 of an identity bottleneck,

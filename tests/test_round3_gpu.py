@@ -13,6 +13,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+from tests.conftest import needs_experimental      # noqa: E402
 
 
 def rnd(seed, *shape, scale=1.0):
@@ -192,6 +193,7 @@ def test_resnet_boundary_hands_out_fp32_unless_opted_in(dev):
         ops.PLANES_MIN_PIXELS = prev
 
 
+@needs_experimental()
 def test_cu_masked_stream_runs_kernels(dev):
     from pylc_amd import ops
     from pylc_amd.lib import PylcError
@@ -287,6 +289,7 @@ def test_residual_gradient_formed_in_the_dgrad_epilogue(dev, planes_min):
         check(lib.pylc_set_conv_precision(prev))
 
 
+@needs_experimental()
 @pytest.mark.parametrize('planes_min', [0])
 def test_bn_backward_sums_taken_in_the_dgrad_epilogue(dev, planes_min):
     """A conv dgrad that writes the complete gradient of a BatchNorm output takes that BatchNorm's backward sums (sum g, sum g xhat, max |g|)
