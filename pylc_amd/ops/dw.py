@@ -12,6 +12,35 @@ def _dw_desc(x, stride, dil, xp, yp):
     return d
 
 
+class _wgrad_stream:
+    """Context of a depthwise filter-gradient launch: on the wgrad SIDE stream, like the dense convs' (ops.conv Conv2dFn.backward), when the
+    gradient goes straight into the optimiser's arena (nobody on the main stream reads it before sync_side_streams()) -- the filter gradient is
+    off the critical chain, and in the Xception step (BASELINE configs[4]) the main queue is the busy one: 56 of 58 ms against 14 ms on the
+    side queue (profiles/r04_c5_trace_streams.txt), 3.2 ms of it depthwise wgrad + combine.  The side stream first waits for the main
+    stream's position (dy and, with a deferred BatchNorm, its coefficients were produced there); the tensors the kernels read are kept alive
+    until the streams are joined.  PYLC_DW_WGRAD_MAIN=1 keeps it on the compute stream (A/B knob)."""
+
+    def __init__(self, device, tgt, *reads):
+        self.side = None
+        if tgt is not None and _runtime.wgrad_side_stream and not os.environ.get('PYLC_DW_WGRAD_MAIN'):
+            self.side = _side_stream(device)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.side.wait_event(ev)
+            _keep_for_side(device, *reads)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.side is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            return self.ctx.__exit__(*a)
+        return False
+
+
 class DwConv3x3Fn(torch.autograd.Function):
     """Depthwise 3x3 (xception.py:29-31 with fixed_padding folded in).  Always returns a tuple (y, statistics partials or None, range bound
     or None): precision mode 3 with half activations runs the stride-1 / dilation-1 shapes on ONE-PLANE fp16 tensors (pylc_dwconv3x3_*_h:
@@ -123,15 +152,16 @@ class DwConv3x3Fn(torch.autograd.Function):
                     else:
                         link.buf = None
             if ctx.needs_input_grad[1]:
-                nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
-                ws = _ws(nbytes, x.device)
                 tgt = _grad_target(w)
-                dw = tgt if tgt is not None else torch.empty_like(w)
-                if bn_coef is not None:
-                    check(lib.pylc_dwconv3x3_wgrad_h_bn(C.byref(d), ptr(x), ptr(yin_bound), ptr(bn_coef[2 * c:3 * c]), ptr(bn_coef[3 * c:]),
-                                                        int(ctx.bn_relu), ptr(x_bound), ptr(dy), ptr(dy_bound), ptr(dw), ptr(ws), nbytes, st))
-                else:
-                    check(lib.pylc_dwconv3x3_wgrad_h(C.byref(d), ptr(x), ptr(x_bound), ptr(dy), ptr(dy_bound), ptr(dw), ptr(ws), nbytes, st))
+                with _wgrad_stream(x.device, tgt, x, x_bound, dy, dy_bound, bn_coef, yin_bound, w, wa):
+                    nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
+                    ws = _ws(nbytes, x.device)
+                    dw = tgt if tgt is not None else torch.empty_like(w)
+                    if bn_coef is not None:
+                        check(lib.pylc_dwconv3x3_wgrad_h_bn(C.byref(d), ptr(x), ptr(yin_bound), ptr(bn_coef[2 * c:3 * c]), ptr(bn_coef[3 * c:]),
+                                                            int(ctx.bn_relu), ptr(x_bound), ptr(dy), ptr(dy_bound), ptr(dw), ptr(ws), nbytes, stream()))
+                    else:
+                        check(lib.pylc_dwconv3x3_wgrad_h(C.byref(d), ptr(x), ptr(x_bound), ptr(dy), ptr(dy_bound), ptr(dw), ptr(ws), nbytes, stream()))
                 dw = _deliver_grad(w, dw)
             return dx, dw, None, None, None, None, None
         dy = as_nhwc(dy)
@@ -151,11 +181,12 @@ class DwConv3x3Fn(torch.autograd.Function):
                 else:
                     link.buf = None
         if ctx.needs_input_grad[1]:
-            nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
-            ws = _ws(nbytes, x.device)
             tgt = _grad_target(w)
-            dw = tgt if tgt is not None else torch.empty_like(w)
-            check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, st))
+            with _wgrad_stream(x.device, tgt, x, dy, w):
+                nbytes = lib.pylc_dwconv3x3_wgrad_workspace(C.byref(d))
+                ws = _ws(nbytes, x.device)
+                dw = tgt if tgt is not None else torch.empty_like(w)
+                check(lib.pylc_dwconv3x3_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), nbytes, stream()))
             dw = _deliver_grad(w, dw)
         return dx, dw, None, None, None, None, None
 
