@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
         xoff[i] = ((unsigned)(rowpix[i] + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * v) * 4u;
     const int bn = n0 + brow;
     // (chunk-interleaved filter planes, a.w_il: row and chunk offsets double, plane 1 sits 64 bytes behind plane 0)
-    const unsigned wil = (BPL && a.w_il) ? 2u : 1u;
+    const unsigned wil = (unsigned)__builtin_amdgcn_readfirstlane((BPL && a.w_il) ? 2 : 1);      // (wave-uniform: it scales the loads' scalar offset)
     const unsigned woff_row = bn < a.N ? ((unsigned)bn * (unsigned)a.w_row_stride * wil + 8u * v) * (BPL ? 2u : 4u) : OOB;
     const unsigned plane1 = (BPL && a.w_il) ? 64u : (unsigned)(a.w_plane_stride * 2);
     auto ldx = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4& lo, f32x4& hi) {
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gather_gemm_pp_kernel(const GatherGemm
             ldx(rx, ok ? xoff[i] + tapdelta : OOB, 0u, R.a[i][0], R.a[i][1]);
         }
         if constexpr (BPL) {       // 8 halves of plane 0 and of plane 1
-            const unsigned so = (unsigned)((woff + ld_chunk * BK) * 2) * wil;
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((woff + ld_chunk * BK) * 2) * wil));
             R.b[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row : OOB, so, 0));
             if constexpr (!ONE) R.b[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, cok ? woff_row + plane1 : OOB, so, 0));
         } else {

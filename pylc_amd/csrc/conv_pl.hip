@@ -656,7 +656,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
 
     // chunk-interleaved filter planes (a.w_il, PylcConvDesc.w_planes_fmt): the two planes of a 32-channel chunk are the two halves of ONE
     // 128-byte line, requested back to back below -- row and chunk offsets double, plane 1 sits 64 bytes behind plane 0
-    const unsigned ilmb = a.w_il ? 2u : 1u;
+    const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);      // provably wave-uniform: it scales the DMA's scalar offset
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx0 =
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
         const bool cok = ld_chunk * KS + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
         const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2);      // wave-uniform, may be "negative"
-        const unsigned so = (unsigned)((woff + ld_chunk * KS) * 2) * ilmb;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((woff + ld_chunk * KS) * 2) * ilmb));      // an SGPR operand: anything less and hipcc wraps the DMA in a waterfall loop
         char* const sa = dstA + stage * STAGE;
         char* const sb = dstB + stage * STAGE;
 #pragma unroll
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     const int hmin_h = a.dh_step > 0 ? a.dh0 : a.dh0 + 2 * a.dh_step;          // smallest tap offset = origin of the halo
     const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
 
-    const unsigned ilmb = a.w_il ? 2u : 1u;                   // chunk-interleaved filter planes, as in gg_pl_kernel
+    const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);      // chunk-interleaved filter planes, as in gg_pl_kernel (wave-uniform: scales the DMA's scalar offset)
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int c = s / 9, t = s - 9 * c;
         const int tr = t / 3, ts = t - 3 * tr;
         const bool cok = c * BK + 8 * lc < a.Cin;
-        const unsigned so = (unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilmb;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilmb));
         const unsigned vo = cok ? woff_row : OOB;
         const unsigned vo1 = cok ? woff_row + plane1_w : OOB;
         char* const d = ldsB + slot * BST + (16 * wave) * ROW;
