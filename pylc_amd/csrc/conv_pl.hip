@@ -788,10 +788,13 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)(sa + RPI * i * ROW), 16, vo, 0, 0, 0);
             if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(sa + BM * ROW + RPI * i * ROW), 16, vo, 0, 0, 0);
         }
+        // filter rows: a lane past Cin in the last chunk gets the out-of-range bit ORed onto its offset (arithmetic, not a select: hipcc turned
+        // `cok ? woff_row : OOB` into a divergent branch with the DMA issued once per side)
+        const unsigned oob = (unsigned)(a.Cin - 1 - (ld_chunk * KS + 8 * lc)) & OOB;      // sign bit of (Cin - 1 - k)
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const unsigned vo = cok ? woff_row[i] : OOB;
-            const unsigned vo1 = cok ? woff_row[i] + plane1_w : OOB;
+            const unsigned vo = woff_row[i] | oob;                    // (woff_row < 2^31, or already OOB for a row past N)
+            const unsigned vo1 = (woff_row[i] + plane1_w) | oob | (woff_row[i] & OOB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + RPI * i * ROW), 16, vo, so, 0, 0);
             if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + BN * ROW + RPI * i * ROW), 16, vo1, so, 0, 0);
         }
@@ -1000,11 +1003,11 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
 
     auto issue_halo = [&](int c) {                            // chunk c -> halo buffer c & 1
         char* const dst = lds + (c & 1) * HALO + (16 * wave) * ROW;
-        const bool cok = c * BK + 8 * lc < a.Cin;
+        const unsigned oob = (unsigned)(a.Cin - 1 - (c * BK + 8 * lc)) & OOB;
         const unsigned cb = (unsigned)(c * BK * 2);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const unsigned vo = (cok & (hoff[j] != OOB)) ? hoff[j] + cb : OOB;
+            const unsigned vo = (hoff[j] + cb) | oob | (hoff[j] & OOB);      // (hoff < 2^31 - the chunk offsets, or exactly OOB for padding / rows past the halo)
             char* const d = dst + (128 * j) * ROW;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)d, 16, vo, 0, 0, 0);
             if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(d + HPL), 16, vo, 0, 0, 0);
@@ -1013,10 +1016,10 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     auto issue_b = [&](int s, int slot) {                      // filter tile of step s = (chunk, tap) -> ring slot
         const int c = s / 9, t = s - 9 * c;
         const int tr = t / 3, ts = t - 3 * tr;
-        const bool cok = c * BK + 8 * lc < a.Cin;
+        const unsigned oob = (unsigned)(a.Cin - 1 - (c * BK + 8 * lc)) & OOB;      // lanes past Cin (last chunk): out-of-range bit, by arithmetic (gg_pl_kernel)
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilmb));
-        const unsigned vo = cok ? woff_row : OOB;
-        const unsigned vo1 = cok ? woff_row + plane1_w : OOB;
+        const unsigned vo = woff_row | oob;
+        const unsigned vo1 = (woff_row + plane1_w) | oob | (woff_row & OOB);
         char* const d = ldsB + slot * BST + (16 * wave) * ROW;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)d, 16, vo, so, 0, 0);
         if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(d + BN * ROW), 16, vo1, so, 0, 0);

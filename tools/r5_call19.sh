@@ -1,0 +1,7 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/c19
+timeout -k 10 900 python -m pytest tests/test_planes_gpu.py tests/test_ops_gpu.py tests/test_fullsize_ops_gpu.py tests/test_eval_planes_gpu.py tests/test_mode3_gpu.py -m gpu -q -x > gpurun_out/c19/tests.log 2>&1; rc=$?
+tail -3 gpurun_out/c19/tests.log
+[ $rc -ne 0 ] && exit $rc
+ROUNDS=2 bash tools/ab_libs.sh c19 pylc_amd/libpylc_hip_prev.so pylc_amd/libpylc_hip.so 2>&1 | tee gpurun_out/c19/ab.txt
