@@ -643,6 +643,9 @@ int pylc_debug_ps(int on);
 int pylc_debug_dw_tiles(int on);
 /* wgrad_pl.hip: 1 runs the 128 x 128 f16x3 wgrad with one accumulator set under 128 registers per wave (A/B knob) */
 int pylc_debug_wgrad_acc1(int on);
+/* wgrad_pl.hip: operand staging register sets -- 0: one set, the loads of tile s + 1 fly while tile s is multiplied; 1 (default): two sets
+ * (loads two tiles ahead, counted vmcnt) for multi-tap filters; 2: two sets for every wgrad.  A/B knob, env PYLC_WG_SETS (DESIGN.md 5.2 g). */
+int pylc_debug_wgrad_sets(int mode);
 /* wgrad_pl.hip rasterisation experiments (tools/wgrad_traffic.py): bit 0 = blocks in plain blockIdx order (no XCD remap), bit 1 = split
  * index fastest (the blocks that share a pixel chunk far apart), bit 2 = taps slowest (the round-3 order).  0 = the product's order
  * (taps fastest, split slowest, XCD-contiguous). */

@@ -25,7 +25,7 @@ namespace pylc {
 // arrive).  What it buys is registers: 64 instead of 128 accumulators put the kernel under 128 VGPRs, so that with two blocks per CU
 // (an LDS reservation keeps a third and fourth out) half of every SIMD's register file stays free for the BatchNorm kernels of the
 // main stream -- with the efficient 64 x 64 wave tiles, unlike the 8-wave experiment above.
-template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false>
+template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false, int SETS = 1>
 __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const WgradArgs a) {
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
     constexpr int WAVES_C = BC / WC;
@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(unsigned)a.x_bytes, 0x00020000);
 
-    uint4 ra[IA][NPL], rb[IB][NPL];
+    // Operand staging registers, TWO sets (round 5): the loads of tile s + 2 are in flight while tile s is computed.  With one set the loads
+    // of tile s + 1 had one K-step (~3 k cycles with the CU's other block) to come back from L2 / HBM and the step waited for them: PMC
+    // showed the matrix pipe busy 0.43 of the kernel's cycles with two 1536-cycle MFMA phases per SIMD and step.
+    constexpr int NSET = SETS;
+    uint4 ra[NSET][IA][NPL], rb[NSET][IB][NPL];
     int f_mb = m_begin, f_q0 = 0, f_p = 0, f_b = 0;
     unsigned f_va[IA], f_tx[IB];
     int f_wc[IB];
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         dst[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r0, voff, soff, 0));
         if constexpr (NPL == 2) dst[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, soff, 0));
     };
-    auto load_tile = [&]() {
+    auto load_tile = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
         const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 2u;
         if constexpr (FAST == 2) {
             const unsigned colb = (unsigned)(c0 + 8 * vb);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
                 const int hi = g_p[i] * a.in_sh + dh, wi = g_q[i] * a.in_sw + dw;
                 const bool ok = b_col_ok & (f_mb + prb + RB * i < m_end) & ((unsigned)hi < (unsigned)a.IH) & ((unsigned)wi < (unsigned)a.IW);
                 const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch + colb) * 2u;
-                ldp(rx0, rx1, ok ? off : OOB, 0u, rb[i]);
+                ldp(rx0, rx1, ok ? off : OOB, 0u, rb[set][i]);
                 g_q[i] += 32;
                 while (g_q[i] >= a.Q) { g_q[i] -= a.Q; ++g_p[i]; }
                 while (g_p[i] >= a.P) { g_p[i] -= a.P; ++g_b[i]; }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 const bool ok = f_mb + pra + RA * i < m_end;
-                ldp(rdy0, rdy1, ok ? f_va[i] : OOB, soff, ra[i]);
+                ldp(rdy0, rdy1, ok ? f_va[i] : OOB, soff, ra[set][i]);
             }
             f_mb += 32;
             return;
@@ -171,10 +176,10 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const bool ok = row_ok & ((unsigned)(f_wc[i] + wq) < (unsigned)a.IW);
-            ldp(rx0, rx1, ok ? f_tx[i] + delta : OOB, 0u, rb[i]);
+            ldp(rx0, rx1, ok ? f_tx[i] + delta : OOB, 0u, rb[set][i]);
         }
 #pragma unroll
-        for (int i = 0; i < IA; ++i) ldp(rdy0, rdy1, f_va[i], soff, ra[i]);
+        for (int i = 0; i < IA; ++i) ldp(rdy0, rdy1, f_va[i], soff, ra[set][i]);
         f_mb += 32;
         f_q0 += 32;
         if (f_q0 == a.Q) {
@@ -182,18 +187,19 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
             if (++f_p == a.P) { f_p = 0; ++f_b; }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
         if (A_ALL || pra < 32) {
 #pragma unroll
             for (int i = 0; i < IA; ++i)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sA + pl * PLA + (pra + RA * i) * ROWA + 16 * va) = ra[i][pl];
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sA + pl * PLA + (pra + RA * i) * ROWA + 16 * va) = ra[set][i][pl];
         }
         if (B_ALL || prb < 32) {
 #pragma unroll
             for (int i = 0; i < IB; ++i)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sB + pl * PLB + (prb + RB * i) * ROWB + 16 * vb) = rb[i][pl];
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sB + pl * PLB + (prb + RB * i) * ROWB + 16 * vb) = rb[set][i][pl];
         }
     };
     // transpose-read addressing (as wgrad_split_kernel): group g = lane>>4 covers channels 16*(g&1).., reduction half h = g>>1
@@ -201,62 +207,82 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const char* fa_base = sA + (8 * h + q4) * ROWA + 2 * (wave_n * WN + 16 * (g & 1) + 4 * p4);
     const char* fb_base = sB + (8 * h + q4) * ROWB + 2 * (wave_c * WC + 16 * (g & 1) + 4 * p4);
 
-    if (S > 0) {
-        load_tile();
-        for (int s = 0; s < S; ++s) {
-            if (s > 0) __syncthreads();
-            store_tile();
-            __syncthreads();
-            if (s + 1 < S) load_tile();
+    auto compute_tile = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[NT][NPL], fb[CT][NPL];
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[NT][NPL], fb[CT][NPL];
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
+                for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = tr_frag(fa_base + pl * PLA + 16 * ks * ROWA + 64 * i, ROWA);
 #pragma unroll
-                for (int j = 0; j < CT; ++j)
+            for (int j = 0; j < CT; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
-                if constexpr (NTERMS == 3 && ACC1) {
-                    // cross terms first, each term over all four accumulators (a dependent MFMA is four instructions away)
-                    const _Float16 k11 = (_Float16)(1.f / 2048.f);
-                    f16x8 a1s[NT], b1s[CT];
+                for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(fb_base + pl * PLB + 16 * ks * ROWB + 64 * j, ROWB);
+            if constexpr (NTERMS == 3 && ACC1) {
+                // cross terms first, each term over all four accumulators (a dependent MFMA is four instructions away)
+                const _Float16 k11 = (_Float16)(1.f / 2048.f);
+                f16x8 a1s[NT], b1s[CT];
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) a1s[i] = __builtin_bit_cast(f16x8, fa[i][1]) * k11;
+                for (int i = 0; i < NT; ++i) a1s[i] = __builtin_bit_cast(f16x8, fa[i][1]) * k11;
 #pragma unroll
-                    for (int j = 0; j < CT; ++j) b1s[j] = __builtin_bit_cast(f16x8, fb[j][1]) * k11;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int j = 0; j < CT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s[i], __builtin_bit_cast(f16x8, fb[j][0]), acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int j = 0; j < CT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), b1s[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-#pragma unroll
-                        for (int j = 0; j < CT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[j][0]),
-                                                                               acc[i][j], 0, 0, 0);
-                } else
+                for (int j = 0; j < CT; ++j) b1s[j] = __builtin_bit_cast(f16x8, fb[j][1]) * k11;
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int j = 0; j < CT; ++j) {
-                        const f16x8 a0 = __builtin_bit_cast(f16x8, fa[i][0]), b0 = __builtin_bit_cast(f16x8, fb[j][0]);
-                        if constexpr (NTERMS == 3) {
-                            const f16x8 a1 = __builtin_bit_cast(f16x8, fa[i][NPL - 1]), b1 = __builtin_bit_cast(f16x8, fb[j][NPL - 1]);
-                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
-                            acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s[i], __builtin_bit_cast(f16x8, fb[j][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), b1s[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, fb[j][0]),
+                                                                           acc[i][j], 0, 0, 0);
+            } else
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, fa[i][0]), b0 = __builtin_bit_cast(f16x8, fb[j][0]);
+                    if constexpr (NTERMS == 3) {
+                        const f16x8 a1 = __builtin_bit_cast(f16x8, fa[i][NPL - 1]), b1 = __builtin_bit_cast(f16x8, fb[j][NPL - 1]);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_lo[i][j], 0, 0, 0);
                     }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    typedef std::integral_constant<int, 0> Set0;
+    typedef std::integral_constant<int, NSET - 1> Set1;
+    // One K-step: hand the staged tile to LDS, refill its register set with tile s + NSET, multiply.  The refill is UNCONDITIONAL -- past the
+    // end of the block's reduction it fetches rows nobody stores (zeros beyond the buffers' ends; at most two extra tiles per block) -- so that
+    // the loop body is straight-line and hipcc's counted vmcnt before the LDS writes leaves exactly the OTHER set's eight loads in flight (with
+    // a conditional refill it merges the two control-flow states and drains everything: seen in the listing).
+    auto step = [&](auto setc, int s) {
+        if (s > 0) __syncthreads();
+        store_tile(setc);
+        __syncthreads();
+        if (NSET == 2 || s + 1 < S) load_tile(setc);
+        compute_tile();
+    };
+    if (S > 0) {
+        int s = 0;
+        load_tile(Set0{});
+        if constexpr (NSET == 2) {
+            load_tile(Set1{});
+            for (; s + 1 < S; s += 2) {
+                step(Set0{}, s);
+                step(Set1{}, s + 1);
             }
+            if (s < S) step(Set0{}, s);
+        } else {
+            for (; s < S; ++s) step(Set0{}, s);
         }
     }
 
@@ -289,6 +315,12 @@ constexpr size_t wgpl_smem() { return (size_t)(NTERMS == 3 ? 2 : 1) * 32 * (wg_r
 // 159 -> 98): 352-354 vs 376 tiles/s; raising the conv kernels' wave priority (s_setprio 3) does not change that.  OFF by default.
 int g_wg_flags = 0;          // rasterisation experiments (WgradArgs::dbg_flags)
 extern "C" int pylc_debug_wgrad_flags(int flags) { g_wg_flags = flags; return PYLC_OK; }
+// Measured (profiles/r05_ab_runs.txt): two sets take the isolated wgrad from 20.1 to 19.7 ms per step and, inside the step, finish the side
+// queue early enough that the dgrads beside it gain 1.7 ms (dgrad1x1 143 -> 160, dgrad3x3 300 -> 316 TFLOP/s) -- which the BatchNorm passes,
+// now sharing HBM with a hungrier wgrad, give back (31.8 -> 33.6 ms): the step is unchanged with policy 1 (405.5 vs 405.0 tiles/s) and 0.4 %
+// slower with policy 2 (the 1x1 wgrads move as many bytes per FLOP as the BatchNorm passes they run beside).  Default 1.
+int g_wg_sets = 1;        // staging register sets policy (pylc_debug_wgrad_sets)
+extern "C" int pylc_debug_wgrad_sets(int mode) { g_wg_sets = mode; return PYLC_OK; }
 int g_wg_acc1 = 0;        // 1: the 128 x 128 f16x3 wgrad runs its one-accumulator, <= 128-register form (pylc_debug_wgrad_acc1)
 extern "C" int pylc_debug_wgrad_acc1(int on) { g_wg_acc1 = on; return PYLC_OK; }
 constexpr size_t kAcc1LdsReserve = 72 * 1024;      // two blocks per CU, not four: the other half of the register file is for other kernels
@@ -305,13 +337,21 @@ static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
             return PYLC_OK;
         }
     }
+    // two staging sets (loads two tiles ahead): pylc_debug_wgrad_sets -- 0 never, 1 multi-tap filters only, 2 always
+    const bool two = g_wg_sets == 2 || (g_wg_sets == 1 && a.TR * a.TS > 1);
     if (a.nterms == 1) {
         constexpr size_t lds = wgpl_smem<BN, BC, 1>();
-        if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>), g, b, lds, st, a);
+        if (two) {
+            if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1, false, 2>), g, b, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2, false, 2>), g, b, lds, st, a);
+        } else if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>), g, b, lds, st, a);
         else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>), g, b, lds, st, a);
     } else {
         constexpr size_t lds = wgpl_smem<BN, BC, 3>();
-        if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1>), g, b, lds, st, a);
+        if (two) {
+            if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, false, 2>), g, b, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, false, 2>), g, b, lds, st, a);
+        } else if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1>), g, b, lds, st, a);
         else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2>), g, b, lds, st, a);
     }
     PYLC_LAUNCH_CHECK();
@@ -342,7 +382,11 @@ int wgrad_pl_init() {
     PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 3, 1>, wgpl_smem<BN, BC, 3>()));                  \
     PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 3, 2>, wgpl_smem<BN, BC, 3>()));                  \
     PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 1>, wgpl_smem<BN, BC, 1>()));                  \
-    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>, wgpl_smem<BN, BC, 1>()));
+    PYLC_HIP(opt_in(wgrad_pl_kernel<BN, BC, WN, WC, 1, 2>, wgpl_smem<BN, BC, 1>()));                  \
+    PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, false, 2>), wgpl_smem<BN, BC, 3>()));      \
+    PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, false, 2>), wgpl_smem<BN, BC, 3>()));      \
+    PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1, false, 2>), wgpl_smem<BN, BC, 1>()));      \
+    PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2, false, 2>), wgpl_smem<BN, BC, 1>()));
     PYLC_OPT(128, 128, 64, 64)
     PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 1, true>, kAcc1LdsReserve));
     PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 2, true>, kAcc1LdsReserve));
