@@ -145,6 +145,15 @@ int pylc_amax_segments(const float* base, const long long* offsets, int count, u
  * fp32 operand, written ONCE by the tensor's producer (4 bytes per element, like fp32) so that the conv kernels copy operand
  * tiles to LDS by LDS-DMA with no arithmetic.  nplanes = 1 writes / reads plane 0 only (precision mode 3).
  * Replaces nothing in the reference: it is the HBM layout of the activations between the BatchNorm and conv kernels. */
+/* Chunk-interleaved two-plane tensors (round 5).  `plane_stride == 32` in any of the entry points below (and in PylcBnExtra, pylc_maxpool_fwd_planes,
+ * pylc_gap_fwd_planes, ...) says: flat element e of the dense [M][C] tensor (C % 32 == 0) is at halves (e >> 5) * 64 + (e & 31) for plane 0 and
+ * + 32 for plane 1, i.e. the two planes of a 32-channel chunk -- one K-step of the conv kernels -- share ONE 128-byte line (LDS-DMA requests
+ * both halves back to back: 21.8 -> 31.7 TB/s L2 -> LDS, profiles/r04_dma_piece.txt).  Any other value: two plane arrays that many halves apart.
+ * pylc_planes_stride(M, C, nplanes) is THE rule every producer and consumer follows (32 iff nplanes == 2, C % 32 == 0, 4 M C < 2^31 and the
+ * format is on); the conv entry points derive the strides of their plane operands from it, so a caller allocates and passes what it returns.
+ * pylc_set_planes_interleave(0) switches the format off process-wide (A/B). */
+long long pylc_planes_stride(long long M, int C, int nplanes);
+int pylc_set_planes_interleave(int on);
 int pylc_to_planes(const float* x, int x_pitch, void* planes, int p_pitch, long long plane_stride, long long M, int C,
                    const unsigned int* amax, int nplanes, void* stream);
 int pylc_from_planes(const void* planes, int p_pitch, long long plane_stride, float* x, int x_pitch, long long M, int C,

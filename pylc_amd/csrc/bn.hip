@@ -35,7 +35,9 @@ __device__ __forceinline__ void planes_store4(const PlanesRef& p, long long elem
         recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: lane ^ 1
         recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
         const uint4 val = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
-        _Float16* dst = odd ? p.base + p.plane_stride + elem - 4 : p.base + elem;
+        // (chunk-interleaved tensor, plane_stride == 32: the pair's 8 channels sit in one 32-channel chunk, plane 1 is 32 halves on)
+        const bool il = planes_il(p.plane_stride);
+        _Float16* dst = odd ? p.base + p.plane_stride + planes_phys(elem - 4, il) : p.base + planes_phys(elem, il);
         *reinterpret_cast<uint4*>(dst) = val;
     } else {
         *reinterpret_cast<uint2*>(p.base + elem) = p0;
@@ -46,8 +48,9 @@ __device__ __forceinline__ void planes_store4(const PlanesRef& p, long long elem
 struct PlanesRaw { uint2 h0, h1; };
 __device__ __forceinline__ PlanesRaw planes_raw4(const PlanesRef& p, long long elem) {
     PlanesRaw r;
-    r.h0 = *reinterpret_cast<const uint2*>(p.base + elem);
-    r.h1 = p.nplanes == 2 ? *reinterpret_cast<const uint2*>(p.base + p.plane_stride + elem) : make_uint2(0u, 0u);
+    const long long e = planes_phys(elem, p.nplanes == 2 && planes_il(p.plane_stride));
+    r.h0 = *reinterpret_cast<const uint2*>(p.base + e);
+    r.h1 = p.nplanes == 2 ? *reinterpret_cast<const uint2*>(p.base + p.plane_stride + e) : make_uint2(0u, 0u);
     return r;
 }
 __device__ __forceinline__ f32x4 halves4(uint2 u) {

@@ -37,6 +37,23 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 template <typename T>
 __host__ __device__ inline T cdiv(T a, T b) { return (a + b - 1) / b; }
 
+// Chunk-interleaved two-plane tensors (round 5; include/pylc_hip.h "fp16 planes"): `plane_stride == 32` says that flat element e of the
+// dense [pixels][C] tensor (C % 32 == 0) lives at halves (e >> 5) * 64 + (e & 31) for plane 0 and + 32 for plane 1 -- the two planes of a
+// 32-channel chunk (one K-step of the conv kernels) share ONE 128-byte line.  Any other stride: two separate plane arrays.
+constexpr long long kPlanesIL = 32;
+__host__ __device__ inline bool planes_il(long long plane_stride) { return plane_stride == kPlanesIL; }
+__host__ __device__ inline long long planes_phys(long long e, bool il) { return il ? ((e >> 5) << 6) + (e & 31) : e; }
+__host__ __device__ inline long long planes_p1(long long plane_stride) { return plane_stride; }      // (interleaved: 32 == the sentinel itself)
+
+// THE rule (one place): a two-plane tensor of M pixels x C channels is chunk-interleaved iff its rows are dense, C is a multiple of 32 and
+// both planes fit one 2 GiB buffer descriptor; everything that allocates, writes or reads such a tensor derives its plane stride from here
+// (C ABI: pylc_planes_stride; pylc_set_planes_interleave(0) switches the format off process-wide -- A/B, env PYLC_NO_PLANE_INTERLEAVE).
+extern int g_planes_interleave;
+inline long long planes_stride_rule(long long M, int C, int pitch, int nplanes) {
+    const bool il = nplanes == 2 && g_planes_interleave && pitch == C && C % 32 == 0 && M * C * 4 < (1ll << 31);
+    return il ? kPlanesIL : M * pitch;
+}
+
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;
 

@@ -1794,7 +1794,7 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
     a.w_il = (d->w_planes != nullptr && (d->w_planes_fmt & 1)) ? 1 : 0;
     if (d->x_fmt == 1) {                     // x points at plane 0 of an fp16-plane tensor
         a.x_planes = x; a.x = nullptr;
-        a.x_plane_stride = (long long)d->B * d->H * d->W * d->x_pitch;
+        a.x_plane_stride = planes_stride_rule((long long)d->B * d->H * d->W, d->Cin, d->x_pitch, (g_conv_precision == 3 ? 1 : 2));
         a.x_bytes /= 2;                      // bytes of ONE plane
     }
     a.P = d->OH; a.Q = d->OW; a.M = d->B * d->OH * d->OW;
@@ -1813,13 +1813,13 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
         if (ex->residual != nullptr) {
             a.ep_res = static_cast<const float*>(ex->residual);
             a.ep_res_fmt = ex->res_fmt; a.ep_res_scale = ex->res_scale_bound; a.ep_res_amax = ex->res_amax;
-            a.ep_res_plane_stride = (long long)d->B * d->OH * d->OW * d->Cout;
+            a.ep_res_plane_stride = planes_stride_rule((long long)d->B * d->OH * d->OW, d->Cout, d->Cout, ex->res_fmt == 2 ? 2 : 1);
         }
         if (d->out_fmt != 0) {
             PYLC_REQUIRE((d->out_fmt == 1 || d->out_fmt == 2) && d->y_pitch == d->Cout && d->Cout % 4 == 0,
                          "conv2d_fwd_bnact_ex: a plane output (out_fmt 1 / 2) needs a dense y with Cout %% 4 == 0");
             a.out_half = d->out_fmt == 1; a.out_planes2 = d->out_fmt == 2;
-            a.out_plane_stride = (long long)d->B * d->OH * d->OW * d->Cout;
+            a.out_plane_stride = planes_stride_rule((long long)d->B * d->OH * d->OW, d->Cout, d->y_pitch, d->out_fmt == 2 ? 2 : 1);
             a.out_bound_k = (float)(d->Cin * d->R * d->S); a.out_bound = d->out_bound;
         }
     } else if (d->out_fmt == 1) {
@@ -1909,7 +1909,7 @@ static int conv2d_dgrad_impl(const PylcConvDesc* d, const float* dy, const float
     a.w_il = (d->w_planes_t != nullptr && (d->w_planes_fmt & 2)) ? 1 : 0;
     if (d->dy_fmt == 1) {
         a.x_planes = dy; a.x = nullptr;
-        a.x_plane_stride = (long long)d->B * d->OH * d->OW * d->y_pitch;
+        a.x_plane_stride = planes_stride_rule((long long)d->B * d->OH * d->OW, Kp, d->y_pitch, (g_conv_precision == 3 ? 1 : 2));
         a.x_bytes /= 2;
     }
     a.IH = d->OH; a.IW = d->OW; a.Cin = Kp; a.x_pitch = d->y_pitch;
@@ -2089,8 +2089,8 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
         PYLC_REQUIRE(g_conv_precision >= 2 && !p.cin4 && d->Cout % 8 == 0, "conv2d_wgrad: fp16-plane operands need precision mode 2 or 3, "
                      "a dense geometry and Cout %% 8 == 0");
         a.x_planes = x; a.dy_planes = dy; a.x = nullptr; a.dy = nullptr;
-        a.x_plane_stride = (long long)d->B * d->H * d->W * d->x_pitch;
-        a.dy_plane_stride = (long long)d->B * d->OH * d->OW * d->y_pitch;
+        a.x_plane_stride = planes_stride_rule((long long)d->B * d->H * d->W, d->Cin, d->x_pitch, (g_conv_precision == 3 ? 1 : 2));
+        a.dy_plane_stride = planes_stride_rule((long long)d->B * d->OH * d->OW, d->Cout, d->y_pitch, (g_conv_precision == 3 ? 1 : 2));
         a.N_ld = d->Cout;
         a.x_bytes /= 2; a.dy_bytes = (((long long)d->B * d->OH * d->OW - 1) * d->y_pitch + a.N_ld) * 2;
         a.nterms = g_conv_precision == 3 ? 1 : 3;

@@ -459,7 +459,9 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                 for (int i = 0; i < AM; ++i) {
                     const int e = eoff[i][j0 + jj];
                     uint4 q;
-                    _Float16* dst = reinterpret_cast<_Float16*>(a.y) + (odd_row ? e - 4 : e);
+                    // (two planes, chunk-interleaved output -- out_plane_stride == 32, common.h: the pair's 8 channels lie in one chunk)
+                    const bool ilo = !a.out_half && planes_il(a.out_plane_stride);
+                    _Float16* dst = reinterpret_cast<_Float16*>(a.y) + planes_phys(odd_row ? e - 4 : e, ilo);
                     if (a.out_half) {
                         const f32x4v_ v = acc[i][j0 + jj] * hscale;
                         const f16x4_ h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -532,7 +534,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                     // lanes l / l + 16 (same pixel, adjacent channel quads): the even row fetches 16 bytes of plane 0, the odd row the same 8
                     // channels of plane 1, and they swap halves (as the stores above, reversed)
                     uint4 q = {0u, 0u, 0u, 0u};
-                    if (e >= 0) q = *reinterpret_cast<const uint4*>(rp + (odd_row ? e - 4 + a.ep_res_plane_stride : e));
+                    if (e >= 0) q = *reinterpret_cast<const uint4*>(rp + planes_phys(odd_row ? e - 4 : e, planes_il(a.ep_res_plane_stride)) + (odd_row ? a.ep_res_plane_stride : 0));
                     const u32x2_ s0 = __builtin_amdgcn_permlane16_swap(q.x, q.z, false, false);      // even: q.z <- partner's q.x; odd: q.x <- partner's q.z
                     const u32x2_ s1 = __builtin_amdgcn_permlane16_swap(q.y, q.w, false, false);
                     // even rows now hold (p0 own: s0.x s1.x | p1 own: s0.y s1.y); odd rows (p0 own: s0.x s1.x | p1 own: s0.y s1.y) as well
@@ -657,12 +659,16 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
     // chunk-interleaved filter planes (a.w_il, PylcConvDesc.w_planes_fmt): the two planes of a 32-channel chunk are the two halves of ONE
     // 128-byte line, requested back to back below -- row and chunk offsets double, plane 1 sits 64 bytes behind plane 0
     const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);      // provably wave-uniform: it scales the DMA's scalar offset
+    // ... and the same layout for the PIXEL operand (a.x_plane_stride == 32, common.h planes_il: written so by BatchNorm / to_planes for tensors
+    // of a multiple of 32 channels): pixel and chunk offsets double, plane 1 is 64 bytes behind plane 0, one descriptor spans both planes
+    const bool ila = NPL == 2 && planes_il(a.x_plane_stride);
+    const unsigned ilma = (unsigned)__builtin_amdgcn_readfirstlane(ila ? 2 : 1);
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * ilma), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(a.x_bytes * ilma - (ila ? 64 : 0)), 0x00020000);
 
     // ---- filter rows of this thread: no geometry needed, so their first DMA goes out before anything else ----
     unsigned woff_row[BI];
@@ -686,14 +692,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         if (ident) {                       // 1x1, stride 1, no padding: input pixel == output pixel, no decode
             rowh[i] = ok ? 0 : -(1 << 28);
             roww[i] = 0;
-            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch + 8u * lc) * 2u;
+            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch * ilma + 8u * lc) * 2u;
         } else {
             const int mm = ok ? m : 0;
             const int q = mm % a.Q, t = mm / a.Q;
             const int p = t % a.P, b = t / a.P;
             rowh[i] = ok ? p * a.in_sh : -(1 << 28);          // invalid rows fail every bounds check
             roww[i] = q * a.in_sw;
-            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch + 8u * lc) * 2u;      // garbage for invalid rows (masked)
+            xoff[i] = ((unsigned)(b * a.IH * a.IW + rowh[i] * a.IW + roww[i]) * (unsigned)a.x_pitch * ilma + 8u * lc) * 2u;      // garbage for invalid rows (masked)
         }
     }
     // output row table (read by the epilogue; the first barrier of the main loop orders it)
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
         const int dh = a.dh0 + ld_tr * a.dh_step, dw = a.dw0 + ld_ts * a.dw_step;
         const int woff = a.w_off0 + ld_tr * a.w_step_r + ld_ts * a.w_step_s;
         const bool cok = ld_chunk * KS + 8 * lc < a.Cin;                 // Cin % 8 == 0; only the last chunk can be partial
-        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2);      // wave-uniform, may be "negative"
+        const unsigned tapdelta = (unsigned)(((dh * a.IW + dw) * a.x_pitch + ld_chunk * KS) * 2) * ilma;      // wave-uniform, may be "negative"
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((woff + ld_chunk * KS) * 2) * ilmb));      // an SGPR operand: anything less and hipcc wraps the DMA in a waterfall loop
         char* const sa = dstA + stage * STAGE;
         char* const sb = dstB + stage * STAGE;
@@ -961,11 +967,13 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
 
     const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);      // chunk-interleaved filter planes, as in gg_pl_kernel (wave-uniform: scales the DMA's scalar offset)
+    const bool ila = NPL == 2 && planes_il(a.x_plane_stride);                             // ... and chunk-interleaved pixel planes
+    const unsigned ilma = (unsigned)__builtin_amdgcn_readfirstlane(ila ? 2 : 1);
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * ilma), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(a.x_bytes * ilma - (ila ? 64 : 0)), 0x00020000);
 
     // filter row of this thread (one 16-row piece per wave)
     const int nrow = n0 + 16 * wave + (lane >> 2);
@@ -979,7 +987,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
         const int hy = h / PLH_HW, hx = h - hy * PLH_HW;
         const int yy = y0 + hmin_h + hy, xx = x0 + hmin_w + hx;
         const bool ok = (h < PLH_HW * PLH_HW) & ((unsigned)yy < (unsigned)a.IH) & ((unsigned)xx < (unsigned)a.IW);
-        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch + 8u * lc) * 2u : OOB;
+        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch * ilma + 8u * lc) * 2u : OOB;
     }
     // output rows: patch pixel (py, px) = (row >> 4, row & 15)
     if (tid < BM) {
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     auto issue_halo = [&](int c) {                            // chunk c -> halo buffer c & 1
         char* const dst = lds + (c & 1) * HALO + (16 * wave) * ROW;
         const unsigned oob = (unsigned)(a.Cin - 1 - (c * BK + 8 * lc)) & OOB;
-        const unsigned cb = (unsigned)(c * BK * 2);
+        const unsigned cb = (unsigned)(c * BK * 2) * ilma;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const unsigned vo = (hoff[j] + cb) | oob | (hoff[j] & OOB);      // (hoff < 2^31 - the chunk offsets, or exactly OOB for padding / rows past the halo)
@@ -1133,6 +1141,8 @@ extern "C" int pylc_debug_stagger(int units) { g_stagger = units; return PYLC_OK
 bool takes_pl(const GatherGemmArgs& a) {
     const bool aligned = a.y_pitch % 4 == 0 && a.N_store % 4 == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(a.x_planes) & 15) == 0 && (a.x_plane_stride % 8) == 0 && a.x_pitch % 8 == 0;
+    const bool ila = a.nterms == 3 && planes_il(a.x_plane_stride);      // chunk-interleaved pixel planes: one descriptor spans both planes
+    if (ila && (a.Cin % 32 != 0 || a.x_pitch != a.Cin || a.x_bytes >= (1ll << 30))) return false;
     return a.x_planes != nullptr && a.w_planes != nullptr && aligned && a.Cin % 8 == 0 && a.x_bytes > 0 && a.x_bytes < (1ll << 31) &&
            a.w_plane_stride * 4 < (1ll << 31);
 }

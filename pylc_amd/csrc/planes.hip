@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
             psplit(hi[e], s, b0, b1);
             h0[e] = a0; h1[e] = a1; h0[4 + e] = b0; h1[4 + e] = b1;
         }
-        *reinterpret_cast<f16x8*>(planes + r * p_pitch + c) = h0;
-        if constexpr (NPL == 2) *reinterpret_cast<f16x8*>(planes + plane_stride + r * p_pitch + c) = h1;
+        const long long e = planes_phys(r * p_pitch + c, NPL == 2 && planes_il(plane_stride));      // (8 channels stay inside a 32-channel chunk)
+        *reinterpret_cast<f16x8*>(planes + e) = h0;
+        if constexpr (NPL == 2) *reinterpret_cast<f16x8*>(planes + plane_stride + e) = h1;
     }
 }
 
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const f16* __restrict_
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long r = i / C8;
         const int c = (int)(i - r * C8) * 8;
-        const f16x8 h0 = *reinterpret_cast<const f16x8*>(planes + r * p_pitch + c);
+        const long long e = planes_phys(r * p_pitch + c, NPL == 2 && planes_il(plane_stride));
+        const f16x8 h0 = *reinterpret_cast<const f16x8*>(planes + e);
         f16x8 h1 = {};
-        if constexpr (NPL == 2) h1 = *reinterpret_cast<const f16x8*>(planes + plane_stride + r * p_pitch + c);
+        if constexpr (NPL == 2) h1 = *reinterpret_cast<const f16x8*>(planes + plane_stride + e);
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void upcat_planes_kernel(const float* __restri
         psplit(hi[e], s, b0, b1);
         q0[e] = a0; q1[e] = a1; q0[4 + e] = b0; q1[4 + e] = b1;
     }
-    f16* dst = planes + ((size_t)(b * OH + oh) * OW + ow) * (C1 + C2) + c;
+    f16* dst = planes + planes_phys((long long)((size_t)(b * OH + oh) * OW + ow) * (C1 + C2) + c, NPL == 2 && planes_il(plane_stride));
     *reinterpret_cast<f16x8*>(dst) = q0;
     if constexpr (NPL == 2) *reinterpret_cast<f16x8*>(dst + plane_stride) = q1;
 }
@@ -143,9 +145,10 @@ __global__ __launch_bounds__(256) void planes_colsum_kernel(const f16* __restric
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (active) {
             for (long long r = r_begin + ty; r < r_end; r += RL) {
-                const f16x8 h0 = *reinterpret_cast<const f16x8*>(planes + r * p_pitch + 8 * c8);
+                const long long e = planes_phys(r * p_pitch + 8 * c8, NPL == 2 && planes_il(plane_stride));
+                const f16x8 h0 = *reinterpret_cast<const f16x8*>(planes + e);
                 f16x8 h1 = {};
-                if constexpr (NPL == 2) h1 = *reinterpret_cast<const f16x8*>(planes + plane_stride + r * p_pitch + 8 * c8);
+                if constexpr (NPL == 2) h1 = *reinterpret_cast<const f16x8*>(planes + plane_stride + e);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += ((float)h0[e] + (float)h1[e] * (1.f / 2048.f)) * inv;
             }
@@ -169,7 +172,10 @@ static int check_planes(const void* planes, int p_pitch, long long plane_stride,
     PYLC_REQUIRE(planes && M > 0 && C > 0 && C % 8 == 0, "%s: need M > 0 and C %% 8 == 0 (M=%lld C=%d)", what, M, C);
     PYLC_REQUIRE(p_pitch >= C && p_pitch % 8 == 0, "%s: plane pitch %d invalid for C=%d (multiple of 8)", what, p_pitch, C);
     PYLC_REQUIRE(nplanes == 1 || nplanes == 2, "%s: nplanes must be 1 or 2", what);
-    PYLC_REQUIRE(nplanes == 1 || (plane_stride >= M * p_pitch - (p_pitch - C) && plane_stride % 8 == 0), "%s: bad plane stride", what);
+    // two planes: separate arrays `plane_stride` halves apart, or chunk-interleaved (plane_stride == 32: dense rows of a multiple of 32 channels)
+    PYLC_REQUIRE(nplanes == 1 || (plane_stride >= M * p_pitch - (p_pitch - C) && plane_stride % 8 == 0) ||
+                     (planes_il(plane_stride) && p_pitch == C && C % 32 == 0),
+                 "%s: bad plane stride (32 = chunk-interleaved needs a dense pitch and C %% 32 == 0)", what);
     PYLC_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "%s: planes must be 16-byte aligned", what);
     return PYLC_OK;
 }
@@ -177,6 +183,10 @@ static int check_planes(const void* planes, int p_pitch, long long plane_stride,
 }  // namespace pylc
 
 using namespace pylc;
+
+int pylc::g_planes_interleave = 1;
+extern "C" int pylc_set_planes_interleave(int on) { pylc::g_planes_interleave = on ? 1 : 0; return PYLC_OK; }
+extern "C" long long pylc_planes_stride(long long M, int C, int nplanes) { return pylc::planes_stride_rule(M, C, C, nplanes); }
 
 extern "C" int pylc_to_planes(const float* x, int x_pitch, void* planes, int p_pitch, long long plane_stride, long long M, int C,
                               const unsigned int* amax, int nplanes, void* stream) {

@@ -63,11 +63,12 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
             const float sc = pool_pow2_scale(*pp.bound);
             const f32x4 xs = best * sc;
             const f16x4_ h0 = {(_Float16)xs.x, (_Float16)xs.y, (_Float16)xs.z, (_Float16)xs.w};
-            *reinterpret_cast<uint2*>(pp.planes + 4 * i) = __builtin_bit_cast(uint2, h0);
+            const long long pe = planes_phys(4 * i, pp.nplanes == 2 && planes_il(pp.plane_stride));      // (chunk-interleaved: common.h)
+            *reinterpret_cast<uint2*>(pp.planes + pe) = __builtin_bit_cast(uint2, h0);
             if (pp.nplanes == 2) {
                 const f32x4 r = {(xs.x - (float)h0.x) * 2048.f, (xs.y - (float)h0.y) * 2048.f, (xs.z - (float)h0.z) * 2048.f, (xs.w - (float)h0.w) * 2048.f};
                 const f16x4_ h1 = {(_Float16)r.x, (_Float16)r.y, (_Float16)r.z, (_Float16)r.w};
-                *reinterpret_cast<uint2*>(pp.planes + pp.plane_stride + 4 * i) = __builtin_bit_cast(uint2, h1);
+                *reinterpret_cast<uint2*>(pp.planes + pp.plane_stride + pe) = __builtin_bit_cast(uint2, h1);
             }
         } else {
             st4(y + 4 * i, best);
@@ -336,15 +337,16 @@ __global__ __launch_bounds__(256) void gap_fwd_planes_kernel(const _Float16* __r
     const float inv = 1.f / __uint_as_float((unsigned)se << 23);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (cv < CV) {
-        const _Float16* base = planes + (size_t)b * HW * C + 4 * cv;
+        const bool il = NPL == 2 && planes_il(plane_stride);      // chunk-interleaved (common.h): C % 32 == 0, a row starts a chunk
+        const long long e0 = (long long)b * HW * C + 4 * cv;
         for (int r = ty; r < HW; r += 16 * 8) {
             f16x4p h0[8], h1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int rr = r + 16 * u;
-                const size_t off = (size_t)(rr < HW ? rr : r) * C;
-                h0[u] = *reinterpret_cast<const f16x4p*>(base + off);
-                if constexpr (NPL == 2) h1[u] = *reinterpret_cast<const f16x4p*>(base + plane_stride + off);
+                const long long off = planes_phys(e0 + (long long)(rr < HW ? rr : r) * C, il);
+                h0[u] = *reinterpret_cast<const f16x4p*>(planes + off);
+                if constexpr (NPL == 2) h1[u] = *reinterpret_cast<const f16x4p*>(planes + plane_stride + off);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -552,7 +554,7 @@ extern "C" int pylc_gap_fwd(const float* x, float* y, int B, int HW, int C, void
 extern "C" int pylc_gap_fwd_planes(const void* planes, long long plane_stride, int nplanes, const unsigned int* amax, float* y, int B, int HW, int C,
                                    void* stream) {
     PYLC_REQUIRE(planes && amax && y && B > 0 && HW > 0 && C > 0 && C % 8 == 0 && (nplanes == 1 || nplanes == 2) &&
-                 (nplanes == 1 || plane_stride >= (long long)B * HW * C), "gap_fwd_planes: bad arguments");
+                 (nplanes == 1 || plane_stride >= (long long)B * HW * C || (planes_il(plane_stride) && C % 32 == 0)), "gap_fwd_planes: bad arguments");
     const _Float16* p = static_cast<const _Float16*>(planes);
     if (nplanes == 2)
         hipLaunchKernelGGL(gap_fwd_planes_kernel<2>, dim3(cdiv(C / 4, 16), B), dim3(256), 0, as_stream(stream), p, plane_stride, amax, y, HW, C);

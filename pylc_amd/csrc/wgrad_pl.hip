@@ -102,12 +102,17 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const float scale_a = pow2_scale_for(*a.amax_dy), scale_b = pow2_scale_for(*a.amax_x);
 
     constexpr unsigned OOB = 0xFFFFFFF0u;                 // >= num_records: the load returns zeros
-    const __amdgpu_buffer_rsrc_t rdy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy_planes), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
+    // chunk-interleaved operands (plane_stride == 32, common.h): pixel offsets double, a column c sits at halves (c >> 5) * 64 + (c & 31) of its
+    // row, plane 1 is 64 bytes behind plane 0 and one descriptor spans both planes
+    const bool il_dy = NPL == 2 && planes_il(a.dy_plane_stride), il_x = NPL == 2 && planes_il(a.x_plane_stride);
+    const unsigned mdy = (unsigned)__builtin_amdgcn_readfirstlane(il_dy ? 2 : 1), mx = (unsigned)__builtin_amdgcn_readfirstlane(il_x ? 2 : 1);
+    auto colh = [](unsigned c, bool il) { return il ? ((c >> 5) << 6) + (c & 31u) : c; };      // column -> halves within the (doubled) row
+    const __amdgpu_buffer_rsrc_t rdy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy_planes), 0, (int)((unsigned)a.dy_bytes * mdy), 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.dy_planes) + a.dy_plane_stride * 2), 0, (int)(unsigned)a.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(unsigned)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.dy_planes) + a.dy_plane_stride * 2), 0, (int)((unsigned)a.dy_bytes * mdy - (il_dy ? 64u : 0u)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)((unsigned)a.x_bytes * mx), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(unsigned)a.x_bytes, 0x00020000);
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)((unsigned)a.x_bytes * mx - (il_x ? 64u : 0u)), 0x00020000);
 
     // Operand staging registers, TWO sets (round 5): the loads of tile s + 2 are in flight while tile s is computed.  With one set the loads
     // of tile s + 1 had one K-step (~3 k cycles with the CU's other block) to come back from L2 / HBM and the step waited for them: PMC
@@ -134,10 +139,10 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         f_p = t % a.P;
         f_b = t / a.P;
 #pragma unroll
-        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch + n0 + 8 * va) * 2u : OOB;
+        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch * mdy + colh((unsigned)(n0 + 8 * va), il_dy)) * 2u : OOB;
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch + c0 + 8 * vb) * 2u;
+            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch * mx + colh((unsigned)(c0 + 8 * vb), il_x)) * 2u;
             f_wc[i] = (prb + RB * i) * a.in_sw + dw;
         }
     }
@@ -147,14 +152,14 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     };
     auto load_tile = [&](auto setc) {
         constexpr int set = decltype(setc)::value;
-        const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 2u;
+        const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 2u * mdy;
         if constexpr (FAST == 2) {
-            const unsigned colb = (unsigned)(c0 + 8 * vb);
+            const unsigned colb = colh((unsigned)(c0 + 8 * vb), il_x);
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const int hi = g_p[i] * a.in_sh + dh, wi = g_q[i] * a.in_sw + dw;
                 const bool ok = b_col_ok & (f_mb + prb + RB * i < m_end) & ((unsigned)hi < (unsigned)a.IH) & ((unsigned)wi < (unsigned)a.IW);
-                const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch + colb) * 2u;
+                const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch * mx + colb) * 2u;
                 ldp(rx0, rx1, ok ? off : OOB, 0u, rb[set][i]);
                 g_q[i] += 32;
                 while (g_q[i] >= a.Q) { g_q[i] -= a.Q; ++g_p[i]; }
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         // FAST 1: tile = 32 consecutive output pixels of row (f_b, f_p) starting at column f_q0
         const int hi = f_p * a.in_sh + dh;
         const bool row_ok = b_col_ok && (unsigned)hi < (unsigned)a.IH;
-        const unsigned delta = (unsigned)((((f_b * a.IH + hi) * a.IW + f_q0 * a.in_sw + dw) * a.x_pitch) * 2);
+        const unsigned delta = (unsigned)((((f_b * a.IH + hi) * a.IW + f_q0 * a.in_sw + dw) * a.x_pitch) * 2) * mx;
         const int wq = f_q0 * a.in_sw;
 #pragma unroll
         for (int i = 0; i < IB; ++i) {

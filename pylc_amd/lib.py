@@ -69,6 +69,8 @@ _SZ = C.c_size_t
 SIGNATURES = {
     'pylc_last_error': (C.c_char_p, []),
     'pylc_abi_version': (_I, []),
+    'pylc_planes_stride': (_LL, [_LL, _I, _I]),
+    'pylc_set_planes_interleave': (_I, [_I]),
     'pylc_experimental_build': (_I, []),
     'pylc_init': (_I, []),
     'pylc_set_conv_precision': (_I, [_I]),
@@ -250,6 +252,8 @@ def init():
         if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
             _need_experimental('PYLC_P1')
             lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
+        if os.environ.get('PYLC_NO_PLANE_INTERLEAVE'):           # two-plane activations as separate plane arrays (A/B; the round-4 format)
+            lib.pylc_set_planes_interleave(0)
         if os.environ.get('PYLC_WG_SETS') is not None:            # wgrad operand staging sets: 0 one, 1 two for multi-tap filters, 2 two always (A/B)
             lib.pylc_debug_wgrad_sets(int(os.environ['PYLC_WG_SETS']))
         if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)

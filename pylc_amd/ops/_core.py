@@ -94,6 +94,12 @@ def filter_planes_fmt(planes):
     return planes[2] if (len(planes) > 3 and planes[3][0]) else 0
 
 
+def pstride(m, c):
+    """Plane stride (halves) of a planes tensor of m pixels x c channels in the current arithmetic -- the C ABI's one rule
+    (pylc_planes_stride, include/pylc_hip.h): 32 = chunk-interleaved (two planes, c % 32 == 0), else m * c (separate plane arrays)."""
+    return lib.pylc_planes_stride(m, c, nplanes())
+
+
 def planes_ok(c, pixels):
     """Can an activation of `c` channels x `pixels` pixels be kept as fp16 planes (16-byte rows per 8 channels, one plane below 2 GiB)?"""
     return lib.pylc_get_conv_precision() >= 2 and c % 8 == 0 and pixels * c * 2 < (1 << 31)
@@ -145,7 +151,7 @@ def to_planes(x, amax=None):
         amax = amax_of(x)
     out = empty_nhwc(b, c, h, w, x.device)
     m = b * h * w
-    check(lib.pylc_to_planes(ptr(x), pitch_of(x), ptr(out), c, m * c, m, c, ptr(amax), nplanes(), stream()))
+    check(lib.pylc_to_planes(ptr(x), pitch_of(x), ptr(out), c, pstride(m, c), m, c, ptr(amax), nplanes(), stream()))
     return mark_planes(out, amax)
 
 
@@ -155,7 +161,7 @@ def from_planes(t):
     b, c, h, w = t.shape
     m = b * h * w
     out = empty_nhwc(b, c, h, w, t.device)
-    check(lib.pylc_from_planes(ptr(t), c, m * c, ptr(out), c, m, c, ptr(planes_amax(t)), nplanes(), stream()))
+    check(lib.pylc_from_planes(ptr(t), c, pstride(m, c), ptr(out), c, m, c, ptr(planes_amax(t)), nplanes(), stream()))
     plane_conversions[0] += 1
     plane_conversions[1] += t.numel()
     tag_amax(out, planes_amax(t))

@@ -144,9 +144,9 @@ class BnActFn(torch.autograd.Function):
             if y_bound is not None:
                 ex.y_half_bound = ptr(y_bound)
             if out_planes:
-                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(bound)
+                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), pstride(m, c), ptr(bound)
             if res_pl is not None:
-                ex.res_planes, ex.res_plane_stride, ex.res_amax = ptr(res_pl), m * c, ptr(res_amax)
+                ex.res_planes, ex.res_plane_stride, ex.res_amax = ptr(res_pl), pstride(m, c), ptr(res_amax)
             check(lib.pylc_bn_apply_ex(ptr(y), yp, ptr(scale), ptr(shift), ptr(res), pitch_of(res) if res is not None else (c if res_pl is not None else 0),
                                        None if out_planes else ptr(out), op_, m, c, int(relu), ptr(amax), C.byref(ex), st))
         else:
@@ -232,7 +232,7 @@ class BnActFn(torch.autograd.Function):
                     ex.relu_mask = ptr(mask)
                 ex.y_half_bound, ex.dout_half_bound = ptr(y_bound), ptr(a_bound)
                 if out_pl:
-                    ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(out_bound)
+                    ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), pstride(m, c), ptr(out_bound)
                 if dy_pl:
                     dy_bound = amax_slot(dev)
                     ex.g_amax = ptr(g_amax)
@@ -245,7 +245,7 @@ class BnActFn(torch.autograd.Function):
                 ex.relu_mask = ptr(mask)
             ex.y_half_bound, ex.dout_half_bound = ptr(y_bound), ptr(a_bound)
             if out_pl:
-                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(out_bound)
+                ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), pstride(m, c), ptr(out_bound)
             if dy_pl:
                 g_amax, dy_bound = amax_slot(dev), amax_slot(dev)
                 ex.g_amax = ptr(g_amax)
@@ -293,7 +293,7 @@ class BnActFn(torch.autograd.Function):
         tm.__enter__()
         if use_ex:
             if dy_pl:
-                ex.dy_planes, ex.dy_plane_stride, ex.dy_bound = ptr(dy), m * c, ptr(dy_bound)
+                ex.dy_planes, ex.dy_plane_stride, ex.dy_bound = ptr(dy), pstride(m, c), ptr(dy_bound)
             check(lib.pylc_bn_bwd_apply_ex(ptr(dout), dout_pitch, None if out_pl else ptr(out), op, ptr(y), y_pitch, ptr(mean), ptr(invstd),
                                            ptr(gamma), ptr(sums_apply), n_global, m, c, int(relu), None if dy_pl else ptr(dy), c,
                                            ptr(g_out), c if g_out is not None else 0, ptr(amax_dy), ptr(scale), ptr(shift), C.byref(ex), st))
@@ -487,7 +487,7 @@ def materialize_deferred(x):
     out = empty_nhwc(b, c, h, w, x.device)
     ex = _bn_extra()
     ex.y_half_bound = ptr(y_bound)
-    ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), m * c, ptr(bound)
+    ex.out_planes, ex.out_plane_stride, ex.out_bound = ptr(out), pstride(m, c), ptr(bound)
     check(lib.pylc_bn_apply_ex(ptr(x), c, ptr(coef[2 * c:3 * c]), ptr(coef[3 * c:]), None, 0, None, c, m, c, int(relu), None, C.byref(ex), stream()))
     return mark_planes(out, bound)
 

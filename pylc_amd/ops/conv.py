@@ -311,7 +311,7 @@ class Conv2dFn(torch.autograd.Function):
             sums = torch.empty(2 * cp, device=x.device)
             if dy_pl:       # per-channel sums straight from the planes (one read pass, as the fp32 form)
                 ws = torch.empty(lib.pylc_planes_colsum_workspace_floats(cout), device=x.device)
-                check(lib.pylc_planes_colsum(ptr(dy), cout, m * cout, nplanes(), ptr(planes_amax(dy)), m, cout, ptr(sums), ptr(ws), st))
+                check(lib.pylc_planes_colsum(ptr(dy), cout, pstride(m, cout), nplanes(), ptr(planes_amax(dy)), m, cout, ptr(sums), ptr(ws), st))
             else:
                 ws = torch.empty(lib.pylc_bn_workspace_floats(m, cp), device=x.device)
                 check(lib.pylc_bn_stats(ptr(dy), m, cp, yp, ptr(sums), ptr(ws), st))

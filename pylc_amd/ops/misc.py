@@ -75,7 +75,7 @@ class MaxPoolFn(torch.autograd.Function):
         need_idx = ctx.needs_input_grad[0]
         idx = torch.empty((b, oh, ow, c), device=x.device, dtype=torch.uint8) if need_idx else None
         if planes_bound is not None:       # the pooled tensor as fp16 planes (its only reader is a conv that takes them)
-            check(lib.pylc_maxpool_fwd_planes(ptr(x), ptr(y), b * oh * ow * c, nplanes(), ptr(planes_bound), ptr(idx), b, h, w, c, k, stride, pad,
+            check(lib.pylc_maxpool_fwd_planes(ptr(x), ptr(y), pstride(b * oh * ow, c), nplanes(), ptr(planes_bound), ptr(idx), b, h, w, c, k, stride, pad,
                                               oh, ow, stream()))
         else:
             check(lib.pylc_maxpool_fwd(ptr(x), ptr(y), ptr(idx), b, h, w, c, k, stride, pad, oh, ow, stream()))
@@ -178,7 +178,7 @@ class UpCatPlanesFn(torch.autograd.Function):
         oh, ow = 2 * h, 2 * w
         out = empty_nhwc(b, c1 + c2, oh, ow, z.device)
         check(lib.pylc_upsample2_crop_concat_planes(ptr(z), pitch_of(z), b, h, w, c1, ptr(bridge), pitch_of(bridge), hh, ww, c2, ptr(out),
-                                                    b * oh * ow * (c1 + c2), nplanes(), ptr(bound), stream()))
+                                                    pstride(b * oh * ow, c1 + c2), nplanes(), ptr(bound), stream()))
         ctx.geom = (b, c1, h, w, c2, hh, ww, (hh - oh) // 2, (ww - ow) // 2)
         ctx.link = link if ctx.needs_input_grad[1] else None
         return out
@@ -314,7 +314,7 @@ class GapFn(torch.autograd.Function):
         y = empty_nhwc(b, c, 1, 1, x.device)
         if is_planes(x) and c % 8 == 0 and _runtime.gap_planes:
             # the backbone's last BatchNorm left fp16 planes for the atrous convs: pool them as they are (same bits as converting first)
-            check(lib.pylc_gap_fwd_planes(ptr(x), b * h * w * c, nplanes(), ptr(planes_amax(x)), ptr(y), b, h * w, c, stream()))
+            check(lib.pylc_gap_fwd_planes(ptr(x), pstride(b * h * w, c), nplanes(), ptr(planes_amax(x)), ptr(y), b, h * w, c, stream()))
         else:
             x = as_nhwc(x)
             if pitch_of(x) != x.shape[1]:
