@@ -71,6 +71,9 @@ constexpr int pl_lds_bytes() { return pl_stages<BM>() * pl_stage_bytes<NTERMS, B
 // needs -- those of the ROUNDED tensor -- are taken from h by mixed-precision fmas (h h is exact in fp32), scaled by 1 / s_y at the end.
 // Everything else (ragged tiles, accumulate + statistics, the BatchNorm-backward and inference epilogues) takes the general path
 // below, unchanged.  Results are bit-identical to it (tests/test_planes_gpu.py pins both against the fp32-operand kernels).
+#ifndef PYLC_EPI_FULL_LINES
+#define PYLC_EPI_FULL_LINES 1      // 0: each lane stores its own quads (16 rows x 64 B per instruction; A/B build)
+#endif
 #ifndef PYLC_EPI_PK
 #define PYLC_EPI_PK 0      // 1: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 forms (A/B: tools/epi_ab.sh)
 #endif
@@ -118,6 +121,19 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
     unsigned offs[AM];                                      // element offsets of this lane's channel quad in its AM rows (all valid here)
 #pragma unroll
     for (int i = 0; i < AM; ++i) offs[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nb);
+    // FULL-LINE STORES (fp32 output).  The accumulator layout gives a store instruction 16 rows x 64 B -- half of each 128-byte line, the other
+    // half following four instructions later.  Lanes l and l ^ 8 (rows r and r + 8 of a fragment, same channel quad) swap one value each per
+    // pair of column groups -- the lower lane's odd group against the upper lane's even group -- so that an instruction writes 8 rows x 128 B:
+    // rows 0-7 first (lower lanes their own even group, upper lanes the odd group they received), then rows 8-15.
+    // tools/micro/store_patterns.hip: whole-line patterns are 8-12 % ahead on pure stores, and a short-K tile's time is its stores (DESIGN 5.2 a).
+    constexpr bool FULL = !HALF && PYLC_EPI_FULL_LINES != 0;
+    unsigned offsP[FULL ? AM : 1];                          // ... of the partner row (r ^ 8)
+    if constexpr (FULL) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i) offsP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nb);
+    }
+    const bool upper = (lane & 8) != 0;
+    f32x4v hold[FULL ? AM : 1];                             // the even column group's values, waiting for their odd neighbour
     const float k = HALF ? c * hscale : c;                  // powers of two: exact
     const float post = HALF ? pow2_inv(hscale) : c;         // what the column sums are multiplied with (sums of squares: twice)
     const bool odd_row = (lane >> 4) & 1;
@@ -172,7 +188,24 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
                 }
                 f32x4v v = epi_fma(t, k, bv);
                 if constexpr (PREV != 0) v = epi_add(v, prev[i]);
-                *reinterpret_cast<f32x4v*>(a.y + (offs[i] + j * 16)) = v;
+                if constexpr (!FULL) {
+                    *reinterpret_cast<f32x4v*>(a.y + (offs[i] + j * 16)) = v;
+                } else if ((j & 1) == 0) {
+                    hold[i] = v;
+                } else {
+                    f32x4v recv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float send = upper ? hold[i][r] : v[r];          // upper lanes give their even group, lower lanes their odd group
+                        recv[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));      // row_ror:8 = lane ^ 8
+                    }
+                    const unsigned col = (upper ? j : j - 1) * 16;
+                    f32x4v da, db;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { da[r] = upper ? recv[r] : hold[i][r]; db[r] = upper ? v[r] : recv[r]; }
+                    *reinterpret_cast<f32x4v*>(a.y + ((upper ? offsP[i] : offs[i]) + col)) = da;      // rows 0-7 of the fragment, 128 B each
+                    *reinterpret_cast<f32x4v*>(a.y + ((upper ? offs[i] : offsP[i]) + col)) = db;      // rows 8-15
+                }
             }
         }
         if constexpr (STATS != 0) {
