@@ -133,7 +133,9 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
         for (int i = 0; i < AM; ++i) offsP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nb);
     }
     const bool upper = (lane & 8) != 0;
+    uint2 hq[(HALF && PYLC_EPI_FULL_LINES != 0) ? AM : 1][4];      // one-plane output: this lane's halves of all four column groups of a row fragment
     f32x4v hold[FULL ? AM : 1];                             // the even column group's values, waiting for their odd neighbour
+    f32x4v prevn[(FULL && PREV != 0) ? AM : 1];             // the odd column group's residual-gradient values, fetched with the even group's
     const float k = HALF ? c * hscale : c;                  // powers of two: exact
     const float post = HALF ? pow2_inv(hscale) : c;         // what the column sums are multiplied with (sums of squares: twice)
     const bool odd_row = (lane >> 4) & 1;
@@ -144,8 +146,34 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
             unsigned mb[AM];
 #pragma unroll
             for (int i = 0; i < AM; ++i) {
-                prev[i] = *reinterpret_cast<const f32x4v*>(extra + (offs[i] + j * 16));
+                if constexpr (!FULL) prev[i] = *reinterpret_cast<const f32x4v*>(extra + (offs[i] + j * 16));
                 if constexpr (PREV == 2) mb[i] = amask[(offs[i] + j * 16) >> 3];
+            }
+            if constexpr (FULL) {
+                // full-line LOADS of the residual-gradient source, the stores' swap in reverse: at an even column group both groups of the pair
+                // are fetched as 8 rows x 128 B per instruction (lower lanes their even group, upper lanes the lower rows' odd group; then rows
+                // 8-15), and lanes l / l ^ 8 hand each other what belongs to the other
+                if ((j & 1) == 0) {
+                    const unsigned col = (upper ? j + 1 : j) * 16;
+                    f32x4v la[AM], lb[AM];
+#pragma unroll
+                    for (int i = 0; i < AM; ++i) {
+                        la[i] = *reinterpret_cast<const f32x4v*>(extra + ((upper ? offsP[i] : offs[i]) + col));      // rows 0-7 of the fragment
+                        lb[i] = *reinterpret_cast<const f32x4v*>(extra + ((upper ? offs[i] : offsP[i]) + col));      // rows 8-15
+                    }
+#pragma unroll
+                    for (int i = 0; i < AM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float send = upper ? la[i][r] : lb[i][r];
+                            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));
+                            prev[i][r] = upper ? recv : la[i][r];          // this lane's even group
+                            prevn[i][r] = upper ? lb[i][r] : recv;         // ... and its odd group, for the next iteration
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < AM; ++i) prev[i] = prevn[i];
+                }
             }
             if constexpr (PREV == 2) {
 #pragma unroll
@@ -176,11 +204,15 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
                         css[r] = i == 0 ? (float)h[r] * (float)h[r] : __builtin_fmaf((float)h[r], (float)h[r], css[r]);
                     }
                 }
-                // lanes l and l + 16 (same pixel, the next channel quad) swap halves: even DPP rows store 8 channels = 16 bytes
-                const uint2 hu = __builtin_bit_cast(uint2, h);
-                const u32x2_ sx = __builtin_amdgcn_permlane16_swap(hu.x, hu.x, false, false);
-                const u32x2_ sy = __builtin_amdgcn_permlane16_swap(hu.y, hu.y, false, false);
-                if (!odd_row) *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(a.y) + (offs[i] + j * 16)) = uint4{hu.x, hu.y, sx.y, sy.y};
+                if constexpr (PYLC_EPI_FULL_LINES != 0) {
+                    hq[i][j] = __builtin_bit_cast(uint2, h);        // stored after the last column group, whole lines at a time (below)
+                } else {
+                    // lanes l and l + 16 (same pixel, the next channel quad) swap halves: even DPP rows store 8 channels = 16 bytes
+                    const uint2 hu = __builtin_bit_cast(uint2, h);
+                    const u32x2_ sx = __builtin_amdgcn_permlane16_swap(hu.x, hu.x, false, false);
+                    const u32x2_ sy = __builtin_amdgcn_permlane16_swap(hu.y, hu.y, false, false);
+                    if (!odd_row) *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(a.y) + (offs[i] + j * 16)) = uint4{hu.x, hu.y, sx.y, sy.y};
+                }
             } else {
                 if constexpr (STATS != 0) {
                     cs = i == 0 ? t : epi_add(cs, t);        // (0 + t == t: the general path's order of additions)
@@ -215,6 +247,41 @@ __device__ __forceinline__ void pl_epilogue_lean(const GatherGemmArgs& a, f32x4v
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r] * post; sdst[(j * 16 + r) * 2 + 1] = css[r] * post * post; }
             }
+        }
+    }
+    if constexpr (HALF && PYLC_EPI_FULL_LINES != 0) {
+        // One-plane output, whole lines: a lane holds 4 channels = 8 bytes per column group, a fragment row 64 channels = ONE 128-byte line.
+        //  (1) per pair of column groups, v_permlane16_swap between lanes l and l + 16 (adjacent channel quads): lanes of even DPP rows end up
+        //      with 8 channels of the even group, lanes of odd rows with 8 channels of the odd group -- 16 bytes in EVERY lane, and the pair's 32
+        //      channels = 64 contiguous bytes per pixel row;
+        //  (2) lanes l / l ^ 8 (rows r and r + 8) swap the second pair of the lower rows against the first pair of the upper rows, as the fp32
+        //      stores do, so that an instruction writes rows 0-7 (then 8-15) of the fragment in full: 8 rows x 128 B.
+        // Two stores per row fragment instead of four 16-rows-x-32-byte ones issued by half the lanes.
+        unsigned offsP[AM];
+#pragma unroll
+        for (int i = 0; i < AM; ++i) offsP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nb - 4 * (lane >> 4));
+        const unsigned q4 = (unsigned)(lane >> 4);                 // this lane's channel quad
+        // after (1): even rows hold the even group's channels 16 jp*2 + 4 q .. + 7, odd rows the odd group's 16 (2 jp + 1) + 4 (q - 1) .. + 7
+        const unsigned colq = odd_row ? 16u + 4u * (q4 - 1u) : 4u * q4;      // channel offset inside the pair's 32 channels
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            // (scalars, not a two-element array: `upper ? pr[0] : pr[1]` on an array makes hipcc index it in scratch memory)
+            const u32x2_ ax = __builtin_amdgcn_permlane16_swap(hq[i][0].x, hq[i][1].x, false, false);
+            const u32x2_ ay = __builtin_amdgcn_permlane16_swap(hq[i][0].y, hq[i][1].y, false, false);
+            const u32x2_ bx = __builtin_amdgcn_permlane16_swap(hq[i][2].x, hq[i][3].x, false, false);
+            const u32x2_ by = __builtin_amdgcn_permlane16_swap(hq[i][2].y, hq[i][3].y, false, false);
+            // pair 0 = (ax.x, ay.x, ax.y, ay.y), pair 1 = (bx.x, by.x, bx.y, by.y): 8 consecutive channels each
+            const unsigned s0 = upper ? ax.x : bx.x, s1 = upper ? ay.x : by.x, s2 = upper ? ax.y : bx.y, s3 = upper ? ay.y : by.y;      // upper sends pair 0, lower pair 1
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xF, 0xF, true);
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xF, 0xF, true);
+            const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s2, 0x128, 0xF, 0xF, true);
+            const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s3, 0x128, 0xF, 0xF, true);
+            const unsigned base_own = offs[i] - 4u * q4, base_par = offsP[i];      // element offset of the fragment row's first channel (own / partner row)
+            const unsigned col = (upper ? 32u : 0u) + colq;
+            const uint4 da = {upper ? r0 : ax.x, upper ? r1 : ay.x, upper ? r2 : ax.y, upper ? r3 : ay.y};      // lower: own pair 0; upper: the lower row's pair 1
+            const uint4 db = {upper ? bx.x : r0, upper ? by.x : r1, upper ? bx.y : r2, upper ? by.y : r3};      // lower: the upper row's pair 0; upper: own pair 1
+            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(a.y) + ((upper ? base_par : base_own) + col)) = da;      // rows 0-7
+            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(a.y) + ((upper ? base_own : base_par) + col)) = db;      // rows 8-15
         }
     }
 }
