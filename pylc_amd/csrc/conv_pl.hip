@@ -367,12 +367,122 @@ __device__ __forceinline__ float pl_epilogue_bn(const GatherGemmArgs& a, f32x4v 
     return gmax;
 }
 
+// The LEAN form of the fused INFERENCE epilogue (EP kernels, pylc_conv2d_fwd_bnact_ex): an edge-free tile whose result -- act(conv * scale +
+// shift (+ residual)) -- leaves as a chunk-interleaved two-plane tensor (plane_stride == 32: a pixel's 32 channels = 64 B of plane 0 + 64 B of
+// plane 1 = one 128-byte line), with the residual, if any, in the same format.  Same expressions and order per element as the general path
+// (bit-identical; tests/test_planes_gpu.py compares the two), but
+//   * no per-element edge selects, no bias,
+//   * WHOLE-LINE stores: per pair of column groups (one 32-channel chunk) v_permlane16_swap between lanes l / l + 16 gives every lane 16 B of
+//     one plane (8 channels), then lanes l / l ^ 8 (rows r / r + 8) swap the lower row's second group against the upper row's first, as the
+//     training epilogue does: a store instruction writes 8 rows x 128 B instead of 16 rows x 2 x 32 B;
+//   * the residual planes are FETCHED as whole lines by the same exchange in reverse.
+// 16-byte piece p (0..7) of a chunk's line: pieces 0-3 = plane 0 channels 8 p .., pieces 4-7 = plane 1; lane quad q = lane >> 4 after the
+// permlane16 exchange holds, for column group j' of the pair, piece (q & 1) * 4 + (q >> 1) + 2 j'.
+// RES: 0 none, 2 two-plane interleaved residual.  Returns max |result| of this lane.
+template <int AM, int RES>
+__device__ __forceinline__ float pl_epilogue_lean_ep(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], const int* rowoff, int nchunk, int wave_m, int lane,
+                                                     float c, float hscale, float res_unscale) {
+    constexpr int WM = 16 * AM;
+    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const unsigned q4 = (unsigned)(lane >> 4);
+    const bool upper = (lane & 8) != 0;
+    // physical half offset of a row's first line of this wave's columns: element offset (a multiple of 32) x 2
+    unsigned base[AM], baseP[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i) {
+        base[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nchunk) * 2u;
+        baseP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nchunk) * 2u;
+    }
+    // this lane's piece in the two store / load instructions of a (row fragment, chunk): lower lanes handle column group 0 of the pair, upper lanes group 1
+    const unsigned piece = ((q4 & 1u) * 4u + (q4 >> 1) + (upper ? 2u : 0u)) * 8u;      // in halves
+    const int nb = nchunk + 4 * (int)q4;
+    _Float16* const yp = reinterpret_cast<_Float16*>(a.y);
+    const _Float16* const rp = reinterpret_cast<const _Float16*>(a.ep_res);
+    const bool relu = a.ep_relu != 0;
+    float ep_max = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        uint4 ra[RES ? AM : 1], rb[RES ? AM : 1];
+        if constexpr (RES != 0) {
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                ra[i] = *reinterpret_cast<const uint4*>(rp + ((upper ? baseP[i] : base[i]) + jp * 64 + piece));      // rows 0-7 of the fragment
+                rb[i] = *reinterpret_cast<const uint4*>(rp + ((upper ? base[i] : baseP[i]) + jp * 64 + piece));      // rows 8-15
+            }
+        }
+        f32x4v esc[2], esh[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            esc[jj] = *reinterpret_cast<const f32x4v*>(a.ep_scale + nb + (2 * jp + jj) * 16);
+            esh[jj] = *reinterpret_cast<const f32x4v*>(a.ep_shift + nb + (2 * jp + jj) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            uint4 qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};      // residual pieces of this lane's own row: column group 0 / 1 of the pair
+            if constexpr (RES != 0) {
+                const unsigned s0 = upper ? ra[i].x : rb[i].x, s1 = upper ? ra[i].y : rb[i].y, s2 = upper ? ra[i].z : rb[i].z, s3 = upper ? ra[i].w : rb[i].w;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xF, 0xF, true);      // row_ror:8 = lane ^ 8
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xF, 0xF, true);
+                const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s2, 0x128, 0xF, 0xF, true);
+                const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s3, 0x128, 0xF, 0xF, true);
+                qa = uint4{upper ? r0 : ra[i].x, upper ? r1 : ra[i].y, upper ? r2 : ra[i].z, upper ? r3 : ra[i].w};
+                qb = uint4{upper ? rb[i].x : r0, upper ? rb[i].y : r1, upper ? rb[i].z : r2, upper ? rb[i].w : r3};
+            }
+            uint4 oa, ob;                                                // output pieces of this lane's own row: column group 0 / 1
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                f32x4v val;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = acc[i][j][r] * c;                    // (the general path's acc * unscale_a * unscale_b: powers of two)
+                    val[r] = t * esc[jj][r] + esh[jj][r];                // BatchNorm-apply's own expression and order
+                }
+                if constexpr (RES != 0) {
+                    const uint4 q = jj == 0 ? qa : qb;
+                    const u32x2_ s0 = __builtin_amdgcn_permlane16_swap(q.x, q.z, false, false);
+                    const u32x2_ s1 = __builtin_amdgcn_permlane16_swap(q.y, q.w, false, false);
+                    const f16x4_ h0 = __builtin_bit_cast(f16x4_, uint2{s0.x, s1.x});
+                    const f16x4_ h1 = __builtin_bit_cast(f16x4_, uint2{s0.y, s1.y});
+                    const f32x4v rv = (__builtin_convertvector(h0, f32x4v) + __builtin_convertvector(h1, f32x4v) * (1.f / 2048.f)) * res_unscale;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (relu) val[r] = fmaxf(val[r], 0.f);
+                    ep_max = fmaxf(ep_max, fabsf(val[r]));
+                }
+                uint2 p0, p1;
+                split2(val, hscale, p0, p1);
+                const u32x2_ sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+                const u32x2_ sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+                // even quads: (own p0, partner's p0) -> 8 channels of plane 0;  odd quads: (partner's p1, own p1) -> plane 1 at the partner's channels
+                if (jj == 0) oa = uint4{sx.x, sy.x, sx.y, sy.y}; else ob = uint4{sx.x, sy.x, sx.y, sy.y};
+            }
+            // lanes l / l ^ 8: the upper row gives its group-0 piece, the lower row its group-1 piece
+            const unsigned s0 = upper ? oa.x : ob.x, s1 = upper ? oa.y : ob.y, s2 = upper ? oa.z : ob.z, s3 = upper ? oa.w : ob.w;
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xF, 0xF, true);
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xF, 0xF, true);
+            const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s2, 0x128, 0xF, 0xF, true);
+            const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s3, 0x128, 0xF, 0xF, true);
+            const uint4 da = {upper ? r0 : oa.x, upper ? r1 : oa.y, upper ? r2 : oa.z, upper ? r3 : oa.w};      // lower: own group 0; upper: the lower row's group 1
+            const uint4 db = {upper ? ob.x : r0, upper ? ob.y : r1, upper ? ob.z : r2, upper ? ob.w : r3};      // lower: the upper row's group 0; upper: own group 1
+            *reinterpret_cast<uint4*>(yp + ((upper ? baseP[i] : base[i]) + jp * 64 + piece)) = da;      // rows 0-7 of the fragment, 128 B each
+            *reinterpret_cast<uint4*>(yp + ((upper ? base[i] : baseP[i]) + jp * 64 + piece)) = db;      // rows 8-15
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one chunk's residual loads at a time
+    }
+    return ep_max;
+}
+
 // Epilogue shared by the planes kernels (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic,
 // then stores): fold the cross-term accumulator, undo the operand scales, bias, optional accumulation into y, BatchNorm statistics
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
 // AM: 16-row fragments per wave along the pixel axis -- 4 (64 x 64 wave tiles, waves 2 wide) or 2 (32 x 64 wave tiles, every wave in the
 // first 64 columns: the NARROW launches for at most 64 output channels)
-template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false>
+template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false, bool LEAN_RES = true>
 __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
                                             const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid, bool rows_full) {
     constexpr int BN = PL_BN, WM = 16 * AM, WN = 64, AT = 4;
@@ -435,6 +545,22 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
                 else PYLC_LEAN(0, 0, false);
             }
 #undef PYLC_LEAN
+        }
+    }
+    if constexpr (EP) {
+        // the lean inference epilogue (pl_epilogue_lean_ep): an edge-free tile, interleaved two-plane result, residual none or in that format
+        const int nchunk = n0 + wave_n * WN;
+        // (LEAN_RES false -- the 3x3 halo kernel, whose convs carry no residual in these networks: the residual form is not compiled in, it would
+        //  cost that kernel 35 spilled registers)
+        const bool res_ok = a.ep_res == nullptr || (LEAN_RES && a.ep_res_fmt == 2 && planes_il(a.ep_res_plane_stride));
+        if (rows_full && nchunk + WN <= a.N && a.out_planes2 && !a.out_half && planes_il(a.out_plane_stride) && a.y_pitch == a.N_store && a.bias == nullptr &&
+            a.ep_scale != nullptr && extra == nullptr && res_ok && !do_stats && !(a.dbg_flags & 8)) {
+            done = true;
+            const float c = unscale_a * unscale_b;
+            float m;
+            if (LEAN_RES && a.ep_res != nullptr) m = pl_epilogue_lean_ep<AM, LEAN_RES ? 2 : 0>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+            else m = pl_epilogue_lean_ep<AM, 0>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+            if (a.ep_amax != nullptr) amax_commit(m, a.ep_amax);
         }
     }
     constexpr bool bn = BNB;                 // (its own instantiations, gg_pl*_kernel<..., BNB = true>: the other launches keep their registers)
@@ -1194,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // LDS is reused for the statistics; orders the row table
-    pl_epilogue<NTERMS, BM, BNB, 4, EP>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q);
+    pl_epilogue<NTERMS, BM, BNB, 4, EP, false>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave_m, wave_n, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q);
 }
 
 template __global__ void gg_plh_kernel<3>(const GatherGemmArgs);

@@ -87,6 +87,63 @@ def test_fused_inference_conv_on_planes(dev, mode, case, out_planes):
     del arena
 
 
+# cin, cout, k, pad, B, H, W, residual as planes, relu
+LEAN_EP_CASES = [
+    (256, 1024, 1, 0, 4, 32, 32, True, True),        # bottleneck conv3 + identity residual: whole-line residual loads and stores
+    (1024, 256, 1, 0, 4, 32, 32, False, True),       # conv1, the 256-row kernel's shapes
+    (256, 256, 3, 1, 4, 32, 32, False, True),        # conv2: the halo kernel
+    (64, 64, 3, 1, 2, 64, 64, False, True),          # layer1 3x3, narrow wave layout
+    (256, 64, 1, 0, 2, 64, 64, False, False),        # narrow 1x1, no ReLU
+    (128, 512, 1, 0, 2, 40, 36, True, False),        # ragged M: the last tile takes the general path, the others the lean one
+    (512, 96, 1, 0, 2, 32, 32, True, True),          # Cout = 96: the second wave column is half outside -> general path beside lean waves
+]
+
+
+@pytest.mark.parametrize('case', LEAN_EP_CASES)
+def test_lean_inference_epilogue_is_bit_identical(dev, case):
+    """pl_epilogue_lean_ep (conv_pl.hip: edge-free tiles of the fused inference conv, whole-line plane stores and residual loads) against
+    the general epilogue of the same kernels (pylc_debug_pp_flags bit 3): the same plane bytes, scale bound and true maximum."""
+    from pylc_amd import ops, layers, optim, runtime
+    from pylc_amd.lib import lib, check
+    cin, cout, k, pad, B, H, W, res_planes, relu = case
+    prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
+    check(lib.pylc_set_conv_precision(2))
+    ops.PLANES_MIN_PIXELS = 0
+    runtime.eval_planes = True
+    try:
+        torch.manual_seed(5)
+        conv = layers.Conv2d(cin, cout, k, 1, pad, 1, bn=True).to(dev)
+        bn = layers.BatchNorm2d(cout).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.3 * rnd(1, cout).to(dev))
+            bn.bias.copy_(0.2 * rnd(2, cout).to(dev))
+            bn.running_mean.copy_(0.1 * rnd(3, cout).to(dev))
+            bn.running_var.copy_(1 + 0.2 * rnd(4, cout).abs().to(dev))
+        arena = optim.FlatArena(torch.nn.ModuleList([conv, bn]))
+        conv.eval(); bn.eval()
+        x = nhwc(rnd(6, B, cin, H, W, scale=1.5), dev)
+        res = nhwc(rnd(7, B, cout, H, W), dev) if res_planes else None
+        out = []
+        with torch.no_grad():
+            xp = ops.to_planes(x)
+            rp = ops.to_planes(res) if res_planes else None
+            for flags in (8, 0):
+                lib.pylc_debug_pp_flags(flags)
+                n0 = ops.eval_plane_convs[0]
+                got = layers.conv_bn(conv, bn, xp, residual=rp, relu=relu, out_planes=True)
+                torch.cuda.synchronize()
+                assert ops.eval_plane_convs[0] == n0 + 1 and ops.is_planes(got)
+                out.append((got.permute(0, 2, 3, 1).reshape(-1).view(torch.int32).clone(), ops.amax_of(got).clone(), ops.planes_amax(got).clone()))
+        assert torch.equal(out[0][0], out[1][0]), 'plane bytes differ: %d words' % (out[0][0] != out[1][0]).sum().item()
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+        del arena
+    finally:
+        lib.pylc_debug_pp_flags(0)
+        ops.PLANES_MIN_PIXELS = prev_min
+        runtime.eval_planes = prev_ep
+        check(lib.pylc_set_conv_precision(prev))
+
+
 def test_resnet_eval_on_planes_matches_fp32_tensors(dev):
     """DeepLabV3+/R101 in eval mode, 2 x 3 x 192 x 160 tiles: logits of the plane-tensor inference path against the fp32-tensor path
     (PYLC_EVAL_PLANES=0, the round-3 path, itself pinned to the reference by the fixtures) -- both fp32-grade, so they agree far inside the
