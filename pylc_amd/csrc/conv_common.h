@@ -123,6 +123,7 @@ struct GatherGemmArgs {
     const float* ep_res;    // same geometry and pitch as y
     unsigned* ep_amax;
     int ep_relu;
+    int ep_vec_ok;          // host: ep_scale, ep_shift and the bias (if any) are 16-byte aligned -- the lean inference epilogue reads them as float4
     // ... on fp16-plane tensors (conv_pl.hip, EP instantiations; pylc_conv2d_fwd_bnact_ex): the residual may arrive as planes
     // (ep_res_fmt 1 = one plane, 2 = two planes at + ep_res_plane_stride halves, scaled with the bound behind ep_res_scale), the output may
     // leave as planes (out_half = one plane; out_planes2 = two planes at + out_plane_stride halves).  The output's scale comes from the bound

@@ -371,7 +371,7 @@ __device__ __forceinline__ float pl_epilogue_bn(const GatherGemmArgs& a, f32x4v 
 // shift (+ residual)) -- leaves as a chunk-interleaved two-plane tensor (plane_stride == 32: a pixel's 32 channels = 64 B of plane 0 + 64 B of
 // plane 1 = one 128-byte line), with the residual, if any, in the same format.  Same expressions and order per element as the general path
 // (bit-identical; tests/test_planes_gpu.py compares the two), but
-//   * no per-element edge selects, no bias,
+//   * no per-element edge selects,
 //   * WHOLE-LINE stores: per pair of column groups (one 32-channel chunk) v_permlane16_swap between lanes l / l + 16 gives every lane 16 B of
 //     one plane (8 channels), then lanes l / l ^ 8 (rows r / r + 8) swap the lower row's second group against the upper row's first, as the
 //     training epilogue does: a store instruction writes 8 rows x 128 B instead of 16 rows x 2 x 32 B;
@@ -379,7 +379,7 @@ __device__ __forceinline__ float pl_epilogue_bn(const GatherGemmArgs& a, f32x4v 
 // 16-byte piece p (0..7) of a chunk's line: pieces 0-3 = plane 0 channels 8 p .., pieces 4-7 = plane 1; lane quad q = lane >> 4 after the
 // permlane16 exchange holds, for column group j' of the pair, piece (q & 1) * 4 + (q >> 1) + 2 j'.
 // RES: 0 none, 2 two-plane interleaved residual.  Returns max |result| of this lane.
-template <int AM, int RES>
+template <int AM, int RES, bool BIAS>
 __device__ __forceinline__ float pl_epilogue_lean_ep(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], const int* rowoff, int nchunk, int wave_m, int lane,
                                                      float c, float hscale, float res_unscale) {
     constexpr int WM = 16 * AM;
@@ -411,11 +411,12 @@ __device__ __forceinline__ float pl_epilogue_lean_ep(const GatherGemmArgs& a, f3
                 rb[i] = *reinterpret_cast<const uint4*>(rp + ((upper ? base[i] : baseP[i]) + jp * 64 + piece));      // rows 8-15
             }
         }
-        f32x4v esc[2], esh[2];
+        f32x4v esc[2], esh[2], bv[BIAS ? 2 : 1];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             esc[jj] = *reinterpret_cast<const f32x4v*>(a.ep_scale + nb + (2 * jp + jj) * 16);
             esh[jj] = *reinterpret_cast<const f32x4v*>(a.ep_shift + nb + (2 * jp + jj) * 16);
+            if constexpr (BIAS) bv[jj] = *reinterpret_cast<const f32x4v*>(a.bias + nb + (2 * jp + jj) * 16);      // (the U-Net's convs carry a bias)
         }
 #pragma unroll
         for (int i = 0; i < AM; ++i) {
@@ -436,7 +437,8 @@ __device__ __forceinline__ float pl_epilogue_lean_ep(const GatherGemmArgs& a, f3
                 f32x4v val;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t = acc[i][j][r] * c;                    // (the general path's acc * unscale_a * unscale_b: powers of two)
+                    float t = acc[i][j][r] * c;                          // (the general path's acc * unscale_a * unscale_b: powers of two)
+                    if constexpr (BIAS) t += bv[jj][r];                  // (... + bias; without one the general path adds an exact 0)
                     val[r] = t * esc[jj][r] + esh[jj][r];                // BatchNorm-apply's own expression and order
                 }
                 if constexpr (RES != 0) {
@@ -553,13 +555,15 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
         // (LEAN_RES false -- the 3x3 halo kernel, whose convs carry no residual in these networks: the residual form is not compiled in, it would
         //  cost that kernel 35 spilled registers)
         const bool res_ok = a.ep_res == nullptr || (LEAN_RES && a.ep_res_fmt == 2 && planes_il(a.ep_res_plane_stride));
-        if (rows_full && nchunk + WN <= a.N && a.out_planes2 && !a.out_half && planes_il(a.out_plane_stride) && a.y_pitch == a.N_store && a.bias == nullptr &&
-            a.ep_scale != nullptr && extra == nullptr && res_ok && !do_stats && !(a.dbg_flags & 8)) {
+        if (rows_full && nchunk + WN <= a.N && a.out_planes2 && !a.out_half && planes_il(a.out_plane_stride) && a.y_pitch == a.N_store && (a.bias == nullptr || a.ep_res == nullptr) &&
+            a.ep_scale != nullptr && a.ep_vec_ok && extra == nullptr && res_ok &&
+            !do_stats && !(a.dbg_flags & 8)) {
             done = true;
             const float c = unscale_a * unscale_b;
             float m;
-            if (LEAN_RES && a.ep_res != nullptr) m = pl_epilogue_lean_ep<AM, LEAN_RES ? 2 : 0>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
-            else m = pl_epilogue_lean_ep<AM, 0>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+            if (LEAN_RES && a.ep_res != nullptr) m = pl_epilogue_lean_ep<AM, LEAN_RES ? 2 : 0, false>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+            else if (a.bias != nullptr) m = pl_epilogue_lean_ep<AM, 0, true>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+            else m = pl_epilogue_lean_ep<AM, 0, false>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
             if (a.ep_amax != nullptr) amax_commit(m, a.ep_amax);
         }
     }

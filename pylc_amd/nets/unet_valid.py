@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..layers import Conv2d, BatchNorm2d, Dropout, Named
+from ..layers import Conv2d, BatchNorm2d, Dropout, Named, conv_bn
 
 
 class UNetConvBlock(nn.Module):
@@ -20,9 +20,11 @@ class UNetConvBlock(nn.Module):
     def forward(self, x, out_planes=False):
         """out_planes: the block's output has ONE reader, a conv that takes fp16 planes (the 1x1 conv of the next up block)."""
         b = self.block
-        x = b.child(1)(b.child(0)(x), relu=True, out_planes=b.child(3).takes_planes(), sole=True)      # feeds the second conv only
+        # (layers.conv_bn: in inference BatchNorm + ReLU run in the conv epilogue and the tensors between the convs are fp16 planes; in
+        #  training it is bn(conv(x), ...) as written in the reference)
+        x = conv_bn(b.child(0), b.child(1), x, relu=True, out_planes=b.child(3).takes_planes(), sole=True)      # feeds the second conv only
         # the block's nn.Dropout (unet.py:120) runs in the BatchNorm passes
-        return b.child(4)(b.child(3)(x), relu=True, drop=self.drop, out_planes=out_planes, sole=out_planes)
+        return conv_bn(b.child(3), b.child(4), x, relu=True, drop=self.drop, out_planes=out_planes, sole=out_planes)
 
 
 class UpConv2x2(nn.Module):

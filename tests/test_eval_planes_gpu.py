@@ -96,6 +96,8 @@ LEAN_EP_CASES = [
     (256, 64, 1, 0, 2, 64, 64, False, False),        # narrow 1x1, no ReLU
     (128, 512, 1, 0, 2, 40, 36, True, False),        # ragged M: the last tile takes the general path, the others the lean one
     (512, 96, 1, 0, 2, 32, 32, True, True),          # Cout = 96: the second wave column is half outside -> general path beside lean waves
+    (128, 128, 3, 0, 2, 68, 68, False, True, True),  # the U-Net's valid 3x3 conv WITH a bias (unet.py:111): 66 x 66 outputs, ragged halo patches
+    (64, 128, 1, 0, 2, 64, 64, False, True, True),   # bias on the 1x1 kernels
 ]
 
 
@@ -105,24 +107,28 @@ def test_lean_inference_epilogue_is_bit_identical(dev, case):
     the general epilogue of the same kernels (pylc_debug_pp_flags bit 3): the same plane bytes, scale bound and true maximum."""
     from pylc_amd import ops, layers, optim, runtime
     from pylc_amd.lib import lib, check
-    cin, cout, k, pad, B, H, W, res_planes, relu = case
+    cin, cout, k, pad, B, H, W, res_planes, relu = case[:9]
+    bias = len(case) > 9 and case[9]
     prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
     check(lib.pylc_set_conv_precision(2))
     ops.PLANES_MIN_PIXELS = 0
     runtime.eval_planes = True
     try:
         torch.manual_seed(5)
-        conv = layers.Conv2d(cin, cout, k, 1, pad, 1, bn=True).to(dev)
+        conv = layers.Conv2d(cin, cout, k, 1, pad, 1, bias=bias, init='torch' if bias else 'resnet', bn=True).to(dev)
         bn = layers.BatchNorm2d(cout).to(dev)
         with torch.no_grad():
             bn.weight.copy_(1 + 0.3 * rnd(1, cout).to(dev))
             bn.bias.copy_(0.2 * rnd(2, cout).to(dev))
             bn.running_mean.copy_(0.1 * rnd(3, cout).to(dev))
             bn.running_var.copy_(1 + 0.2 * rnd(4, cout).abs().to(dev))
+            if bias:
+                conv.bias.copy_(0.5 * rnd(8, cout).to(dev))
         arena = optim.FlatArena(torch.nn.ModuleList([conv, bn]))
         conv.eval(); bn.eval()
         x = nhwc(rnd(6, B, cin, H, W, scale=1.5), dev)
-        res = nhwc(rnd(7, B, cout, H, W), dev) if res_planes else None
+        oh = ops.conv_out_size(H, k, 1, pad, 1)
+        res = nhwc(rnd(7, B, cout, oh, oh), dev) if res_planes else None
         out = []
         with torch.no_grad():
             xp = ops.to_planes(x)

@@ -29,7 +29,7 @@ for name in (sys.argv[1:] or list(CFG)):
                 for _ in range(3): out = model.test(x)[0]
                 ops.eval_plane_convs[0] = 0; ops.plane_conversions[:] = [0, 0]; ops.amax_passes[:] = [0, 0]
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                n = 5
+                n = 20
                 for _ in range(n): out = model.test(x)[0]
                 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
                 res.setdefault(on, []).append((dt, ops.eval_plane_convs[0] // n, ops.plane_conversions[0] // n, ops.amax_passes[0] // n, out.float().clone()))
