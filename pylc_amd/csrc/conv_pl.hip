@@ -479,6 +479,109 @@ __device__ __forceinline__ float pl_epilogue_lean_ep(const GatherGemmArgs& a, f3
     return ep_max;
 }
 
+// ... and its ONE-PLANE form (precision mode 3: out_half, residual none or one plane of the same geometry).  A fragment row's 64 channels are
+// one 128-byte run; stores and residual loads move whole runs by the exchanges of pl_epilogue_lean<.., HALF = true>: v_permlane16_swap merges the
+// quads of lanes l / l + 16 into 8 consecutive channels (pair 0 = column groups 0-1, pair 1 = groups 2-3), lanes l / l ^ 8 swap pair 1 of the
+// lower row against pair 0 of the upper row.  Per element the general path's expressions: val = act((c t) scale + shift (+ residual)),
+// h = rn16(val s_y).  RES: 0 none, 1 one-plane residual.  Returns max |val| of this lane.
+template <int AM, int RES, bool BIAS>
+__device__ __forceinline__ float pl_epilogue_lean_ep_half(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], const int* rowoff, int nchunk, int wave_m, int lane,
+                                                          float c, float hscale, float res_unscale) {
+    constexpr int WM = 16 * AM;
+    typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const unsigned q4 = (unsigned)(lane >> 4);
+    const bool upper = (lane & 8) != 0, odd_row = (q4 & 1u) != 0;
+    // after the pair merge: even quads hold channels 4 q .. + 7 of the pair's first group, odd quads 16 + 4 (q - 1) .. + 7 (the second group)
+    const unsigned col = (upper ? 32u : 0u) + (odd_row ? 16u + 4u * (q4 - 1u) : 4u * q4);
+    unsigned base[AM], baseP[AM];                           // element offsets of the wave's first column in this lane's row / the partner row (r ^ 8)
+#pragma unroll
+    for (int i = 0; i < AM; ++i) {
+        base[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nchunk);
+        baseP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nchunk);
+    }
+    const int nb = nchunk + 4 * (int)q4;
+    _Float16* const yp = reinterpret_cast<_Float16*>(a.y);
+    const _Float16* const rp = reinterpret_cast<const _Float16*>(a.ep_res);
+    const bool relu = a.ep_relu != 0;
+    float ep_max = 0.f;
+    f32x4v esc[4], esh[4], bv[BIAS ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        esc[j] = *reinterpret_cast<const f32x4v*>(a.ep_scale + nb + j * 16);
+        esh[j] = *reinterpret_cast<const f32x4v*>(a.ep_shift + nb + j * 16);
+        if constexpr (BIAS) bv[j] = *reinterpret_cast<const f32x4v*>(a.bias + nb + j * 16);      // (Xception's pointwise convs: the folded BatchNorm of the depthwise conv)
+    }
+    constexpr int IB = 2;                                   // row fragments per batch of residual loads
+#pragma unroll
+    for (int i0 = 0; i0 < AM; i0 += IB) {
+        uint4 la[RES ? IB : 1], lb[RES ? IB : 1];
+        if constexpr (RES != 0) {
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                la[ii] = *reinterpret_cast<const uint4*>(rp + ((upper ? baseP[i0 + ii] : base[i0 + ii]) + col));      // rows 0-7 of the fragment
+                lb[ii] = *reinterpret_cast<const uint4*>(rp + ((upper ? base[i0 + ii] : baseP[i0 + ii]) + col));      // rows 8-15
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const int i = i0 + ii;
+            uint2 rq[RES ? 4 : 1];                           // the residual's halves of this lane's four channel quads
+            if constexpr (RES != 0) {
+                const unsigned s0 = upper ? la[ii].x : lb[ii].x, s1 = upper ? la[ii].y : lb[ii].y, s2 = upper ? la[ii].z : lb[ii].z, s3 = upper ? la[ii].w : lb[ii].w;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xF, 0xF, true);      // row_ror:8 = lane ^ 8
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xF, 0xF, true);
+                const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s2, 0x128, 0xF, 0xF, true);
+                const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s3, 0x128, 0xF, 0xF, true);
+                // own row: pair 0 (lower lanes loaded it, upper lanes received it), pair 1 (the other way round)
+                const unsigned p0x = upper ? r0 : la[ii].x, p0y = upper ? r1 : la[ii].y, p0z = upper ? r2 : la[ii].z, p0w = upper ? r3 : la[ii].w;
+                const unsigned p1x = upper ? lb[ii].x : r0, p1y = upper ? lb[ii].y : r1, p1z = upper ? lb[ii].z : r2, p1w = upper ? lb[ii].w : r3;
+                const u32x2_ ax = __builtin_amdgcn_permlane16_swap(p0x, p0z, false, false), ay = __builtin_amdgcn_permlane16_swap(p0y, p0w, false, false);
+                const u32x2_ bx = __builtin_amdgcn_permlane16_swap(p1x, p1z, false, false), by = __builtin_amdgcn_permlane16_swap(p1y, p1w, false, false);
+                rq[0] = uint2{ax.x, ay.x}; rq[1] = uint2{ax.y, ay.y}; rq[2] = uint2{bx.x, by.x}; rq[3] = uint2{bx.y, by.y};
+            }
+            uint2 hq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4v val;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] * c;              // (the general path's acc * unscale_a * unscale_b: powers of two)
+                    if constexpr (BIAS) t += bv[j][r];
+                    val[r] = t * esc[j][r] + esh[j][r];      // BatchNorm-apply's own expression and order
+                }
+                if constexpr (RES != 0) {
+                    const f32x4v rv = __builtin_convertvector(__builtin_bit_cast(f16x4_, rq[j]), f32x4v) * res_unscale;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] += rv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (relu) val[r] = fmaxf(val[r], 0.f);
+                    ep_max = fmaxf(ep_max, fabsf(val[r]));
+                }
+                const f32x4v v = val * hscale;
+                const f16x4_ h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                hq[j] = __builtin_bit_cast(uint2, h);
+            }
+            const u32x2_ ax = __builtin_amdgcn_permlane16_swap(hq[0].x, hq[1].x, false, false), ay = __builtin_amdgcn_permlane16_swap(hq[0].y, hq[1].y, false, false);
+            const u32x2_ bx = __builtin_amdgcn_permlane16_swap(hq[2].x, hq[3].x, false, false), by = __builtin_amdgcn_permlane16_swap(hq[2].y, hq[3].y, false, false);
+            // pair 0 = (ax.x, ay.x, ax.y, ay.y), pair 1 = (bx.x, by.x, bx.y, by.y); the upper row sends pair 0, the lower row pair 1
+            const unsigned s0 = upper ? ax.x : bx.x, s1 = upper ? ay.x : by.x, s2 = upper ? ax.y : bx.y, s3 = upper ? ay.y : by.y;
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xF, 0xF, true);
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xF, 0xF, true);
+            const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s2, 0x128, 0xF, 0xF, true);
+            const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s3, 0x128, 0xF, 0xF, true);
+            const uint4 da = {upper ? r0 : ax.x, upper ? r1 : ay.x, upper ? r2 : ax.y, upper ? r3 : ay.y};      // lower: own pair 0; upper: the lower row's pair 1
+            const uint4 db = {upper ? bx.x : r0, upper ? by.x : r1, upper ? bx.y : r2, upper ? by.y : r3};      // lower: the upper row's pair 0; upper: own pair 1
+            *reinterpret_cast<uint4*>(yp + ((upper ? baseP[i] : base[i]) + col)) = da;      // rows 0-7 of the fragment, 128 B each
+            *reinterpret_cast<uint4*>(yp + ((upper ? base[i] : baseP[i]) + col)) = db;      // rows 8-15
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one batch of residual loads at a time
+    }
+    return ep_max;
+}
+
 // Epilogue shared by the planes kernels (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic,
 // then stores): fold the cross-term accumulator, undo the operand scales, bias, optional accumulation into y, BatchNorm statistics
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
@@ -565,6 +668,24 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             else if (a.bias != nullptr) m = pl_epilogue_lean_ep<AM, 0, true>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
             else m = pl_epilogue_lean_ep<AM, 0, false>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
             if (a.ep_amax != nullptr) amax_commit(m, a.ep_amax);
+        }
+        if constexpr (NTERMS == 1) {
+            // ... one-plane result (precision mode 3), residual none or one dense plane; 16-byte pieces need pixel rows that are multiples of 8 channels
+            const bool res1_ok = a.ep_res == nullptr || (LEAN_RES && a.ep_res_fmt == 1);
+            if (!done && rows_full && nchunk + WN <= a.N && a.out_half && a.y_pitch == a.N_store && (a.N_store & 7) == 0 && a.ep_scale != nullptr &&
+                a.ep_vec_ok && extra == nullptr && res1_ok && !do_stats && !(a.dbg_flags & 8)) {
+                done = true;
+                const float c = unscale_a * unscale_b;
+                float m;
+                if (LEAN_RES && a.ep_res != nullptr) {
+                    m = a.bias != nullptr ? pl_epilogue_lean_ep_half<AM, LEAN_RES ? 1 : 0, true>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale)
+                                          : pl_epilogue_lean_ep_half<AM, LEAN_RES ? 1 : 0, false>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+                } else {
+                    m = a.bias != nullptr ? pl_epilogue_lean_ep_half<AM, 0, true>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale)
+                                          : pl_epilogue_lean_ep_half<AM, 0, false>(a, acc, rowoff, nchunk, wave_m, lane, c, hscale, res_unscale);
+                }
+                if (a.ep_amax != nullptr) amax_commit(m, a.ep_amax);
+            }
         }
     }
     constexpr bool bn = BNB;                 // (its own instantiations, gg_pl*_kernel<..., BNB = true>: the other launches keep their registers)

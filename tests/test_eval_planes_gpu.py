@@ -101,16 +101,18 @@ LEAN_EP_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', LEAN_EP_CASES)
-def test_lean_inference_epilogue_is_bit_identical(dev, case):
-    """pl_epilogue_lean_ep (conv_pl.hip: edge-free tiles of the fused inference conv, whole-line plane stores and residual loads) against
-    the general epilogue of the same kernels (pylc_debug_pp_flags bit 3): the same plane bytes, scale bound and true maximum."""
+@pytest.mark.parametrize('prec', [2, 3], ids=['f16x3', 'mode3'])
+@pytest.mark.parametrize('case', LEAN_EP_CASES + [(728, 728, 1, 0, 2, 32, 32, True, False), (728, 728, 1, 0, 2, 32, 32, True, True, True)])      # + the Xception pointwise conv with its skip, without / with the folded bias
+def test_lean_inference_epilogue_is_bit_identical(dev, case, prec):
+    """pl_epilogue_lean_ep / pl_epilogue_lean_ep_half (conv_pl.hip: edge-free tiles of the fused inference conv, whole-line plane stores and
+    residual loads, two-plane and one-plane tensors) against the general epilogue of the same kernels (pylc_debug_pp_flags bit 3): the same
+    plane bytes, scale bound and true maximum."""
     from pylc_amd import ops, layers, optim, runtime
     from pylc_amd.lib import lib, check
     cin, cout, k, pad, B, H, W, res_planes, relu = case[:9]
     bias = len(case) > 9 and case[9]
     prev, prev_min, prev_ep = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS, runtime.eval_planes
-    check(lib.pylc_set_conv_precision(2))
+    check(lib.pylc_set_conv_precision(prec))
     ops.PLANES_MIN_PIXELS = 0
     runtime.eval_planes = True
     try:
@@ -139,7 +141,7 @@ def test_lean_inference_epilogue_is_bit_identical(dev, case):
                 got = layers.conv_bn(conv, bn, xp, residual=rp, relu=relu, out_planes=True)
                 torch.cuda.synchronize()
                 assert ops.eval_plane_convs[0] == n0 + 1 and ops.is_planes(got)
-                out.append((got.permute(0, 2, 3, 1).reshape(-1).view(torch.int32).clone(), ops.amax_of(got).clone(), ops.planes_amax(got).clone()))
+                out.append((got.permute(0, 2, 3, 1).reshape(-1).view(torch.int16).clone(), ops.amax_of(got).clone(), ops.planes_amax(got).clone()))
         assert torch.equal(out[0][0], out[1][0]), 'plane bytes differ: %d words' % (out[0][0] != out[1][0]).sum().item()
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
         del arena
