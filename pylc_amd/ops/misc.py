@@ -112,7 +112,7 @@ def maxpool(x, k, stride, pad=0, link=None, out_planes=False):
     """out_planes: the pooled tensor has ONE reader, a conv that takes fp16 planes (the U-Net's next block): written as planes directly."""
     b, c, h, w = x.shape
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    if (out_planes and torch.is_grad_enabled() and ranges_needed() and not _runtime.no_planes and not is_planes(x) and c % 8 == 0
+    if (out_planes and (torch.is_grad_enabled() or _runtime.eval_planes) and ranges_needed() and not _runtime.no_planes and not is_planes(x) and c % 8 == 0
             and planes_ok(c, b * oh * ow) and b * oh * ow >= _core.PLANES_MIN_PIXELS and not os.environ.get('PYLC_NO_POOL_PLANES')):
         bound = amax_of(x)                 # the maxima are bounded by the input's range
         return mark_planes(MaxPoolFn.apply(x, k, stride, pad, link, bound), bound)
@@ -207,11 +207,12 @@ class UpCatPlanesFn(torch.autograd.Function):
 
 
 def upsample2_crop_concat(z, bridge, link=None):
-    """cat([upsample_x2_bilinear(z), center_crop(bridge)], 1) as one fp16-plane tensor (training graphs with ranged arithmetic, channel counts
-    that are multiples of 8); None when that form does not apply -- the caller then uses bilinear(into=) + crop_concat."""
+    """cat([upsample_x2_bilinear(z), center_crop(bridge)], 1) as one fp16-plane tensor (training graphs and plane-tensor inference with ranged
+    arithmetic, channel counts that are multiples of 8); None when that form does not apply -- the caller then uses bilinear(into=) +
+    crop_concat."""
     c1, c2 = z.shape[1], bridge.shape[1]
     pixels = z.shape[0] * 4 * z.shape[2] * z.shape[3]
-    if not (torch.is_grad_enabled() and ranges_needed() and not _runtime.no_planes and c1 % 8 == 0 and c2 % 8 == 0 and planes_ok(c1 + c2, pixels)
+    if not ((torch.is_grad_enabled() or _runtime.eval_planes) and ranges_needed() and not _runtime.no_planes and c1 % 8 == 0 and c2 % 8 == 0 and planes_ok(c1 + c2, pixels)
             and pixels >= _core.PLANES_MIN_PIXELS and not is_planes(z) and _runtime.upcat_planes):
         return None
     bound = torch.maximum(amax_of(z), amax_of(bridge))          # float bit patterns of non-negative values: integer order = float order

@@ -141,7 +141,10 @@ def test_lean_inference_epilogue_is_bit_identical(dev, case, prec):
                 got = layers.conv_bn(conv, bn, xp, residual=rp, relu=relu, out_planes=True)
                 torch.cuda.synchronize()
                 assert ops.eval_plane_convs[0] == n0 + 1 and ops.is_planes(got)
-                out.append((got.permute(0, 2, 3, 1).reshape(-1).view(torch.int16).clone(), ops.amax_of(got).clone(), ops.planes_amax(got).clone()))
+                raw = got.permute(0, 2, 3, 1).reshape(-1).view(torch.int16)
+                if prec == 3:
+                    raw = raw[:got.numel()]                  # one plane: the second half of the buffer is never written
+                out.append((raw.clone(), ops.amax_of(got).clone(), ops.planes_amax(got).clone()))
         assert torch.equal(out[0][0], out[1][0]), 'plane bytes differ: %d words' % (out[0][0] != out[1][0]).sum().item()
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
         del arena
