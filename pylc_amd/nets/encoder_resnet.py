@@ -90,7 +90,11 @@ class ResNet101(nn.Module):
         silently compute on reinterpreted bytes.  (Hooks on the INNER modules -- Bottleneck outputs -- still see the raw format: read
         them through ops.as_nhwc.)"""
         x = self.bn1(self.conv1(x4), relu=True)
-        x = ops.maxpool(x, 3, 2, 1)
+        # (inference: the pooled tensor is read by layer1's conv1 and downsample conv only -- written as their plane operand directly; training
+        #  keeps the fp32 tensor, whose gradient the two dgrads accumulate)
+        blk = self.layer1[0]
+        pool_planes = (not torch.is_grad_enabled()) and blk.conv1.takes_planes() and (blk.downsample is None or blk.downsample.child(0).takes_planes())
+        x = ops.maxpool(x, 3, 2, 1, out_planes=pool_planes)
         low = self.layer1(x)
         x = self.layer4(self.layer3(self.layer2(low)))
         if not keep_planes:
