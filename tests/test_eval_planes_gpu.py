@@ -98,6 +98,8 @@ LEAN_EP_CASES = [
     (512, 96, 1, 0, 2, 32, 32, True, True),          # Cout = 96: the second wave column is half outside -> general path beside lean waves
     (128, 128, 3, 0, 2, 68, 68, False, True, True),  # the U-Net's valid 3x3 conv WITH a bias (unet.py:111): 66 x 66 outputs, ragged halo patches
     (64, 128, 1, 0, 2, 64, 64, False, True, True),   # bias on the 1x1 kernels
+    (256, 1024, 1, 0, 32, 32, 32, True, True),       # BASELINE size: configs[2]'s conv3 at batch 32 (2048 tiles, four rounds of blocks)
+    (728, 728, 1, 0, 8, 64, 64, True, True, True),   # BASELINE size: configs[4]'s middle-flow pointwise conv at 1024^2 / 16, batch 8
 ]
 
 
