@@ -139,7 +139,8 @@ def conv_bn(conv, bn, x, residual=None, relu=False, conv_link=None, out_planes=F
     """[drop](bn(conv(x), residual, relu)).  In inference (eval mode, autograd off) the BatchNorm, the residual add and the ReLU run
     inside the conv epilogue (ops.conv_bn_act_eval); otherwise the two modules are called as usual (the conv output has ONE consumer,
     the BatchNorm: that is what lets its backward hand dy back as fp16 planes)."""
-    if (not bn.training and not torch.is_grad_enabled() and runtime.fuse_eval_bn and conv.cin % 4 == 0
+    thin = conv.cin % 4 != 0 and not ops.is_planes(x) and x.shape[1] == ((conv.cin + 3) & ~3)          # the stem on the 4-channel input pack
+    if (not bn.training and not torch.is_grad_enabled() and runtime.fuse_eval_bn and (conv.cin % 4 == 0 or thin)
             and (residual is None or ops.is_planes(residual) or ops.pitch_of(ops.as_nhwc(residual)) == ((conv.cout + 3) & ~3))):
         return ops.conv_bn_act_eval(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn.running_mean,
                                     bn.running_var, bn.weight, bn.bias, bn.eps, residual, relu, into, coef=bn.eval_coeffs(),

@@ -89,7 +89,7 @@ class ResNet101(nn.Module):
         any other caller gets ordinary fp32 NHWC tensors (one conversion pass each), so that a foreign op on the features cannot
         silently compute on reinterpreted bytes.  (Hooks on the INNER modules -- Bottleneck outputs -- still see the raw format: read
         them through ops.as_nhwc.)"""
-        x = self.bn1(self.conv1(x4), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x4, relu=True)          # (inference: BatchNorm + ReLU in the stem conv's epilogue)
         # (inference: the pooled tensor is read by layer1's conv1 and downsample conv only -- written as their plane operand directly; training
         #  keeps the fp32 tensor, whose gradient the two dgrads accumulate)
         blk = self.layer1[0]

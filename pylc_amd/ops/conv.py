@@ -517,7 +517,10 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
         residual = as_nhwc(residual)
     cout, cin_w, r, s = w.shape
     cin = x.shape[1]
-    if cin != cin_w or cin_w % 4 or not w.permute(0, 2, 3, 1).is_contiguous():
+    w_k = w
+    if cin_w % 4 != 0 and cin == _r4(cin_w):
+        w_k = _padded_stem_filter(w, cin)          # the thin-input stem (resnet.py:72, unet.py:111 first block): x is the 4-channel pack
+    elif cin != cin_w or cin_w % 4 or not w.permute(0, 2, 3, 1).is_contiguous():
         raise L.PylcError('conv_bn_act_eval: needs a KRSC filter with Cin % 4 == 0 matching the input')
     b, _, h, wd = x.shape
     oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
@@ -536,7 +539,7 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
         keep = (amax_of(x), weight_amax(w))
         d.x_amax, d.w_amax = ptr(keep[0]), ptr(keep[1])
         planes = getattr(w, '_pylc_planes', None)
-        if planes is not None:
+        if planes is not None and w_k is w:
             d.w_planes, d.w_planes_fmt = ptr(planes[0]), filter_planes_fmt(planes)
         amax = amax_slot(x.device)
     st = stream()
@@ -552,7 +555,7 @@ def conv_bn_act_eval(x, w, bias, stride, pad, dil, running_mean, running_var, ga
     if _core._timer is not None and _core._timer.inference and cout > 64 and cin % 8 == 0:
         ev = _core._timer.bracket(2.0 * b * oh * ow * cout * r * s * cin, 1, 'fwd_bnact%dx%d' % (r, s), 4.0 * (b * h * wd * cin + w.numel() + b * oh * ow * cout))
         ev[0].record()
-    check(lib.pylc_conv2d_fwd_bnact(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(coef[:cout]), ptr(coef[cout:]), ptr(res), int(relu), ptr(y),
+    check(lib.pylc_conv2d_fwd_bnact(C.byref(d), ptr(x), ptr(w_k), ptr(bias), ptr(coef[:cout]), ptr(coef[cout:]), ptr(res), int(relu), ptr(y),
                                     ptr(amax), st))
     if ev is not None:
         ev[1].record()
