@@ -40,6 +40,7 @@ CASES = [
     (128, 128, 3, 2, 1, 1, 2, 45, 45, 'none', True),         # stride 2
     (2048, 256, 3, 1, 12, 12, 2, 32, 32, 'none', True),      # ASPP branch: tap skipping
     (728, 728, 1, 1, 0, 1, 2, 16, 16, 'planes', False),      # Xception pointwise + skip, channel tails
+    (64, 64, 3, 1, 1, 1, 8, 128, 128, 'none', True),         # 64 channels on enough patches for the halo kernel's narrow form (the U-Net's first blocks)
 ]
 
 
@@ -93,6 +94,7 @@ LEAN_EP_CASES = [
     (1024, 256, 1, 0, 4, 32, 32, False, True),       # conv1, the 256-row kernel's shapes
     (256, 256, 3, 1, 4, 32, 32, False, True),        # conv2: the halo kernel
     (64, 64, 3, 1, 2, 64, 64, False, True),          # layer1 3x3, narrow wave layout
+    (64, 64, 3, 1, 8, 128, 128, False, True),        # ... on the halo kernel's narrow form
     (256, 64, 1, 0, 2, 64, 64, False, False),        # narrow 1x1, no ReLU
     (128, 512, 1, 0, 2, 40, 36, True, False),        # ragged M: the last tile takes the general path, the others the lean one
     (512, 96, 1, 0, 2, 32, 32, True, True),          # Cout = 96: the second wave column is half outside -> general path beside lean waves

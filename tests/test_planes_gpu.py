@@ -459,7 +459,8 @@ def test_conv_with_bias_on_planes(dev, f16x3, case):
     assert rel(out['planes'][0], ref) < 3e-6
 
 
-@pytest.mark.parametrize('case', [(128, 128, 8, 64, 64), (64, 256, 4, 128, 128), (256, 136, 8, 48, 80)])
+@pytest.mark.parametrize('case', [(128, 128, 8, 64, 64), (64, 256, 4, 128, 128), (256, 136, 8, 48, 80),
+                                  (64, 64, 4, 128, 128), (128, 64, 4, 124, 124), (64, 48, 4, 128, 128)])      # the last three: <= 64 output channels, the NARROW form
 def test_halo_kernel_is_bit_identical(dev, f16x3, case):
     """The 3x3 halo variant (conv_pl.hip gg_plh_kernel: a 16x16 output patch's 18x18 input rows DMA'd once per channel chunk) takes
     launches of at least half a round of 256-pixel tiles -- larger than the other cases of this file: forward and dgrad (flipped taps)
