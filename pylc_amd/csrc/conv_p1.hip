@@ -336,7 +336,7 @@ extern "C" int pylc_debug_p1(int on) { g_p1 = on; return PYLC_OK; }
 
 bool takes_p1(const GatherGemmArgs& a) {
     const long long tiles = (long long)cdiv(a.M, P1_BM) * cdiv(a.N_store, P1_BN);
-    return g_p1 && !a.w_il && a.ident && !a.accumulate && a.bias == nullptr && a.ep_scale == nullptr && a.ep_amax == nullptr && a.ep_res == nullptr && !a.out_planes2 && a.dbg == nullptr && a.Cin >= 2 * BK &&
+    return g_p1 && !a.w_il && !planes_il(a.x_plane_stride) && a.ident && !a.accumulate && a.bias == nullptr && a.ep_scale == nullptr && a.ep_amax == nullptr && a.ep_res == nullptr && !a.out_planes2 && a.dbg == nullptr && a.Cin >= 2 * BK &&
            tiles >= 2 * kNumCU &&      // at least one full round of resident blocks, or there is no next tile to hide a store behind
            (long long)a.M * a.y_pitch * 4 < (1ll << 31);      // y addressed through a 32-bit buffer offset
 }

@@ -403,7 +403,7 @@ extern "C" int pylc_debug_ps(int on) { g_ps = on; return PYLC_OK; }
 
 bool takes_ps(const GatherGemmArgs& a) {
     const long long tiles = (long long)cdiv(a.M, PS_BM) * cdiv(a.N_store, PS_BN);
-    if (!(g_ps & 1) || a.w_il || !a.ident || a.accumulate || a.bias != nullptr || a.ep_scale != nullptr || a.ep_amax != nullptr || a.ep_res != nullptr || a.out_planes2 || a.dbg != nullptr || a.out_half || a.bn_y != nullptr)
+    if (!(g_ps & 1) || a.w_il || planes_il(a.x_plane_stride) || !a.ident || a.accumulate || a.bias != nullptr || a.ep_scale != nullptr || a.ep_amax != nullptr || a.ep_res != nullptr || a.out_planes2 || a.dbg != nullptr || a.out_half || a.bn_y != nullptr)
         return false;
     if (a.add_src != nullptr && !(g_ps & 2)) return false;
     return a.Cin >= 2 * BK && a.N_store > 64 && tiles >= kNumCU &&      // at least a tile per CU; narrow outputs stay on the NARROW per-tile form

@@ -12,6 +12,18 @@ pytestmark = pytest.mark.gpu
 from tests.conftest import needs_experimental      # noqa: E402
 
 
+@pytest.fixture
+def separate_planes(monkeypatch):
+    """The round-4 plane format for one test: separate filter planes (env, read when the arena prepares them) and separate pixel planes
+    (pylc_set_planes_interleave is process-wide: restored afterwards) -- what the experimental 1x1 kernels read (takes_p1 / takes_ps)."""
+    import os
+    from pylc_amd.lib import lib
+    monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')
+    lib.pylc_set_planes_interleave(0)
+    yield
+    lib.pylc_set_planes_interleave(0 if os.environ.get('PYLC_NO_PLANE_INTERLEAVE') else 1)
+
+
 def rnd(seed, *shape, scale=1.0):
     return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
 
@@ -255,14 +267,13 @@ def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
 @needs_experimental()
 @pytest.mark.parametrize('shape', [(2, 64, 256, 1024), (2, 64, 1024, 256), (1, 128, 64, 256), (2, 70, 256, 48), (1, 96, 72, 200)])
 @pytest.mark.parametrize('mode', [2, 3])
-def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
+def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, separate_planes):
     """conv_p1.hip (off by default: pylc_debug_p1): the persistent 1x1 kernel whose finished tile is stored under the next tile's main
     loop -- output bit-identical to the per-tile kernel, run twice (the counted vmcnt of its main loop depends on every store being
     issued: masked rows / channel quads, here Cout = 48 and ragged M, must not change the count), BatchNorm statistics equal to sums
     over the output."""
     from pylc_amd import ops, layers, optim
     from pylc_amd.lib import lib, check
-    monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')      # the experimental 1x1 kernels read separate filter planes only (takes_p1 / takes_ps)
     B, H, cin, cout = shape
     prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
     check(lib.pylc_set_conv_precision(mode))
@@ -300,14 +311,13 @@ def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
 @needs_experimental()
 @pytest.mark.parametrize('mode', [2, 3])
 @pytest.mark.parametrize('shape', [(8, 64, 256, 1024), (8, 61, 96, 200), (2, 128, 64, 256), (8, 64, 1024, 256)])
-def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypatch):
+def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, separate_planes):
     """conv_ps.hip (pylc_debug_ps): the persistent 1x1 kernel whose loader waves stream the operand tiles through tile boundaries while its
     compute waves multiply, fold, store and go on -- output bit-identical to the per-tile kernel (run twice), BatchNorm statistics partials
     bit-identical to the 128-row per-tile kernel's and equal to sums over the output; ragged M (61^2 x 8 pixels), a ragged last channel tile
     (Cout = 200), an odd number of K-steps (Cin = 96), two K-steps per tile (Cin = 64), more tiles than CUs in several rounds."""
     from pylc_amd import ops, layers, optim
     from pylc_amd.lib import lib, check
-    monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')      # the experimental 1x1 kernels read separate filter planes only (takes_p1 / takes_ps)
     B, H, cin, cout = shape
     prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
     check(lib.pylc_set_conv_precision(mode))
@@ -344,7 +354,7 @@ def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, monkeypa
 
 
 @needs_experimental()
-def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, monkeypatch):
+def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, separate_planes):
     """The three launch kinds conv_ps.hip takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
     of gradient), and the dgrad that adds the ReLU-masked residual gradient in its epilogue (conv1 of an identity bottleneck,
     pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 8 x 61 x 64 pixels (ragged M; small enough that the
@@ -353,7 +363,6 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, monkeypat
     from pylc_amd import ops, optim, runtime
     from pylc_amd.lib import lib
     from pylc_amd.nets.encoder_resnet import Bottleneck
-    monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')      # the experimental 1x1 kernels read separate filter planes only (takes_ps)
     prev_drop = runtime.dropout_enabled
     runtime.dropout_enabled = False
     try:
