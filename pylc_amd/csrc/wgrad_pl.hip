@@ -25,15 +25,23 @@ namespace pylc {
 // arrive).  What it buys is registers: 64 instead of 128 accumulators put the kernel under 128 VGPRs, so that with two blocks per CU
 // (an LDS reservation keeps a third and fourth out) half of every SIMD's register file stays free for the BatchNorm kernels of the
 // main stream -- with the efficient 64 x 64 wave tiles, unlike the 8-wave experiment above.
-template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false, int SETS = 1>
+// M16 (round 5; 128 x 128 block tiles, 64 x 64 wave tiles): the products are v_mfma_f32_16x16x32_f16 -- one instruction per term and 32-pixel
+// K-step for each of the wave's 4 x 4 tiles of 16 x 16 -- instead of v_mfma_f32_32x32x16_f16: same FLOPs per matrix-pipe cycle, but the
+// 16 x 16 x 32 form draws less power (bare loops on random data sustain 2005 vs 1690 TFLOP/s under the board's cap,
+// tools/micro/mfma_shapes.hip; conv_pl.hip made the same move in round 1).  The LDS image is then unpadded 256-byte pixel rows with the
+// 16-byte chunk index XORed by ((row & 3) << 2) | ((row >> 2) & 3): conflict-free for the ds_write_b128 stores and for the transposed
+// reads of a 16 x 16 x 32 operand (a 32-lane half reads two 4-pixel blocks 8 pixels apart in the same 16 channels), 32 KB instead of 40.
+// Same products, summed 32 instead of 16 pixels per instruction: fp32-rounding-level differences from the 32 x 32 x 16 form.
+template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false, int SETS = 1, bool M16 = false>
 __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const WgradArgs a) {
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
     constexpr int WAVES_C = BC / WC;
     constexpr int NT = WN / 32, CT = WC / 32;
+    static_assert(!M16 || (BN == 128 && BC == 128 && WN == 64 && WC == 64 && !ACC1), "M16: 128 x 128 block tiles, 64 x 64 wave tiles, two accumulator sets");
     constexpr int VA = BN / 8, RA = 256 / VA, IA = 32 / RA > 0 ? 32 / RA : 1;      // dy tile: 8 halves per lane, RA rows per pass
     constexpr int VB = BC / 8, RB = 256 / VB, IB = 32 / RB > 0 ? 32 / RB : 1;
     constexpr bool A_ALL = RA <= 32, B_ALL = RB <= 32;                             // else only threads with row < 32 take part (BN = 32)
-    constexpr int ROWA = wg_rowb(BN), ROWB = wg_rowb(BC);
+    constexpr int ROWA = M16 ? 256 : wg_rowb(BN), ROWB = M16 ? 256 : wg_rowb(BC);
     constexpr int PLA = 32 * ROWA, PLB = 32 * ROWB;          // bytes per plane
     static_assert((BN / WN) * (BC / WC) == 4, "4 waves per block");
     static_assert(FAST == 1 || FAST == 2, "buffer-load geometry paths only");
@@ -87,9 +95,19 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const bool b_col_ok = c0 + 8 * vb < a.Cin && (B_ALL || prb < 32);          // Cin % 8 == 0
     const bool a_col_ok = n0 + 8 * va < a.N_ld && (A_ALL || pra < 32);         // N_ld % 8 == 0 (launch_wg_pl)
 
-    f32x16 acc[NT][CT];
+    f32x16 acc[M16 ? 1 : NT][M16 ? 1 : CT];
     constexpr bool TWO_ACC = NTERMS == 3 && !ACC1;
-    f32x16 acc_lo[TWO_ACC ? NT : 1][TWO_ACC ? CT : 1];
+    f32x16 acc_lo[TWO_ACC && !M16 ? NT : 1][TWO_ACC && !M16 ? CT : 1];
+    f32x4 acc16[M16 ? 4 : 1][M16 ? 4 : 1], acc16_lo[M16 && TWO_ACC ? 4 : 1][M16 && TWO_ACC ? 4 : 1];      // M16: 4 x 4 tiles of 16 x 16
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (TWO_ACC) acc16_lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    } else {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
                 acc[i][j][r] = 0.f;
                 if constexpr (TWO_ACC) acc_lo[i][j][r] = 0.f;
             }
+    }
     const float scale_a = pow2_scale_for(*a.amax_dy), scale_b = pow2_scale_for(*a.amax_x);
 
     constexpr unsigned OOB = 0xFFFFFFF0u;                 // >= num_records: the load returns zeros
@@ -194,6 +213,19 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     };
     auto store_tile = [&](auto setc) {
         constexpr int set = decltype(setc)::value;
+        if constexpr (M16) {
+            // swizzled 256-byte rows: chunk va of row r at 16 * (va ^ swz(r)); r = pra + 16 i leaves swz unchanged (RA == RB == 16)
+            const int sa = ((pra & 3) << 2) | ((pra >> 2) & 3);
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sA + pl * PLA + (pra + RA * i) * 256 + 16 * (va ^ sa)) = ra[set][i][pl];
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<uint4*>(sB + pl * PLB + (prb + RB * i) * 256 + 16 * (vb ^ sa)) = rb[set][i][pl];
+            return;
+        }
         if (A_ALL || pra < 32) {
 #pragma unroll
             for (int i = 0; i < IA; ++i)
@@ -212,7 +244,44 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const char* fa_base = sA + (8 * h + q4) * ROWA + 2 * (wave_n * WN + 16 * (g & 1) + 4 * p4);
     const char* fb_base = sB + (8 * h + q4) * ROWB + 2 * (wave_c * WC + 16 * (g & 1) + 4 * p4);
 
+    // M16 transposed reads: lane group g = the operand's k-group (pixels 8g .. 8g + 7: rows 8g + q by the first read, 8g + 4 + q by the
+    // second), lane 4q + p of the group supplies row q, channels 4p .. 4p + 3 of the 16-channel tile: chunk (tile base / 8) + (p >> 1),
+    // byte 8 (p & 1) within it.  swz(8g + q) = (q << 2) | (2g & 3), swz(8g + 4 + q) = that | 1: the second read sits 1024 bytes on with
+    // chunk bit 0 flipped; tile t of the wave XORs 32 t into the address (chunk bits 1-2; the wave's base occupies bit 3 only).
+    const int swz_lo = (q4 << 2) | ((2 * g) & 3);
+    const int m16_a0 = (8 * g + q4) * 256 + 16 * ((wave_n * 8 + (p4 >> 1)) ^ swz_lo) + 8 * (p4 & 1);
+    const int m16_b0 = (8 * g + q4) * 256 + 16 * ((wave_c * 8 + (p4 >> 1)) ^ swz_lo) + 8 * (p4 & 1);
+    auto tr16 = [&](const char* base, int off0, int t) {
+        const int o = off0 ^ (32 * t);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + o));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + ((o + 1024) ^ 16)));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto compute_tile16 = [&]() {
+        // the dy fragments of the wave's four 16-row tiles stay; the x fragments come one 16-channel tile at a time (40 fragment registers
+        // live instead of 64); within a tile the terms run term-major, four independent products between two that share an accumulator
+        f16x8 fa[4][NPL];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[t][pl] = tr16(sA + pl * PLA, m16_a0, t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x8 fb[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[pl] = tr16(sB + pl * PLB, m16_b0, j);
+            if constexpr (NTERMS == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][NPL - 1], fb[0], acc16_lo[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[NPL - 1], acc16_lo[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[0], acc16[i][j], 0, 0, 0);
+        }
+    };
     auto compute_tile = [&]() {
+        if constexpr (M16) { compute_tile16(); return; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[NT][NPL], fb[CT][NPL];
@@ -294,6 +363,27 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const float unscale_a = 1.f / scale_a, unscale_b = 1.f / scale_b;
     float* out = a.out + (size_t)split * a.slab_stride;
     const int col_base = tap * a.Cin;
+    if constexpr (M16) {
+        // 16 x 16 accumulator: lane l holds rows 4 (l >> 4) + r (cout), column l & 15 (channel)
+        const float us = unscale_a * unscale_b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + wave_c * WC + j * 16 + (lane & 15);
+            if (c >= a.Cin) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wave_n * WN + i * 16 + 4 * (lane >> 4) + r;
+                    float val = acc16[i][j][r];
+                    if constexpr (TWO_ACC) val = (val + acc16_lo[i][j][r] * (1.f / 2048.f)) * unscale_a * unscale_b;
+                    else val = val * unscale_a * unscale_b;
+                    (void)us;
+                    if (n < a.N) out[(size_t)n * a.out_row_stride + col_base + c] = val;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
         const int c = c0 + wave_c * WC + j * 32 + (lane & 31);
@@ -324,6 +414,11 @@ extern "C" int pylc_debug_wgrad_flags(int flags) { g_wg_flags = flags; return PY
 // queue early enough that the dgrads beside it gain 1.7 ms (dgrad1x1 143 -> 160, dgrad3x3 300 -> 316 TFLOP/s) -- which the BatchNorm passes,
 // now sharing HBM with a hungrier wgrad, give back (31.8 -> 33.6 ms): the step is unchanged with policy 1 (405.5 vs 405.0 tiles/s) and 0.4 %
 // slower with policy 2 (the 1x1 wgrads move as many bytes per FLOP as the BatchNorm passes they run beside).  Default 1.
+// Measured (profiles/r05_wgrad_m16.txt): serial, on the step's own tensors, the 16 x 16 x 32 form is +1-2 % on the 1x1 filters and -1..-8 % on
+// the multi-tap ones (which give up their second staging set); INSIDE the step it is +0.4 % (416.4 vs 414.9 tiles/s, three interleaved rounds)
+// when every f16x3 wgrad takes it and neutral for the 1x1 filters alone -- the cheaper matrix instructions leave power to the dgrads beside them.
+int g_wg_m16 = 2;         // 128 x 128 f16x3 wgrad on 16 x 16 x 32 MFMAs: 0 never, 1 single-tap filters, 2 always (pylc_debug_wgrad_m16)
+extern "C" int pylc_debug_wgrad_m16(int on) { g_wg_m16 = on; return PYLC_OK; }
 int g_wg_sets = 1;        // staging register sets policy (pylc_debug_wgrad_sets)
 extern "C" int pylc_debug_wgrad_sets(int mode) { g_wg_sets = mode; return PYLC_OK; }
 int g_wg_acc1 = 0;        // 1: the 128 x 128 f16x3 wgrad runs its one-accumulator, <= 128-register form (pylc_debug_wgrad_acc1)
@@ -344,6 +439,17 @@ static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
     }
     // two staging sets (loads two tiles ahead): pylc_debug_wgrad_sets -- 0 never, 1 multi-tap filters only, 2 always
     const bool two = g_wg_sets == 2 || (g_wg_sets == 1 && a.TR * a.TS > 1);
+    if constexpr (BN == 128 && BC == 128) {
+        // f16x3 only: the one-plane instantiations (precision mode 3) are 5-28 % slower in this form (profiles/r05_wgrad_m16.txt)
+        if (a.nterms == 3 && (g_wg_m16 == 2 || (g_wg_m16 == 1 && a.TR * a.TS == 1))) {
+            constexpr size_t lds = 4 * 32 * 256;
+            // (two staging sets do not fit beside the 40 fragment registers of this form: 256 VGPRs and spills -- one set)
+            if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, false, 1, true>), g, b, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, false, 1, true>), g, b, lds, st, a);
+            PYLC_LAUNCH_CHECK();
+            return PYLC_OK;
+        }
+    }
     if (a.nterms == 1) {
         constexpr size_t lds = wgpl_smem<BN, BC, 1>();
         if (two) {

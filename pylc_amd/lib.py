@@ -94,6 +94,7 @@ SIGNATURES = {
     'pylc_conv1x1_fold_input_affine': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     'pylc_debug_wgrad_acc1': (_I, [_I]),
     'pylc_debug_wgrad_sets': (_I, [_I]),
+    'pylc_debug_wgrad_m16': (_I, [_I]),
     'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
@@ -256,6 +257,8 @@ def init():
             lib.pylc_set_planes_interleave(0)
         if os.environ.get('PYLC_WG_SETS') is not None:            # wgrad operand staging sets: 0 one, 1 two for multi-tap filters, 2 two always (A/B)
             lib.pylc_debug_wgrad_sets(int(os.environ['PYLC_WG_SETS']))
+        if os.environ.get('PYLC_WG_M16') is not None:             # 128 x 128 wgrad on 16 x 16 x 32 MFMAs (A/B)
+            lib.pylc_debug_wgrad_m16(int(os.environ['PYLC_WG_M16']))
         if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)
             lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
         if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)

@@ -46,7 +46,11 @@ def f16x3(dev):
     check(lib.pylc_set_conv_precision(2))
     ops.PLANES_MIN_PIXELS = 0              # the cases here are small: take the planes kernels at every size
     runtime.dropout_enabled = True         # (whole-network parity tests switch dropout off process-wide)
+    # the bit-identity cases compare with the fp32-operand wgrad (32x32x16 MFMAs): the planes wgrad runs in that form here; its default
+    # 16x16x32 form (same products, 32 pixels per instruction) has test_wgrad_16x16x32_form_matches_32x32x16_form
+    lib.pylc_debug_wgrad_m16(0)
     yield
+    lib.pylc_debug_wgrad_m16(2)
     ops.PLANES_MIN_PIXELS = prev_min
     runtime.dropout_enabled = prev_drop
     check(lib.pylc_set_conv_precision(prev))
@@ -391,6 +395,41 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, separate_
         lib.pylc_debug_ps(0)
         lib.pylc_debug_pp_flags(0)
         runtime.dropout_enabled = prev_drop
+
+
+@pytest.mark.parametrize('case', [(256, 256, 3, 1, 1, 1, 2, 32, 32), (128, 512, 1, 1, 0, 1, 2, 32, 64), (304, 256, 3, 1, 1, 1, 1, 20, 44),
+                                  (136, 200, 3, 1, 2, 2, 3, 17, 23), (2048, 256, 3, 1, 12, 12, 2, 32, 32), (128, 128, 3, 2, 1, 1, 2, 45, 45)])
+def test_wgrad_16x16x32_form_matches_32x32x16_form(dev, f16x3, case):
+    """wgrad_pl.hip's default form for 128 x 128 f16x3 tiles (v_mfma_f32_16x16x32_f16 on swizzled unpadded LDS rows, pylc_debug_wgrad_m16)
+    against the 32x32x16 form: the same products, so the results differ by isolated last-place roundings of the folded cross terms
+    (<= 2 ulp of the largest gradient), and both sit at the same distance from fp64."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib
+    cin, cout, k, st, pad, dil, B, H, W = case
+    torch.manual_seed(3)
+    conv = layers.Conv2d(cin, cout, k, st, pad, dil).to(dev)
+    arena = optim.FlatArena(conv)
+    x = nhwc(rnd(5, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
+    dws = {}
+    try:
+        for m16 in (0, 2):
+            lib.pylc_debug_wgrad_m16(m16)
+            arena.g.zero_()
+            x.grad = None
+            y = conv(x)
+            dy = nhwc(rnd(6, *y.shape), dev)
+            y.backward(dy)
+            ops.sync_side_streams()
+            torch.cuda.synchronize()
+            dws[m16] = conv.weight.grad.detach().clone()
+    finally:
+        lib.pylc_debug_wgrad_m16(0)
+    wr = conv.weight.detach().double().cpu().requires_grad_(True)
+    torch.nn.functional.conv2d(x.detach().double().cpu(), wr, None, st, pad, dil).backward(dy.double().cpu())
+    e0, e2 = rel(dws[0], wr.grad), rel(dws[2], wr.grad)
+    print('wgrad vs fp64: 32x32x16 %.2e, 16x16x32 %.2e; forms differ by %.2e of max|dw|' % (e0, e2, rel(dws[2], dws[0])))
+    assert rel(dws[2], dws[0]) < 2.5e-7
+    assert e2 < max(3e-6, 1.2 * e0)
 
 
 def test_one_accumulator_wgrad_is_fp32_grade(dev, f16x3):
