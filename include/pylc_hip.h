@@ -653,6 +653,9 @@ int pylc_debug_dw_tiles(int on);
 /* wgrad_pl.hip: 1 = the 128 x 128 wgrad takes its products as v_mfma_f32_16x16x32_f16 (swizzled unpadded LDS rows) instead of
  * v_mfma_f32_32x32x16_f16: same terms, fp32-rounding-level differences.  A/B knob, env PYLC_WG_M16. */
 int pylc_debug_wgrad_m16(int on);
+/* wgrad_pl.hip: 1 = the 16x16x32 form takes its operand tiles by LDS-DMA into two 32 KB LDS stages (no staging registers, no LDS stores,
+ * one barrier per K-step).  Bit-identical to the register-staged form.  A/B knob, env PYLC_WG_DMA. */
+int pylc_debug_wgrad_dma(int on);
 /* wgrad_pl.hip: 1 runs the 128 x 128 f16x3 wgrad with one accumulator set under 128 registers per wave (A/B knob) */
 int pylc_debug_wgrad_acc1(int on);
 /* wgrad_pl.hip: operand staging register sets -- 0: one set, the loads of tile s + 1 fly while tile s is multiplied; 1 (default): two sets

@@ -32,8 +32,15 @@ namespace pylc {
 // 16-byte chunk index XORed by ((row & 3) << 2) | ((row >> 2) & 3): conflict-free for the ds_write_b128 stores and for the transposed
 // reads of a 16 x 16 x 32 operand (a 32-lane half reads two 4-pixel blocks 8 pixels apart in the same 16 channels), 32 KB instead of 40.
 // Same products, summed 32 instead of 16 pixels per instruction: fp32-rounding-level differences from the 32 x 32 x 16 form.
-template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false, int SETS = 1, bool M16 = false>
+//
+// DMA (M16 only): the operand tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane, 1 KB = four 256-byte pixel rows per
+// wave instruction) into TWO LDS stages of 32 KB -- the swizzle is applied on the GLOBAL side (lane = physical chunk, it fetches logical chunk
+// lane ^ swz(row)), which the padded rows of the 32x32x16 image did not allow.  No staging registers, no ds_write_b128 (the LDS's slowest
+// instruction: ~13 cycles per wave, 8 per thread and K-step), one barrier per K-step; tile s + 1 is in flight while tile s is multiplied.
+typedef __attribute__((address_space(3))) void* wg_lds_vptr;
+template <int BN, int BC, int WN, int WC, int NTERMS, int FAST, bool ACC1 = false, int SETS = 1, bool M16 = false, bool DMA = false>
 __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const WgradArgs a) {
+    static_assert(!DMA || (M16 && SETS == 1), "DMA: the 16x16x32 image only");
     constexpr int NPL = NTERMS == 3 ? 2 : 1;
     constexpr int WAVES_C = BC / WC;
     constexpr int NT = WN / 32, CT = WC / 32;
@@ -48,6 +55,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sA = reinterpret_cast<char*>(smem);               // NPL planes of dy
     char* sB = sA + NPL * PLA;                               // NPL planes of gathered x
+    constexpr int STG = NPL * (PLA + PLB);                   // DMA: bytes of one LDS stage (two of them)
 
     const int T = a.TR * a.TS;
     // Rasterisation: taps fastest, then (channel tile, cout tile), split slowest, every XCD a contiguous range.  The blocks resident on an
@@ -91,9 +99,12 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     const int wave_n = wave / WAVES_C, wave_c = wave % WAVES_C;
     const int va = tid % VA, pra = tid / VA;
     const int vb = tid % VB, prb = tid / VB;
+    // DMA: a lane IS a physical 16-byte chunk of its LDS row, so it fetches the logical chunk that the swizzle puts there
+    const int sw_row = ((pra & 3) << 2) | ((pra >> 2) & 3);      // swz(row): rows pra + 16 i share it (M16: VA == VB == 16)
+    const int va_g = DMA ? (va ^ sw_row) : va, vb_g = DMA ? (vb ^ sw_row) : vb;
     const int dh = a.dh0 + (tap / a.TS) * a.dh_step, dw = a.dw0 + (tap % a.TS) * a.dw_step;
-    const bool b_col_ok = c0 + 8 * vb < a.Cin && (B_ALL || prb < 32);          // Cin % 8 == 0
-    const bool a_col_ok = n0 + 8 * va < a.N_ld && (A_ALL || pra < 32);         // N_ld % 8 == 0 (launch_wg_pl)
+    const bool b_col_ok = c0 + 8 * vb_g < a.Cin && (B_ALL || prb < 32);          // Cin % 8 == 0
+    const bool a_col_ok = n0 + 8 * va_g < a.N_ld && (A_ALL || pra < 32);         // N_ld % 8 == 0 (launch_wg_pl)
 
     f32x16 acc[M16 ? 1 : NT][M16 ? 1 : CT];
     constexpr bool TWO_ACC = NTERMS == 3 && !ACC1;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     // of tile s + 1 had one K-step (~3 k cycles with the CU's other block) to come back from L2 / HBM and the step waited for them: PMC
     // showed the matrix pipe busy 0.43 of the kernel's cycles with two 1536-cycle MFMA phases per SIMD and step.
     constexpr int NSET = SETS;
-    uint4 ra[NSET][IA][NPL], rb[NSET][IB][NPL];
+    uint4 ra[NSET][IA][NPL], rb[NSET][IB][NPL];      // (DMA: unused, optimised away)
     int f_mb = m_begin, f_q0 = 0, f_p = 0, f_b = 0;
     unsigned f_va[IA], f_tx[IB];
     int f_wc[IB];
@@ -158,28 +169,37 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         f_p = t % a.P;
         f_b = t / a.P;
 #pragma unroll
-        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch * mdy + colh((unsigned)(n0 + 8 * va), il_dy)) * 2u : OOB;
+        for (int i = 0; i < IA; ++i) f_va[i] = a_col_ok ? ((unsigned)(pra + RA * i) * (unsigned)a.dy_pitch * mdy + colh((unsigned)(n0 + 8 * va_g), il_dy)) * 2u : OOB;
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch * mx + colh((unsigned)(c0 + 8 * vb), il_x)) * 2u;
+            f_tx[i] = ((unsigned)((prb + RB * i) * a.in_sw) * (unsigned)a.x_pitch * mx + colh((unsigned)(c0 + 8 * vb_g), il_x)) * 2u;
             f_wc[i] = (prb + RB * i) * a.in_sw + dw;
         }
     }
-    auto ldp = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, unsigned voff, unsigned soff, uint4 (&dst)[NPL]) {
-        dst[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r0, voff, soff, 0));
-        if constexpr (NPL == 2) dst[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, soff, 0));
+    // DMA: `set` is the LDS stage; a wave's instruction i covers pixel rows 4 wave + 16 i .. + 3 (lane l: row + (l >> 4), physical chunk l & 15)
+    char* dma_a = nullptr; char* dma_b = nullptr;
+    if constexpr (DMA) { dma_a = sA + (4 * wave) * 256; dma_b = sB + (4 * wave) * 256; }
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, unsigned voff, unsigned soff, uint4 (&dst)[NPL], char* lds0, int plb) {
+        if constexpr (DMA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (wg_lds_vptr)lds0, 16, voff, soff, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (wg_lds_vptr)(lds0 + plb), 16, voff, soff, 0, 0);
+        } else {
+            dst[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r0, voff, soff, 0));
+            if constexpr (NPL == 2) dst[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, voff, soff, 0));
+        }
     };
     auto load_tile = [&](auto setc) {
-        constexpr int set = decltype(setc)::value;
-        const unsigned soff = (unsigned)f_mb * (unsigned)a.dy_pitch * 2u * mdy;
+        constexpr int set = DMA ? 0 : decltype(setc)::value;
+        constexpr int stg = DMA ? decltype(setc)::value * STG : 0;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)f_mb * (unsigned)a.dy_pitch * 2u * mdy));
         if constexpr (FAST == 2) {
-            const unsigned colb = colh((unsigned)(c0 + 8 * vb), il_x);
+            const unsigned colb = colh((unsigned)(c0 + 8 * vb_g), il_x);
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const int hi = g_p[i] * a.in_sh + dh, wi = g_q[i] * a.in_sw + dw;
                 const bool ok = b_col_ok & (f_mb + prb + RB * i < m_end) & ((unsigned)hi < (unsigned)a.IH) & ((unsigned)wi < (unsigned)a.IW);
                 const unsigned off = (((unsigned)(g_b[i] * a.IH + hi) * (unsigned)a.IW + (unsigned)wi) * (unsigned)a.x_pitch * mx + colb) * 2u;
-                ldp(rx0, rx1, ok ? off : OOB, 0u, rb[set][i]);
+                ldp(rx0, rx1, ok ? off : OOB, 0u, rb[set][i], dma_b + stg + RB * i * 256, PLB);
                 g_q[i] += 32;
                 while (g_q[i] >= a.Q) { g_q[i] -= a.Q; ++g_p[i]; }
                 while (g_p[i] >= a.P) { g_p[i] -= a.P; ++g_b[i]; }
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 const bool ok = f_mb + pra + RA * i < m_end;
-                ldp(rdy0, rdy1, ok ? f_va[i] : OOB, soff, ra[set][i]);
+                ldp(rdy0, rdy1, ok ? f_va[i] : OOB, soff, ra[set][i], dma_a + stg + RA * i * 256, PLA);
             }
             f_mb += 32;
             return;
@@ -200,10 +220,10 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const bool ok = row_ok & ((unsigned)(f_wc[i] + wq) < (unsigned)a.IW);
-            ldp(rx0, rx1, ok ? f_tx[i] + delta : OOB, 0u, rb[set][i]);
+            ldp(rx0, rx1, ok ? f_tx[i] + delta : OOB, 0u, rb[set][i], dma_b + stg + RB * i * 256, PLB);
         }
 #pragma unroll
-        for (int i = 0; i < IA; ++i) ldp(rdy0, rdy1, f_va[i], soff, ra[set][i]);
+        for (int i = 0; i < IA; ++i) ldp(rdy0, rdy1, f_va[i], soff, ra[set][i], dma_a + stg + RA * i * 256, PLA);
         f_mb += 32;
         f_q0 += 32;
         if (f_q0 == a.Q) {
@@ -257,19 +277,20 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + ((o + 1024) ^ 16)));
         return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    auto compute_tile16 = [&]() {
+    auto compute_tile16 = [&](auto stgc) {
+        constexpr int so = decltype(stgc)::value * STG;      // DMA: the LDS stage; 0 otherwise
         // the dy fragments of the wave's four 16-row tiles stay; the x fragments come one 16-channel tile at a time (40 fragment registers
         // live instead of 64); within a tile the terms run term-major, four independent products between two that share an accumulator
         f16x8 fa[4][NPL];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fa[t][pl] = tr16(sA + pl * PLA, m16_a0, t);
+            for (int pl = 0; pl < NPL; ++pl) fa[t][pl] = tr16(sA + so + pl * PLA, m16_a0, t);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f16x8 fb[NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fb[pl] = tr16(sB + pl * PLB, m16_b0, j);
+            for (int pl = 0; pl < NPL; ++pl) fb[pl] = tr16(sB + so + pl * PLB, m16_b0, j);
             if constexpr (NTERMS == 3) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][NPL - 1], fb[0], acc16_lo[i][j], 0, 0, 0);
@@ -280,8 +301,36 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
             for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[0], acc16[i][j], 0, 0, 0);
         }
     };
+    // DMA form of a K-step: ALL fragment reads of tile s first, then the DMA of tile s + 1, then the 48 products.  hipcc orders an LDS read
+    // behind every LDS-DMA issued before it in program order (s_waitcnt vmcnt(0): it cannot tell the stages apart, seen in the listing), so
+    // the DMA goes after the step's last LDS read; the next read is behind the next barrier, where the tile is waited for anyway.
+    auto step_dma = [&](auto stgc, auto issue) {
+        constexpr int so = decltype(stgc)::value * STG;
+        f16x8 fa[4][NPL], fb[4][NPL];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                fa[t][pl] = tr16(sA + so + pl * PLA, m16_a0, t);
+                fb[t][pl] = tr16(sB + so + pl * PLB, m16_b0, t);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (NTERMS == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][NPL - 1], fb[j][0], acc16_lo[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[j][NPL - 1], acc16_lo[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[j][0], acc16[i][j], 0, 0, 0);
+        }
+    };
     auto compute_tile = [&]() {
-        if constexpr (M16) { compute_tile16(); return; }
+        if constexpr (M16) { compute_tile16(std::integral_constant<int, 0>{}); return; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[NT][NPL], fb[CT][NPL];
@@ -345,6 +394,23 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         if (NSET == 2 || s + 1 < S) load_tile(setc);
         compute_tile();
     };
+    if constexpr (DMA) {
+        // two LDS stages, ONE barrier per K-step: __syncthreads() = s_waitcnt vmcnt(0) (this wave's share of tile s has landed) + s_barrier
+        // (every wave's has, and every wave is done reading the stage tile s + 1 is about to overwrite).  Every DMA issued is waited for by a
+        // later barrier: none is in flight when the block ends (its LDS may belong to the next block by then).
+        typedef std::integral_constant<int, 1> Stg1;
+        if (S > 0) {
+            load_tile(Set0{});
+            for (int s = 0; s < S; s += 2) {
+                __syncthreads();
+                step_dma(Set0{}, [&] { if (s + 1 < S) load_tile(Stg1{}); });
+                if (s + 1 < S) {
+                    __syncthreads();
+                    step_dma(Stg1{}, [&] { if (s + 2 < S) load_tile(Set0{}); });
+                }
+            }
+        }
+    } else
     if (S > 0) {
         int s = 0;
         load_tile(Set0{});
@@ -419,6 +485,8 @@ extern "C" int pylc_debug_wgrad_flags(int flags) { g_wg_flags = flags; return PY
 // when every f16x3 wgrad takes it and neutral for the 1x1 filters alone -- the cheaper matrix instructions leave power to the dgrads beside them.
 int g_wg_m16 = 2;         // 128 x 128 f16x3 wgrad on 16 x 16 x 32 MFMAs: 0 never, 1 single-tap filters, 2 always (pylc_debug_wgrad_m16)
 extern "C" int pylc_debug_wgrad_m16(int on) { g_wg_m16 = on; return PYLC_OK; }
+int g_wg_dma = 1;         // 1: the 16x16x32 form takes its tiles by LDS-DMA into two LDS stages (pylc_debug_wgrad_dma)
+extern "C" int pylc_debug_wgrad_dma(int on) { g_wg_dma = on; return PYLC_OK; }
 int g_wg_sets = 1;        // staging register sets policy (pylc_debug_wgrad_sets)
 extern "C" int pylc_debug_wgrad_sets(int mode) { g_wg_sets = mode; return PYLC_OK; }
 int g_wg_acc1 = 0;        // 1: the 128 x 128 f16x3 wgrad runs its one-accumulator, <= 128-register form (pylc_debug_wgrad_acc1)
@@ -440,9 +508,23 @@ static int launch_cfg(const WgradArgs& a, long long grid, hipStream_t st) {
     // two staging sets (loads two tiles ahead): pylc_debug_wgrad_sets -- 0 never, 1 multi-tap filters only, 2 always
     const bool two = g_wg_sets == 2 || (g_wg_sets == 1 && a.TR * a.TS > 1);
     if constexpr (BN == 128 && BC == 128) {
-        // f16x3 only: the one-plane instantiations (precision mode 3) are 5-28 % slower in this form (profiles/r05_wgrad_m16.txt)
+        if (a.nterms == 1 && g_wg_m16 && g_wg_dma) {
+            // one plane (precision mode 3): register-staged, this form is 5-28 % slower than the 32x32x16 one (profiles/r05_wgrad_m16.txt);
+            // with LDS-DMA it is the faster one
+            constexpr size_t lds = 2 * 2 * 32 * 256;
+            if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1, false, 1, true, true>), g, b, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2, false, 1, true, true>), g, b, lds, st, a);
+            PYLC_LAUNCH_CHECK();
+            return PYLC_OK;
+        }
         if (a.nterms == 3 && (g_wg_m16 == 2 || (g_wg_m16 == 1 && a.TR * a.TS == 1))) {
             constexpr size_t lds = 4 * 32 * 256;
+            if (g_wg_dma) {
+                if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, false, 1, true, true>), g, b, 2 * lds, st, a);
+                else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, false, 1, true, true>), g, b, 2 * lds, st, a);
+                PYLC_LAUNCH_CHECK();
+                return PYLC_OK;
+            }
             // (two staging sets do not fit beside the 40 fragment registers of this form: 256 VGPRs and spills -- one set)
             if (fast == 1) hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 1, false, 1, true>), g, b, lds, st, a);
             else hipLaunchKernelGGL((wgrad_pl_kernel<BN, BC, WN, WC, 3, 2, false, 1, true>), g, b, lds, st, a);
@@ -499,6 +581,8 @@ int wgrad_pl_init() {
     PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 1, 1, false, 2>), wgpl_smem<BN, BC, 1>()));      \
     PYLC_HIP(opt_in((wgrad_pl_kernel<BN, BC, WN, WC, 1, 2, false, 2>), wgpl_smem<BN, BC, 1>()));
     PYLC_OPT(128, 128, 64, 64)
+    PYLC_HIP(opt_in((wgrad_pl_kernel<128, 128, 64, 64, 3, 1, false, 1, true, true>), 2 * 4 * 32 * 256));
+    PYLC_HIP(opt_in((wgrad_pl_kernel<128, 128, 64, 64, 3, 2, false, 1, true, true>), 2 * 4 * 32 * 256));
     PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 1, true>, kAcc1LdsReserve));
     PYLC_HIP(opt_in(wgrad_pl_kernel<128, 128, 64, 64, 3, 2, true>, kAcc1LdsReserve));
     PYLC_OPT(64, 64, 32, 32)

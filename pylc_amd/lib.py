@@ -95,6 +95,7 @@ SIGNATURES = {
     'pylc_debug_wgrad_acc1': (_I, [_I]),
     'pylc_debug_wgrad_sets': (_I, [_I]),
     'pylc_debug_wgrad_m16': (_I, [_I]),
+    'pylc_debug_wgrad_dma': (_I, [_I]),
     'pylc_debug_pp_stamps': (_I, [_P]),
     'pylc_amax': (_I, [_P, _LL, _I, _I, _P, _P]),
     'pylc_amax_segments': (_I, [_P, _P, _I, _P, _P]),
@@ -259,6 +260,8 @@ def init():
             lib.pylc_debug_wgrad_sets(int(os.environ['PYLC_WG_SETS']))
         if os.environ.get('PYLC_WG_M16') is not None:             # 128 x 128 wgrad on 16 x 16 x 32 MFMAs (A/B)
             lib.pylc_debug_wgrad_m16(int(os.environ['PYLC_WG_M16']))
+        if os.environ.get('PYLC_WG_DMA') is not None:             # 16x16x32 wgrad tiles by LDS-DMA (A/B)
+            lib.pylc_debug_wgrad_dma(int(os.environ['PYLC_WG_DMA']))
         if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)
             lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
         if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)

@@ -22,6 +22,9 @@ def _padded_stem_filter(w, cin):
     return w_k
 
 
+_last_wgrad_ev = {}      # device -> event behind the latest side-stream wgrad (runtime.wgrad_gate)
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
@@ -174,6 +177,12 @@ class Conv2dFn(torch.autograd.Function):
         st = stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            if _runtime.wgrad_gate:
+                # gated overlap (PYLC_WGRAD_GATE=1): this dgrad starts only when the previous layer's wgrad is done, so that a wgrad shares
+                # the chip with the (HBM-bound) BatchNorm backward between two dgrads and never with a matrix-bound dgrad
+                e = _last_wgrad_ev.pop(x.device, None)
+                if e is not None:
+                    torch.cuda.current_stream().wait_event(e)
             kp = _r4(cout)
             link = ctx.res_link
             masked = None
@@ -248,7 +257,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # wgrad is off the critical chain (only the optimiser needs it), so it runs on a side stream: the matrix-bound
             # wgrad kernels then overlap the HBM-bound BatchNorm-backward kernels of the layers that follow on the main stream
-            side = _side_stream(x.device) if _runtime.wgrad_side_stream else None
+            side = _side_stream(x.device) if _runtime.side_stream_on() else None
             # PYLC_WGRAD_1X1_MAIN (A/B knob): 1x1 wgrads move as many bytes per FLOP as the BatchNorm passes they would run beside; 1 keeps
             # all of them on the compute stream, 2 only those of maps with at most 32768 pixels (layer3 / layer4 / ASPP)
             if side is not None and r * s == 1 and _runtime.wgrad_1x1_main and (_runtime.wgrad_1x1_main == 1 or x.shape[0] * x.shape[2] * x.shape[3] <= 32768):
@@ -274,6 +283,10 @@ class Conv2dFn(torch.autograd.Function):
                         check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, sst))
                         dwl = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
                         dwl.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
+                    if side is not None and _runtime.wgrad_gate:
+                        e = torch.cuda.Event()
+                        e.record()
+                        _last_wgrad_ev[x.device] = e
                 if side is not None and tgt is None:
                     torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
                 return _deliver_grad(w, dwl)

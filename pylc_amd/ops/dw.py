@@ -22,7 +22,7 @@ class _wgrad_stream:
 
     def __init__(self, device, tgt, *reads):
         self.side = None
-        if tgt is not None and _runtime.wgrad_side_stream and not os.environ.get('PYLC_DW_WGRAD_MAIN'):
+        if tgt is not None and _runtime.side_stream_on() and not os.environ.get('PYLC_DW_WGRAD_MAIN'):
             self.side = _side_stream(device)
             ev = torch.cuda.Event()
             ev.record()

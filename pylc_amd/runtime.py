@@ -6,6 +6,13 @@ import os
 
 
 class _Runtime:
+    def side_stream_on(self):
+        """Whether wgrad kernels go to the side stream (see wgrad_side_stream)."""
+        if self.wgrad_side_stream is None:
+            from .lib import lib
+            return lib.pylc_get_conv_precision() == 3
+        return bool(self.wgrad_side_stream)
+
     def __init__(self):
         self.sync_group = None        # torch.distributed group for SyncBN / loss statistics (None = single GPU)
         # SyncBN on (default): every BatchNorm all-reduces [sum, sumsq, n] forward and [sum g, sum g xhat] backward, so N ranks compute
@@ -25,8 +32,12 @@ class _Runtime:
         self.wgrad_hold = os.environ.get('PYLC_WGRAD_HOLD', '1') != '0'
         self.grad_group = None        # separate RCCL communicator for the bucketed gradient all-reduce
         self.grad_ready = None        # callable(param) invoked when a parameter gradient has been enqueued (GradBucketer.ready)
-        # run conv wgrad kernels on a second HIP stream (overlaps BN backward); PYLC_NO_SIDE_STREAM=1 keeps one queue (profiling)
-        self.wgrad_side_stream = not os.environ.get('PYLC_NO_SIDE_STREAM')
+        # conv wgrad kernels on a second HIP stream (they then share the chip with the BatchNorm-backward and dgrad kernels that follow on the
+        # main stream).  None = by precision mode (`side_stream_on()`): OFF for f16x3 since the wgrad takes its tiles by LDS-DMA (round 5: the
+        # kernel is 25 % faster ALONE and no faster beside other kernels -- one queue: R101 +0.9 %, U-Net +0.8 %; DESIGN.md 5.2 i), ON for
+        # precision mode 3, whose main queue is short kernels that a second queue fills the gaps of (one queue: -4 %).
+        # PYLC_NO_SIDE_STREAM=1 / PYLC_SIDE_STREAM=1 force it.
+        self.wgrad_side_stream = False if os.environ.get('PYLC_NO_SIDE_STREAM') else (True if os.environ.get('PYLC_SIDE_STREAM') else None)
         # confine the wgrad side stream to this many compute units (0 = all 256): PYLC_WGRAD_CUS, a multiple of 8 (A/B knob)
         # (experimental: needs a library built with EXPERIMENTAL=1 -- pylc_stream_create_cu_mask)
         self.wgrad_cus = int(os.environ.get('PYLC_WGRAD_CUS', '0'))
@@ -48,6 +59,8 @@ class _Runtime:
         # the ASPP's image pool reads the backbone output as the fp16 planes it is (pylc_gap_fwd_planes) instead of converting it first, and the
         # Xception stem / exit BatchNorms write planes for the convs behind them (PYLC_NO_GAP_PLANES=1: the round-2 forms, A/B knob)
         self.gap_planes = not os.environ.get('PYLC_NO_GAP_PLANES')
+        # PYLC_WGRAD_GATE=1: every conv dgrad waits for the previous layer's side-stream wgrad (A/B knob; ops.Conv2dFn.backward)
+        self.wgrad_gate = os.environ.get('PYLC_WGRAD_GATE', '0') == '1'
         self.wgrad_1x1_main = int(os.environ.get('PYLC_WGRAD_1X1_MAIN', '0'))      # see ops.Conv2dFn.backward (A/B knob)
         # PYLC_FUSE_BN_SUMS=1: a conv dgrad that writes the complete gradient of a BatchNorm output takes that BatchNorm's backward sums in its
         # epilogue (pylc_conv2d_dgrad_bn) and the BatchNorm skips its reduction pass.  Built, tested, measured NEGATIVE (the dgrad epilogue is the

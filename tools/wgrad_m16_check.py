@@ -32,8 +32,9 @@ for (B, H, W, cin, cout, k, pad, dil) in SHAPES:
     nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
     ws = torch.empty(max(nbytes, 4) // 4 + 1, device=dev)
     out, times = [], []
-    for m16 in (0, 1):
+    for m16, dma in ((0, 0), (2, 0), (2, 1)):
         lib.pylc_debug_wgrad_m16(m16)
+        lib.pylc_debug_wgrad_dma(dma)
         dw = torch.zeros((cout, k, k, cin), device=dev)
         check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(xp), ptr(dyp), ptr(dw), None, ptr(ws), nbytes, stream()))
         torch.cuda.synchronize()
@@ -44,13 +45,17 @@ for (B, H, W, cin, cout, k, pad, dil) in SHAPES:
         b.record(); torch.cuda.synchronize()
         out.append(dw); times.append(a.elapsed_time(b) / reps)
     lib.pylc_debug_wgrad_m16(0)
+    lib.pylc_debug_wgrad_dma(0)
     ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride=1, padding=pad, dilation=dil) if B * H * W <= 4096 else None
     scale = out[0].abs().max().item()
     diff = (out[0] - out[1]).abs().max().item() / scale
     worst = max(worst, diff)
     fl = 2.0 * B * H * W * cout * cin * k * k
-    line = '%-44s 32x32x16 %8.1f us %6.1f TF/s | 16x16x32 %8.1f us %6.1f TF/s | max |diff| / max|dw| %.2e' % (
-        str((B, H, W, cin, cout, k, dil)), 1e3 * times[0], fl / times[0] / 1e9, 1e3 * times[1], fl / times[1] / 1e9, diff)
+    same = torch.equal(out[1], out[2])
+    worst = max(worst, 0.0 if same else 1.0)
+    line = '%-44s 32x32x16 %8.1f us %6.1f TF/s | 16x16x32 %8.1f us %6.1f TF/s | + LDS-DMA %8.1f us %6.1f TF/s (%s) | max |diff| / max|dw| %.2e' % (
+        str((B, H, W, cin, cout, k, dil)), 1e3 * times[0], fl / times[0] / 1e9, 1e3 * times[1], fl / times[1] / 1e9,
+        1e3 * times[2], fl / times[2] / 1e9, 'bit-identical' if same else 'DIFFERENT', diff)
     if ref is not None:
         r = ref.permute(0, 2, 3, 1)
         line += ' | vs fp64: %.2e / %.2e' % ((out[0].double() - r).abs().max().item() / scale, (out[1].double() - r).abs().max().item() / scale)
