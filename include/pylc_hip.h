@@ -261,6 +261,23 @@ size_t pylc_conv2d_wgrad_workspace(const PylcConvDesc* d);
 int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const float* dy, float* dw_krsc,
                       float* dbias /* must be NULL: take sums[0:C] of pylc_bn_stats(dy) */,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same wgrad WITHOUT its split-K slab sum: the slabs stay in `workspace` (which must then outlive the call until the sum has run) and
+ * `*pending` describes the sum -- splits == 0: dw is already complete (a single split).  pylc_splitk_reduce_batch sums the slabs of many
+ * wgrads in ONE launch (table and tile prefix in device memory: tile_prefix[e] = sum over entries before e of ceil(n4 / 32), n + 1 values;
+ * total_tiles = tile_prefix[n]); per element the association is that of pylc_conv2d_wgrad's own sum, so the results are bit-identical.
+ * Why: one queue runs ~1100 kernels per training step and every dependent launch costs 2-3 us on top of the kernel (DESIGN.md 5.2 i);
+ * the reference's optimiser (train.py:93-99) needs the gradients only after the whole backward pass. */
+typedef struct PylcSlabSum {
+    const float* slabs;       /* [splits][slab_stride] floats */
+    float* dw;                /* n4 float4 columns */
+    long long n4;
+    long long slab_stride;    /* floats */
+    int splits;
+    int reserved;
+} PylcSlabSum;
+int pylc_conv2d_wgrad_slabs(const PylcConvDesc* d, const float* x, const float* dy, float* dw_krsc, void* workspace, size_t workspace_bytes,
+                            PylcSlabSum* pending, void* stream);
+int pylc_splitk_reduce_batch(const PylcSlabSum* table_dev, const long long* tile_prefix_dev, int n, long long total_tiles, void* stream);
 /* [K][R*S][C] -> [C][R*S][Kp], Kp = roundup4(K), zero-filled pad columns */
 int pylc_weight_transpose(const float* w_krsc, float* w_crsk, int K, int RS, int C, void* stream);
 

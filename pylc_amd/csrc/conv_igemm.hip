@@ -2060,8 +2060,64 @@ static int launch_wg(WgradArgs& a, long long grid, hipStream_t st) {
     return PYLC_OK;
 }
 
+// The split-K slab sums of MANY wgrads in one launch (pylc_splitk_reduce_batch): tile t of the launch is 32 float4 columns of the entry whose
+// tile range [tile_prefix[e], tile_prefix[e + 1]) holds t; per column the arithmetic is splitk_reduce_kernel's (same association: bit-identical).
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const PylcSlabSum* __restrict__ tab, const long long* __restrict__ tile_prefix, int n,
+                                                                  long long total_tiles) {
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        int lo = 0, hi = n;                     // largest e with tile_prefix[e] <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tile_prefix[mid] <= t) lo = mid; else hi = mid;
+        }
+        const PylcSlabSum e = tab[lo];
+        const long long i = (t - tile_prefix[lo]) * 32 + col;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < e.n4)
+            for (int k = sl; k < e.splits; k += 4 * 8) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(e.slabs + (size_t)(k + 8 * u < e.splits ? k + 8 * u : k) * e.slab_stride + 4 * i);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { if (k + 8 * u < e.splits) s += v[u]; }
+            }
+        red[sl][col] = s;
+        __syncthreads();
+        if (sl == 0 && i < e.n4) {
+#pragma unroll
+            for (int j = 1; j < 8; ++j) s += red[j][col];
+            *reinterpret_cast<f32x4*>(e.dw + 4 * i) = s;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pylc_splitk_reduce_batch(const PylcSlabSum* table_dev, const long long* tile_prefix_dev, int n, long long total_tiles, void* stream) {
+    PYLC_REQUIRE(table_dev && tile_prefix_dev && n > 0 && total_tiles > 0, "splitk_reduce_batch: bad arguments");
+    const int blocks = (int)(total_tiles < 4096 ? total_tiles : 4096);
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table_dev, tile_prefix_dev, n, total_tiles);
+    PYLC_LAUNCH_CHECK();
+    return PYLC_OK;
+}
+
+static int wgrad_impl(const PylcConvDesc* d, const float* x, const float* dy, float* dw, float* dbias,
+                      void* workspace, size_t workspace_bytes, PylcSlabSum* pending, void* stream);
+
 extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const float* dy, float* dw, float* dbias,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int pylc_conv2d_wgrad_slabs(const PylcConvDesc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                       PylcSlabSum* pending, void* stream) {
+    PYLC_REQUIRE(pending != nullptr, "conv2d_wgrad_slabs: null `pending`");
+    return wgrad_impl(d, x, dy, dw, nullptr, workspace, workspace_bytes, pending, stream);
+}
+
+static int wgrad_impl(const PylcConvDesc* d, const float* x, const float* dy, float* dw, float* dbias,
+                      void* workspace, size_t workspace_bytes, PylcSlabSum* pending, void* stream) {
     if (int rc = check_desc(d)) return rc;
     PYLC_REQUIRE(x && dy && dw, "null pointer");
     PYLC_REQUIRE(dbias == nullptr, "dbias: use pylc_bn_stats on dy (column sums)");
@@ -2107,6 +2163,10 @@ extern "C" int pylc_conv2d_wgrad(const PylcConvDesc* d, const float* x, const fl
         default: rc = launch_wg<64, 64, 32, 32, true>(a, grid, st); break;
     }
     if (rc) return rc;
+    if (pending != nullptr) {          // the caller sums the slabs later (pylc_splitk_reduce_batch); splits 0 = dw is complete
+        *pending = PylcSlabSum{p.splits > 1 ? static_cast<const float*>(workspace) : nullptr, dw, p.slab / 4, p.slab, p.splits > 1 ? p.splits : 0, 0};
+        return PYLC_OK;
+    }
     if (p.splits > 1) {
         const long long n4 = p.slab / 4;
         const int blocks = (int)(cdiv<long long>(n4, 32) < 4096 ? cdiv<long long>(n4, 32) : 4096);

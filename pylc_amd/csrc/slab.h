@@ -12,8 +12,10 @@ constexpr int kDefaultSlabs = 1024;   // dwconv.hip's strip kernels
 // Blocks per launch of the row-slab kernels (BatchNorm, ReLU, dropout).  With one row per iteration 1024 (4 blocks per CU) was
 // best (512 cost 10-25 %); with the batched row walks (walk_rows) a wave keeps 8-12 loads in flight and 768 = three blocks per CU
 // wins inside the training step: 344-345 vs 336-337 tiles/s on one box (640: 342, 896: 340, 1536 / 2048: 335).
+// Round 5, one queue (wgrad no longer beside these kernels): 512 = two blocks per CU -- R101 +0.1 .. +0.35 % by box, U-Net +0.6 %, configs[4]
+// +1.1 %; 256 / 384 / 640 lose 0.5-1 %, 1024 and 1536 2.3-2.8 % (profiles/r05_ab_runs.txt).
 // PYLC_MAX_SLABS overrides for A/B runs.
-constexpr int kRowSlabs = 768;
+constexpr int kRowSlabs = 512;
 inline int slab_limit() {
     static const int v = [] {
         const char* e = getenv("PYLC_MAX_SLABS");

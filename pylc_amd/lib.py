@@ -33,6 +33,11 @@ class WPrepEntry(C.Structure):
                 ('tile_begin', C.c_longlong), ('K', C.c_int), ('RS', C.c_int), ('C', C.c_int), ('amax_index', C.c_int)]
 
 
+class SlabSum(C.Structure):
+    """PylcSlabSum: one pending split-K slab sum (pylc_conv2d_wgrad_slabs -> pylc_splitk_reduce_batch)."""
+    _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p), ('n4', C.c_longlong), ('slab_stride', C.c_longlong), ('splits', C.c_int), ('reserved', C.c_int)]
+
+
 class BnExtra(C.Structure):
     """PylcBnExtra: fp16-plane operands / fused dropout of the BatchNorm *_ex entry points."""
     _fields_ = [('out_planes', C.c_void_p), ('out_plane_stride', C.c_longlong), ('out_bound', C.c_void_p),
@@ -118,6 +123,8 @@ SIGNATURES = {
     'pylc_bn_bwd_sums_from_partial': (_I, [_P, _I, _I, _P, _P, _P, _D, _P, _P, _P]),
     'pylc_conv2d_wgrad_workspace': (_SZ, [C.POINTER(ConvDesc)]),
     'pylc_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _SZ, _P]),
+    'pylc_conv2d_wgrad_slabs': (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _SZ, C.POINTER(SlabSum), _P]),
+    'pylc_splitk_reduce_batch': (_I, [_P, _P, _I, C.c_longlong, _P]),
     'pylc_weight_transpose': (_I, [_P, _P, _I, _I, _I, _P]),
     'pylc_dwconv3x3_fwd': (_I, [C.POINTER(DwDesc), _P, _P, _P, _P]),
     'pylc_dwconv3x3_fwd_stats_rows': (_I, [C.POINTER(DwDesc)]),

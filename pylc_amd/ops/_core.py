@@ -454,11 +454,45 @@ def _keep_for_side(device, *tensors):
         sync_side_streams()
 
 
+_pending_slab_sums = {}      # device index -> [bytes of a PylcSlabSum, ...] of this backward pass
+_slab_tables = {}            # device index -> (key bytes, table tensor, prefix tensor, n, total tiles): re-used while the entries repeat
+
+
+def add_slab_sum(device, entry):
+    """A wgrad left its split-K slabs in its weight's own workspace (ops.conv, runtime.batch_slab_sums): note the sum for flush_slab_sums()."""
+    _pending_slab_sums.setdefault(torch.device(device).index, []).append(bytes(entry))
+
+
+def flush_slab_sums(device=None):
+    """ONE launch that sums the split-K slabs of every wgrad since the last flush (pylc_splitk_reduce_batch), on the current stream.  The
+    table lives in device memory and is re-used while the same layers run with the same buffers (every training step after the first)."""
+    for idx in ([torch.device(device).index] if device is not None else list(_pending_slab_sums)):
+        pend = _pending_slab_sums.get(idx)
+        if not pend:
+            continue
+        key = b''.join(pend)
+        pend.clear()
+        cached = _slab_tables.get(idx)
+        if cached is None or cached[0] != key:
+            n = len(key) // C.sizeof(L.SlabSum)
+            ents = (L.SlabSum * n).from_buffer_copy(key)
+            prefix = [0]
+            for e in ents:
+                prefix.append(prefix[-1] + (e.n4 + 31) // 32)
+            dev = torch.device('cuda', idx)
+            tab = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(dev)
+            pre = torch.tensor(prefix, dtype=torch.int64).to(dev)
+            cached = _slab_tables[idx] = (key, tab, pre, n, prefix[-1])
+        with torch.cuda.device(idx):
+            check(lib.pylc_splitk_reduce_batch(ptr(cached[1]), ptr(cached[2]), cached[3], cached[4], stream()))
+
+
 def sync_side_streams():
     """Make the current stream wait for everything queued on the wgrad side stream (before the optimiser / a gradient
-    all-reduce reads the arena), then release the tensors kept alive for it."""
+    all-reduce reads the arena), then release the tensors kept alive for it.  Also where the deferred split-K slab sums run."""
     for idx in list(_deferred_wgrad):
         flush_deferred_wgrad(torch.device('cuda', idx), everything=True)
+    flush_slab_sums()
     for st in _side_streams.values():
         torch.cuda.current_stream().wait_stream(st)
     for keep in _side_keep.values():

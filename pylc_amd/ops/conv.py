@@ -275,7 +275,18 @@ class Conv2dFn(torch.autograd.Function):
                     sst = stream()
                     nbytes = lib.pylc_conv2d_wgrad_workspace(C.byref(d))
                     ws = _ws(nbytes, x.device)
-                    if cin_w % 4 == 0:
+                    if cin_w % 4 == 0 and tgt is not None and side is None and _runtime.batch_slab_sums and nbytes > 0:
+                        # one queue: the split-K slabs stay in this weight's OWN workspace and every layer's slab sum runs in one launch
+                        # before the gradients are read (ops.flush_slab_sums, from sync_side_streams / the gradient bucketer)
+                        own = getattr(w, '_pylc_slab_ws', None)
+                        if own is None or own.numel() * 4 < nbytes or own.device != x.device:
+                            own = w._pylc_slab_ws = torch.empty(nbytes // 4 + 1, device=x.device)
+                        dwl = tgt
+                        pend = L.SlabSum()
+                        check(lib.pylc_conv2d_wgrad_slabs(C.byref(d), ptr(x), ptr(dy), ptr(dwl), ptr(own), nbytes, C.byref(pend), sst))
+                        if pend.splits > 0:
+                            _core.add_slab_sum(x.device, pend)
+                    elif cin_w % 4 == 0:
                         dwl = tgt if tgt is not None else torch.empty((cout, r, s, cin), device=x.device).permute(0, 3, 1, 2)
                         check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dwl), None, ptr(ws), nbytes, sst))
                     else:

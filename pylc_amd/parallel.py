@@ -174,6 +174,8 @@ class GradBucketer:
         # The bucket holds conv gradients written on the wgrad side stream and BatchNorm gradients written on the compute stream; the
         # collective must be ordered after BOTH, and neither producer stream may wait for it.
         from . import ops
+        if self.arena.g.is_cuda:
+            ops.flush_slab_sums(self.arena.g.device)        # conv gradients whose split-K slabs are still to be summed (one queue)
         side = ops.side_stream_if_any(self.arena.g.device)
         native = runtime.grad_comm is not None and self.arena.g.is_cuda
         if native:

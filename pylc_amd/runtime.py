@@ -59,6 +59,9 @@ class _Runtime:
         # the ASPP's image pool reads the backbone output as the fp16 planes it is (pylc_gap_fwd_planes) instead of converting it first, and the
         # Xception stem / exit BatchNorms write planes for the convs behind them (PYLC_NO_GAP_PLANES=1: the round-2 forms, A/B knob)
         self.gap_planes = not os.environ.get('PYLC_NO_GAP_PLANES')
+        # one queue: the split-K slab sums of all wgrads of a backward pass run as ONE launch before the gradients are read
+        # (ops.flush_slab_sums); PYLC_NO_BATCH_SLAB_SUMS=1: one sum behind every wgrad (A/B knob)
+        self.batch_slab_sums = not os.environ.get('PYLC_NO_BATCH_SLAB_SUMS')
         # PYLC_WGRAD_GATE=1: every conv dgrad waits for the previous layer's side-stream wgrad (A/B knob; ops.Conv2dFn.backward)
         self.wgrad_gate = os.environ.get('PYLC_WGRAD_GATE', '0') == '1'
         self.wgrad_1x1_main = int(os.environ.get('PYLC_WGRAD_1X1_MAIN', '0'))      # see ops.Conv2dFn.backward (A/B knob)

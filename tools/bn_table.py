@@ -17,7 +17,10 @@ meta, b, ch, hw, ncls, prec = {'c3': (Meta(report=10**9), 32, 3, 512, 9, 2),
                                'c5': (Meta(backbone='xception', ch=1, n_classes=11, report=10**9), 8, 1, 1024, 11, 3)}[cfg]
 from pylc_amd import lib as L
 L.init()
-runtime.wgrad_side_stream = not os.environ.get('PYLC_SERIAL')
+if os.environ.get('PYLC_SERIAL'):          # wgrad on the compute stream (un-overlapped kernel times); the product's default for f16x3 since round 5
+    runtime.wgrad_side_stream = False
+elif os.environ.get('PYLC_SIDE'):          # wgrad on the side stream (the schedule of rounds 1-5)
+    runtime.wgrad_side_stream = True
 check(lib.pylc_set_conv_precision(prec))
 model = Model(meta, dev).build()
 x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (b, ch, hw, hw)).astype(np.float32)).to(dev)

@@ -27,7 +27,10 @@ class Shim:
 for _m in (ops._core, ops.conv, ops.bn, ops.dw, ops.misc):
     _m.lib = Shim()
 from pylc_amd.runtime import runtime
-runtime.wgrad_side_stream = not os.environ.get('PYLC_SERIAL')      # PYLC_SERIAL=1: wgrad on the main stream (un-overlapped kernel times)
+if os.environ.get('PYLC_SERIAL'):          # wgrad on the compute stream (un-overlapped kernel times); the product's default for f16x3 since round 5
+    runtime.wgrad_side_stream = False
+elif os.environ.get('PYLC_SIDE'):          # wgrad on the side stream (the schedule of rounds 1-5)
+    runtime.wgrad_side_stream = True
 dev = torch.device('cuda:0')
 if os.environ.get('PYLC_TABLE_CFG') == 'c2':        # BASELINE configs[1]: U-Net, bs 16, CE only
     model = Model(Meta(arch='unet', ce_weight=1.0, dice_weight=0.0, focal_weight=0.0, report=10**9), dev).build()
