@@ -432,6 +432,36 @@ def test_wgrad_16x16x32_form_matches_32x32x16_form(dev, f16x3, case):
     assert e2 < max(3e-6, 1.2 * e0)
 
 
+def test_batched_slab_sums_are_bit_identical(dev, f16x3):
+    """One queue: the split-K slabs of every wgrad of a backward pass stay in their weights' own workspaces and ONE launch sums them all
+    (pylc_conv2d_wgrad_slabs + pylc_splitk_reduce_batch, ops.flush_slab_sums from ops.sync_side_streams) -- the gradients must be the bits
+    of the per-layer sums (pylc_conv2d_wgrad), for several layers per pass and over repeated passes (cached table)."""
+    from pylc_amd import ops, layers, optim, runtime
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(layers.Conv2d(64, 128, 3, 1, 1, 1), layers.Conv2d(128, 128, 1, 1, 0, 1), layers.Conv2d(128, 72, 3, 1, 2, 2)).to(dev)
+    arena = optim.FlatArena(net)
+    x = nhwc(rnd(5, 8, 64, 48, 48, scale=2.0), dev)
+    grads = {}
+    prev_side, prev_batch = runtime.wgrad_side_stream, runtime.batch_slab_sums
+    try:
+        runtime.wgrad_side_stream = False
+        for batch in (False, True, True):
+            runtime.batch_slab_sums = batch
+            arena.g.zero_()
+            y = net(x)
+            y.backward(nhwc(rnd(6, *y.shape), dev))
+            if batch:
+                assert ops._core._pending_slab_sums.get(dev.index), 'no wgrad of this pass left its slabs for the batched sum'
+            ops.sync_side_streams()
+            assert not ops._core._pending_slab_sums.get(dev.index)
+            torch.cuda.synchronize()
+            grads.setdefault(batch, []).append(arena.g.clone())
+    finally:
+        runtime.wgrad_side_stream, runtime.batch_slab_sums = prev_side, prev_batch
+    assert float(grads[False][0].abs().max()) > 0
+    assert torch.equal(grads[False][0], grads[True][0]) and torch.equal(grads[True][0], grads[True][1])
+
+
 def test_one_accumulator_wgrad_is_fp32_grade(dev, f16x3):
     """wgrad_pl.hip ACC1 (off by default: pylc_debug_wgrad_acc1): the 128 x 128 wgrad with ONE accumulator set under 128 registers --
     cross terms scaled by 2^-11 in registers and added into the same fp32 accumulator.  Not bit-identical to the two-accumulator form,

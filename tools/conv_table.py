@@ -13,7 +13,7 @@ def wrap(name):
         dd = d._obj
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record(); rc = fn(d, *a); a1.record()
-        key = (name.replace('pylc_conv2d_', '').replace('fwd_stats', 'fwd').replace('dgrad_add', 'dgrad'), dd.Cin, dd.Cout, dd.R, dd.stride, dd.dil, dd.H, dd.OH)
+        key = (name.replace('pylc_conv2d_', '').replace('fwd_stats', 'fwd').replace('dgrad_add', 'dgrad').replace('wgrad_slabs', 'wgrad'), dd.Cin, dd.Cout, dd.R, dd.stride, dd.dil, dd.H, dd.OH)
         flops = 2.0 * dd.B * dd.OH * dd.OW * dd.Cout * dd.R * dd.S * dd.Cin
         recs.append((key, a0, a1, flops))
         return rc
@@ -21,7 +21,7 @@ def wrap(name):
 import pylc_amd.ops as ops
 class Shim:
     def __getattr__(self, n):
-        if n in ('pylc_conv2d_fwd', 'pylc_conv2d_fwd_stats', 'pylc_conv2d_dgrad', 'pylc_conv2d_dgrad_add', 'pylc_conv2d_wgrad'):
+        if n in ('pylc_conv2d_fwd', 'pylc_conv2d_fwd_stats', 'pylc_conv2d_dgrad', 'pylc_conv2d_dgrad_add', 'pylc_conv2d_wgrad', 'pylc_conv2d_wgrad_slabs'):
             return wrap(n)
         return getattr(L.lib, n)
 for _m in (ops._core, ops.conv, ops.bn, ops.dw, ops.misc):
