@@ -58,6 +58,11 @@ def synth(rank, b, ch, hw, n_cls, dev):
     return x, y
 
 
+def _side_stream_on():
+    from pylc_amd.runtime import runtime
+    return runtime.side_stream_on()
+
+
 def csrc_fingerprint():
     """sha256 over the kernel sources: ties a committed PMC profile to the build it was measured on."""
     import glob
@@ -188,8 +193,8 @@ def hbm_roofline(bn_records, n_steps):
     return {'bound': 'hbm', 'kernel': 'bn_apply_kernel + bn_reduce_kernel + bn_bwd_apply_kernel (bn.hip)', 'achieved': ach, 'peak': PEAK_HBM_TBS,
             'unit': 'TB/s', 'frac': ach / PEAK_HBM_TBS, 'bytes_per_step': tot_b / n_steps, 'ms_per_step': tot_ms / n_steps,
             'launches_per_step': n / n_steps,
-            'note': 'achieved = algorithmic bytes / HIP-event time of the passes INSIDE the step (the wgrad side stream shares HBM with the '
-                    'backward passes); isolated rates: profiles/*_bn_table_serial.txt',
+            'note': 'achieved = algorithmic bytes / HIP-event time of the passes INSIDE the step (config.wgrad_queue: on the compute stream nothing '
+                    'runs beside them; a wgrad side stream shares the chip with the backward passes); per shape: profiles/*_bn_table_serial.txt',
             'by_pass': {k: {'ms_per_step': v[0] / n_steps, 'GB_per_step': v[1] / n_steps / 1e9,
                             'TBps': v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0.0, 'launches_per_step': v[2] / n_steps} for k, v in by.items()}}
 
@@ -442,6 +447,8 @@ def main():
                    # torch.distributed work objects; 'native': the C ABI's own RCCL communicator, pylc_comm_*)
                    'rccl_ranks': world if (dist_backend == 'nccl' or comm_kind == 'native') else 0,
                    'dist_backend': dist_backend, 'comm': comm_kind,
+                   # where the conv filter gradients run (pylc_amd.runtime.side_stream_on: one queue for f16x3 since round 5, DESIGN.md 5.2 i)
+                   'wgrad_queue': 'side stream' if _side_stream_on() else 'compute stream',
                    'sync_bn': bool(pylc_amd.runtime.sync_bn),
                    'collectives_per_step': collectives if world > 1 else dp_collectives,
                    'dp_codepath_overhead': dp_overhead,
