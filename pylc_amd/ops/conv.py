@@ -22,9 +22,6 @@ def _padded_stem_filter(w, cin):
     return w_k
 
 
-_last_wgrad_ev = {}      # device -> event behind the latest side-stream wgrad (runtime.wgrad_gate)
-
-
 class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w) + bias on the MFMA implicit-GEMM kernels."""
 
@@ -177,12 +174,6 @@ class Conv2dFn(torch.autograd.Function):
         st = stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if _runtime.wgrad_gate:
-                # gated overlap (PYLC_WGRAD_GATE=1): this dgrad starts only when the previous layer's wgrad is done, so that a wgrad shares
-                # the chip with the (HBM-bound) BatchNorm backward between two dgrads and never with a matrix-bound dgrad
-                e = _last_wgrad_ev.pop(x.device, None)
-                if e is not None:
-                    torch.cuda.current_stream().wait_event(e)
             kp = _r4(cout)
             link = ctx.res_link
             masked = None
@@ -294,10 +285,6 @@ class Conv2dFn(torch.autograd.Function):
                         check(lib.pylc_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw4), None, ptr(ws), nbytes, sst))
                         dwl = tgt if tgt is not None else torch.empty((cout, r, s, cin_w), device=x.device).permute(0, 3, 1, 2)
                         dwl.copy_(dw4[..., :cin_w].permute(0, 3, 1, 2))
-                    if side is not None and _runtime.wgrad_gate:
-                        e = torch.cuda.Event()
-                        e.record()
-                        _last_wgrad_ev[x.device] = e
                 if side is not None and tgt is None:
                     torch.cuda.current_stream().wait_stream(side)      # the returned tensor is consumed by autograd on the main stream
                 return _deliver_grad(w, dwl)

@@ -62,8 +62,6 @@ class _Runtime:
         # one queue: the split-K slab sums of all wgrads of a backward pass run as ONE launch before the gradients are read
         # (ops.flush_slab_sums); PYLC_NO_BATCH_SLAB_SUMS=1: one sum behind every wgrad (A/B knob)
         self.batch_slab_sums = not os.environ.get('PYLC_NO_BATCH_SLAB_SUMS')
-        # PYLC_WGRAD_GATE=1: every conv dgrad waits for the previous layer's side-stream wgrad (A/B knob; ops.Conv2dFn.backward)
-        self.wgrad_gate = os.environ.get('PYLC_WGRAD_GATE', '0') == '1'
         self.wgrad_1x1_main = int(os.environ.get('PYLC_WGRAD_1X1_MAIN', '0'))      # see ops.Conv2dFn.backward (A/B knob)
         # PYLC_FUSE_BN_SUMS=1: a conv dgrad that writes the complete gradient of a BatchNorm output takes that BatchNorm's backward sums in its
         # epilogue (pylc_conv2d_dgrad_bn) and the BatchNorm skips its reduction pass.  Built, tested, measured NEGATIVE (the dgrad epilogue is the
