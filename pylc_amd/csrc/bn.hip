@@ -584,19 +584,19 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
     const int c = blockIdx.x * 8 + tx;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
-        // twelve rows (24 loads) in flight per thread, the tail batch included: rows past the end load row 0 and add an exact 0, so a
-        // 745-row combine is two load round trips instead of three plus eight dependent ones; row order of the adds unchanged
-        for (int r = ty; r < nrows; r += 12 * 32) {
-            float v0[12], v1[12];
+        // sixteen rows (32 loads) in flight per thread, the tail batch included: rows past the end load row 0 and add an exact 0, so the
+        // 512-row combine of a 512-slab reduce (slab.h kRowSlabs) is ONE load round trip; row order of the adds unchanged
+        for (int r = ty; r < nrows; r += 16 * 32) {
+            float v0[16], v1[16];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int rr = r + u * 32;
                 const size_t row = rr < nrows ? (size_t)rr : 0;
                 v0[u] = partial[row * 2 * C + c];
                 v1[u] = partial[row * 2 * C + C + c];
             }
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const bool ok = r + u * 32 < nrows;
                 a0 += ok ? (double)v0[u] : 0.0;
                 a1 += ok ? (double)v1[u] : 0.0;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYLC_LIB: load another build of the library (same-box A/B of two builds: tools/ab_builds.sh)
 LIB_PATH = os.environ.get('PYLC_LIB') or os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class PylcError(RuntimeError):
