@@ -37,6 +37,33 @@ def test_library_exports_every_header_symbol():
     assert dll.pylc_abi_version() == L.ABI_VERSION
 
 
+def test_wgrad_queue_policy_follows_the_precision_mode():
+    """runtime.side_stream_on(): filter gradients run on the compute stream for f16x3 (one queue, DESIGN.md 5.2 i) and on the side stream
+    for precision mode 3, unless the process forces one schedule; a pending split-K slab sum needs no GPU to be noted and forgotten."""
+    import ctypes as C
+    from pylc_amd.lib import lib, check, SlabSum
+    from pylc_amd.runtime import runtime
+    from pylc_amd import ops
+    prev_mode, prev_side = lib.pylc_get_conv_precision(), runtime.wgrad_side_stream
+    try:
+        runtime.wgrad_side_stream = None
+        check(lib.pylc_set_conv_precision(2))
+        assert runtime.side_stream_on() is False
+        check(lib.pylc_set_conv_precision(3))
+        assert runtime.side_stream_on() is True
+        runtime.wgrad_side_stream = False
+        assert runtime.side_stream_on() is False
+        check(lib.pylc_set_conv_precision(2))
+        runtime.wgrad_side_stream = True
+        assert runtime.side_stream_on() is True
+    finally:
+        runtime.wgrad_side_stream = prev_side
+        check(lib.pylc_set_conv_precision(prev_mode))
+    assert C.sizeof(SlabSum) == 40                     # include/pylc_hip.h PylcSlabSum
+    assert ops.side_stream_if_any('cpu') is None
+    ops.flush_slab_sums()                              # nothing pending: no launch, no GPU needed
+
+
 def test_error_reporting_without_gpu():
     """Argument validation happens on the host before any launch: callable (and failing cleanly) without a GPU."""
     import ctypes as C
