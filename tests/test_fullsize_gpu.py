@@ -96,6 +96,35 @@ def test_config3_config4_r101_512_bs32_deterministic(dev, n_cls):
     assert abs(runs[0][0][0][0] - math.log(n_cls)) < 1.2 and sum(runs[0][0][-1]) < sum(runs[0][0][0])
 
 
+def test_one_queue_and_side_stream_schedules_are_bit_identical(dev):
+    """Round 5: the f16x3 step runs ONE queue (filter gradients on the compute stream, their split-K slab sums in one launch at the end of the
+    backward pass -- runtime.side_stream_on(), ops.flush_slab_sums); the side-stream schedule of rounds 1-5 (a sum behind every wgrad) stays
+    for precision mode 3.  Same kernels either way: two training steps of DeepLabV3+/R101 (256x256, bs 4) must leave the same bits in every
+    parameter and gradient."""
+    from pylc_amd.model import Model, Meta
+    from pylc_amd import runtime
+    from tests import _data as D
+    x, y = D.learnable_tiles(35, 4, 256, 9, cell=32)
+    prev = runtime.wgrad_side_stream
+    runs = []
+    try:
+        for side in (False, True):
+            runtime.wgrad_side_stream = side
+            torch.manual_seed(1234)
+            runtime.manual_seed(7)
+            model = Model(Meta(n_classes=9, lr=1e-3), dev).build()
+            for _ in range(2):
+                model.train(x, y)
+            torch.cuda.synchronize()
+            runs.append((float(model.crit.ce), model.arena.p.clone(), model.arena.g.clone()))
+            del model
+    finally:
+        runtime.wgrad_side_stream = prev
+    assert runs[0][0] == runs[1][0]
+    assert float(runs[0][2].abs().max()) > 0
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
 def test_config5_inference_leg_full_res_image(dev):
     """configs[4], second half: sliding-window inference over a full-resolution image at the reference's size (pylc_gpu.ipynb:1057-1063:
     a 3453x4940 photograph fitted to 3072 x 4096; test.py:63 stride = tile / 2): one grayscale 3072 x 4096 image, 1024^2 tiles, stride
