@@ -243,8 +243,9 @@ class Model:
                 self._bucketer = GradBucketer(self.arena, runtime.grad_group)
             self._bucketer.reset()
             runtime.grad_ready = self._bucketer.ready
+        ops.reset_slab_sums()                     # (sums noted by a backward pass that an exception cut short)
         loss.backward()
-        ops.sync_side_streams()                   # wgrad kernels run on a side stream
+        ops.sync_side_streams()                   # side-stream wgrads (precision mode 3) joined, pending split-K slab sums launched
         self.arena.clear_undelivered()            # a parameter without a gradient this step must not keep last step's (before the exchange)
         if runtime.sync_group is not None:
             runtime.grad_ready = None

@@ -463,6 +463,22 @@ def add_slab_sum(device, entry):
     _pending_slab_sums.setdefault(torch.device(device).index, []).append(bytes(entry))
 
 
+def slab_sum_pending(device, workspace):
+    """True while a noted sum still reads `workspace` (a weight that takes part in the graph twice: its second wgrad must not overwrite the
+    slabs of its first -- the caller flushes first)."""
+    pend = _pending_slab_sums.get(torch.device(device).index)
+    if not pend:
+        return False
+    p = workspace.data_ptr()
+    return any(L.SlabSum.from_buffer_copy(e).slabs == p for e in pend)
+
+
+def reset_slab_sums():
+    """Forget sums noted by a backward pass that did not reach its flush (an exception in between): Model.train calls this before backward()."""
+    for pend in _pending_slab_sums.values():
+        pend.clear()
+
+
 def flush_slab_sums(device=None):
     """ONE launch that sums the split-K slabs of every wgrad since the last flush (pylc_splitk_reduce_batch), on the current stream.  The
     table lives in device memory and is re-used while the same layers run with the same buffers (every training step after the first)."""

@@ -272,6 +272,8 @@ class Conv2dFn(torch.autograd.Function):
                         own = getattr(w, '_pylc_slab_ws', None)
                         if own is None or own.numel() * 4 < nbytes or own.device != x.device:
                             own = w._pylc_slab_ws = torch.empty(nbytes // 4 + 1, device=x.device)
+                        elif _core.slab_sum_pending(x.device, own):       # the same weight again in this pass: sum its first slabs before they go
+                            _core.flush_slab_sums(x.device)
                         dwl = tgt
                         pend = L.SlabSum()
                         check(lib.pylc_conv2d_wgrad_slabs(C.byref(d), ptr(x), ptr(dy), ptr(dwl), ptr(own), nbytes, C.byref(pend), sst))
