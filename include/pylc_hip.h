@@ -698,6 +698,7 @@ int pylc_debug_pp_stamps(unsigned long long* buf);
  * PYLC_ERR_UNSUPPORTED.  Everything is enqueued on the caller's stream.  pylc_amd uses them when PYLC_COMM=native (default: the same
  * collectives through torch.distributed's RCCL backend). */
 #define PYLC_COMM_ID_BYTES 128
+int pylc_comm_available(void);                                           /* PYLC_OK if an RCCL could be resolved in this process (no GPU call, no collective): the probe every rank runs BEFORE any rank starts a communicator hand-shake */
 int pylc_comm_unique_id(void* id_out);                                   /* PYLC_COMM_ID_BYTES bytes; one rank makes it, the caller hands it to all */
 int pylc_comm_init(const void* id, int rank, int world, void** comm_out);   /* collective; the current HIP device is this rank's GPU */
 int pylc_comm_allreduce(void* comm, void* buf, long long count, int dtype, void* stream);      /* in-place SUM; dtype 0 = fp32, 1 = fp64 */

@@ -8,7 +8,7 @@ int conv_init();
 
 extern "C" const char* pylc_last_error(void) { return pylc::g_err; }
 
-extern "C" int pylc_abi_version(void) { return 12; }      // r5: pylc_comm_*, PylcFwdEp, PylcConvDesc.w_planes_fmt, pylc_weight_prepare(interleave); 12: pylc_conv2d_wgrad_slabs, pylc_splitk_reduce_batch, PylcSlabSum
+extern "C" int pylc_abi_version(void) { return 13; }      // r5: pylc_comm_*, PylcFwdEp, PylcConvDesc.w_planes_fmt, pylc_weight_prepare(interleave); 12: pylc_conv2d_wgrad_slabs, pylc_splitk_reduce_batch, PylcSlabSum; 13 (r6): pylc_comm_available
 
 // 1 when the library was built with EXPERIMENTAL=1 (include/pylc_hip.h: the #ifdef PYLC_EXPERIMENTAL entry points exist)
 extern "C" int pylc_experimental_build(void) {

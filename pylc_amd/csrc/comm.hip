@@ -79,6 +79,13 @@ struct Comm { NcclComm comm; int rank, world; };
 
 using namespace pylc;
 
+// Local probe: can this process reach an RCCL at all?  No GPU call, no collective -- what every rank asks first, so that the decision to
+// start a communicator hand-shake is taken by all ranks together (pylc_amd/parallel.py try_native_comm)
+extern "C" int pylc_comm_available(void) {
+    PYLC_RCCL_READY(r);
+    return PYLC_OK;
+}
+
 // 128 bytes that identify a new communicator: produced on ONE rank, handed to every rank by the caller (torch.distributed store, a file, MPI)
 extern "C" int pylc_comm_unique_id(void* id_out) {
     PYLC_REQUIRE(id_out != nullptr, "comm_unique_id: null output");

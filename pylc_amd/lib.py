@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYLC_LIB: load another build of the library (same-box A/B of two builds: tools/ab_builds.sh)
 LIB_PATH = os.environ.get('PYLC_LIB') or os.path.join(_HERE, 'libpylc_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class PylcError(RuntimeError):
@@ -86,6 +86,7 @@ SIGNATURES = {
     'pylc_debug_p1': (_I, [_I]),
     'pylc_debug_wgrad_flags': (_I, [_I]),
     'pylc_debug_wgrad_max_steps': (_I, [_I]),
+    'pylc_comm_available': (_I, []),
     'pylc_comm_unique_id': (_I, [_P]),
     'pylc_comm_init': (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
     'pylc_comm_allreduce': (_I, [_P, _P, _LL, _I, _P]),

@@ -11,6 +11,7 @@ import ctypes as C
 
 import os
 import time
+from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
@@ -455,12 +456,35 @@ def _keep_for_side(device, *tensors):
 
 
 _pending_slab_sums = {}      # device index -> [bytes of a PylcSlabSum, ...] of this backward pass
-_slab_tables = {}            # device index -> (key bytes, table tensor, prefix tensor, n, total tiles): re-used while the entries repeat
+_slab_tables = {}            # device index -> OrderedDict {key bytes: (table tensor, prefix tensor, n, total tiles)}: a small LRU -- a data-parallel
+                             # step flushes once per gradient bucket and once at the end, each with its own entry list, every step the same
+SLAB_TABLES_MAX = 16
+
+
+_slab_callback = {}          # device index -> the stream the end-of-backward flush of this pass will run on (present = callback queued)
 
 
 def add_slab_sum(device, entry):
-    """A wgrad left its split-K slabs in its weight's own workspace (ops.conv, runtime.batch_slab_sums): note the sum for flush_slab_sums()."""
-    _pending_slab_sums.setdefault(torch.device(device).index, []).append(bytes(entry))
+    """A wgrad left its split-K slabs in its weight's own workspace (ops.conv, runtime.batch_slab_sums): note the sum for flush_slab_sums().
+    The first note of a backward pass also queues an autograd-engine callback that flushes when the pass ends, on the stream the wgrad ran on:
+    whoever called backward() -- Model.train, torch.ops users, a maintainer's own loop over layers.Conv2d -- finds SUMMED filter gradients in
+    .grad without knowing about slabs.  Model.train and the gradient bucketer still flush earlier where they want the
+    sums earlier; a flush with nothing pending is free."""
+    idx = torch.device(device).index
+    _pending_slab_sums.setdefault(idx, []).append(bytes(entry))
+    if idx not in _slab_callback:
+        st = torch.cuda.current_stream(idx)
+
+        def at_end_of_backward(idx=idx, st=st):
+            _slab_callback.pop(idx, None)
+            if _pending_slab_sums.get(idx):
+                with torch.cuda.stream(st):
+                    flush_slab_sums(torch.device('cuda', idx))
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(at_end_of_backward)
+            _slab_callback[idx] = st
+        except RuntimeError:          # not inside a backward pass (a test driving the C ABI by hand): the caller flushes
+            pass
 
 
 def slab_sum_pending(device, workspace):
@@ -477,6 +501,7 @@ def reset_slab_sums():
     """Forget sums noted by a backward pass that did not reach its flush (an exception in between): Model.train calls this before backward()."""
     for pend in _pending_slab_sums.values():
         pend.clear()
+    _slab_callback.clear()
 
 
 def flush_slab_sums(device=None):
@@ -488,19 +513,26 @@ def flush_slab_sums(device=None):
             continue
         key = b''.join(pend)
         pend.clear()
-        cached = _slab_tables.get(idx)
-        if cached is None or cached[0] != key:
+        tables = _slab_tables.setdefault(idx, OrderedDict())
+        cached = tables.get(key)
+        if cached is None:
             n = len(key) // C.sizeof(L.SlabSum)
             ents = (L.SlabSum * n).from_buffer_copy(key)
             prefix = [0]
             for e in ents:
                 prefix.append(prefix[-1] + (e.n4 + 31) // 32)
             dev = torch.device('cuda', idx)
-            tab = torch.frombuffer(bytearray(key), dtype=torch.uint8).to(dev)
-            pre = torch.tensor(prefix, dtype=torch.int64).to(dev)
-            cached = _slab_tables[idx] = (key, tab, pre, n, prefix[-1])
+            # staged through pinned memory, asynchronously: a pageable .to(dev) is host-synchronous and stream-ordered -- in a data-parallel
+            # backward it drained the compute queue at every bucket.  The pinned sources are kept with the entry.
+            tab_h = torch.frombuffer(bytearray(key), dtype=torch.uint8).pin_memory()
+            pre_h = torch.tensor(prefix, dtype=torch.int64).pin_memory()
+            cached = tables[key] = (tab_h.to(dev, non_blocking=True), pre_h.to(dev, non_blocking=True), n, prefix[-1], tab_h, pre_h)
+            while len(tables) > SLAB_TABLES_MAX:
+                tables.popitem(last=False)
+        else:
+            tables.move_to_end(key)
         with torch.cuda.device(idx):
-            check(lib.pylc_splitk_reduce_batch(ptr(cached[1]), ptr(cached[2]), cached[3], cached[4], stream()))
+            check(lib.pylc_splitk_reduce_batch(ptr(cached[0]), ptr(cached[1]), cached[2], cached[3], stream()))
 
 
 def sync_side_streams():

@@ -270,10 +270,12 @@ class Conv2dFn(torch.autograd.Function):
                         # one queue: the split-K slabs stay in this weight's OWN workspace and every layer's slab sum runs in one launch
                         # before the gradients are read (ops.flush_slab_sums, from sync_side_streams / the gradient bucketer)
                         own = getattr(w, '_pylc_slab_ws', None)
+                        if own is not None and own.is_cuda and _core.slab_sum_pending(own.device, own):
+                            # the same weight again in this pass: sum its first slabs before they are overwritten -- or, when the second plan
+                            # needs a larger block, before the old block goes back to the allocator with a noted sum still pointing at it
+                            _core.flush_slab_sums(own.device)
                         if own is None or own.numel() * 4 < nbytes or own.device != x.device:
                             own = w._pylc_slab_ws = torch.empty(nbytes // 4 + 1, device=x.device)
-                        elif _core.slab_sum_pending(x.device, own):       # the same weight again in this pass: sum its first slabs before they go
-                            _core.flush_slab_sums(x.device)
                         dwl = tgt
                         pend = L.SlabSum()
                         check(lib.pylc_conv2d_wgrad_slabs(C.byref(d), ptr(x), ptr(dy), ptr(dwl), ptr(own), nbytes, C.byref(pend), sst))

@@ -60,45 +60,112 @@ def init_from_env(backend=None):
     return rank, world
 
 
-def try_native_comm(rank, world):
-    """PYLC_COMM=native with a fall-back: if the C ABI's communicator cannot be brought up (no loadable RCCL, ncclCommInitRank failing),
-    the run continues on the torch.distributed path -- the decision is taken by ALL ranks together (a MIN all-reduce of the local outcome: one
-    rank on native and its peers on torch.distributed would wait for each other forever) and the reason is logged once per rank."""
-    ok, why = 1, ''
-    try:
-        init_native_comm(rank, world)
-    except Exception as e:          # PylcError (PYLC_ERR_UNSUPPORTED: RCCL not loadable; PYLC_ERR_HIP: RCCL error) or a ctypes failure
-        ok, why = 0, '%s: %s' % (type(e).__name__, e)
-    if world > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        all_ok = int(flag.item()) == 1
-    else:
-        all_ok = bool(ok)
-    if not all_ok:
-        import sys
-        destroy_native_comm()
-        print('[pylc_amd] rank %d: PYLC_COMM=native unavailable (%s); collectives stay on torch.distributed'
-              % (rank, why or 'another rank could not create its communicator'), file=sys.stderr, flush=True)
-    return all_ok
+def _side_device():
+    """Where the side-channel tensors of the hand-shake live: the GPU under torch.distributed's RCCL backend, the host under gloo."""
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
 
 
-def _native_communicator(rank, world):
-    """One RCCL communicator behind the C ABI (pylc_comm_init); torch.distributed is the side channel for rank 0's 128-byte id."""
+def _agree(ok, world):
+    """MIN over all ranks of a local outcome (1 / 0): every decision of the hand-shake below is taken on a value ALL ranks hold."""
+    if world <= 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_side_device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
+# the three local steps of the hand-shake, each a thin call into the C ABI (tests replace them to make one rank fail)
+def _comm_available():
+    from .lib import lib, check
+    check(lib.pylc_comm_available())
+
+
+def _comm_unique_id():
     import ctypes as C
     from .lib import lib, check
-    dev = torch.device('cuda', torch.cuda.current_device())
-    ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        buf = (C.c_char * 128)()
-        check(lib.pylc_comm_unique_id(buf))
-        ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-    if world > 1:
-        dist.broadcast(ident, 0)
-    raw = bytes(ident.cpu().numpy().tobytes())
+    buf = (C.c_char * 128)()
+    check(lib.pylc_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def _comm_init(raw, rank, world):
+    import ctypes as C
+    from .lib import lib, check
     handle = C.c_void_p()
     check(lib.pylc_comm_init(raw, rank, world, C.byref(handle)))
     return handle
+
+
+def _comm_destroy(handle):
+    from .lib import lib
+    lib.pylc_comm_destroy(handle)
+
+
+def n_native_comms():
+    return 2 if os.environ.get('PYLC_SEPARATE_GRAD_COMM', '1') != '0' else 1
+
+
+def try_native_comm(rank, world):
+    """PYLC_COMM=native with a fall-back: if the C ABI's communicators cannot be brought up (no loadable RCCL, ncclGetUniqueId or
+    ncclCommInitRank failing on any rank), the run continues on the torch.distributed path and every rank logs why.
+
+    The hand-shake uses torch.distributed as its side channel, and the SEQUENCE of side-channel collectives is the same on every rank
+    whatever happens locally (a rank that raised before its peers' broadcast went on to an all-reduce they had not reached --
+    mismatched collectives on one process group hang or corrupt):
+        1. every rank probes RCCL locally (pylc_comm_available: no collective)               -> MIN all-reduce;  any 0: all ranks stop here
+        2. per communicator: rank 0 makes the id (zeros if that fails) -> broadcast, ALWAYS  -> each rank joins ncclCommInitRank unless the
+           id is all zeros                                                                   -> MIN all-reduce of the outcomes; any 0: all
+           ranks destroy what they hold and stop.
+    Every early exit is taken on an all-reduced value, so all ranks leave at the same point."""
+    import sys
+    handles = []
+    why = ''
+
+    def give_up(stage):
+        for h in handles:
+            if h is not None:
+                try:
+                    _comm_destroy(h)
+                except Exception:
+                    pass
+        runtime.comm = runtime.grad_comm = None
+        print('[pylc_amd] rank %d: PYLC_COMM=native unavailable (%s: %s); collectives stay on torch.distributed'
+              % (rank, stage, why or 'another rank failed'), file=sys.stderr, flush=True)
+        return False
+
+    ok = 1
+    try:
+        _comm_available()
+    except Exception as e:          # PylcError (PYLC_ERR_UNSUPPORTED: RCCL not loadable) or a ctypes failure
+        ok, why = 0, '%s: %s' % (type(e).__name__, e)
+    if not _agree(ok, world):
+        return give_up('RCCL probe')
+    for i in range(n_native_comms()):
+        ident = torch.zeros(128, dtype=torch.uint8, device=_side_device())
+        ok = 1
+        if rank == 0:
+            try:
+                ident.copy_(torch.frombuffer(bytearray(_comm_unique_id()), dtype=torch.uint8))
+            except Exception as e:
+                ok, why = 0, '%s: %s' % (type(e).__name__, e)
+                ident.zero_()                               # the peers read "no id" and skip ncclCommInitRank
+        if world > 1:
+            dist.broadcast(ident, 0)
+        handle = None
+        if bool(ident.any()):
+            try:
+                handle = _comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
+            except Exception as e:
+                ok, why = 0, '%s: %s' % (type(e).__name__, e)
+        else:
+            ok = 0
+        handles.append(handle)
+        if not _agree(ok, world):
+            return give_up('communicator %d' % i)
+    runtime.comm, runtime.grad_comm = handles[0], handles[-1]
+    return True
 
 
 def init_native_comm(rank, world):
@@ -111,12 +178,10 @@ def init_native_comm(rank, world):
                            waits for the wgrads (stream-ordered RCCL serialises a communicator's collectives in enqueue order).
     Every rank enqueues each communicator's collectives in the same program order; the two never wait for each other on the host, and the
     compute stream waits for the bucket stream only in GradBucketer.finish(), before the optimiser.  torch.distributed stays the side
-    channel that carries the communicator ids from rank 0 (and the barrier / parameter broadcast at set-up)."""
-    runtime.comm = _native_communicator(rank, world)
-    if os.environ.get('PYLC_SEPARATE_GRAD_COMM', '1') != '0':
-        runtime.grad_comm = _native_communicator(rank, world)
-    else:
-        runtime.grad_comm = runtime.comm
+    channel that carries the communicator ids from rank 0 (and the barrier / parameter broadcast at set-up).  Raises if the communicators
+    cannot be created (try_native_comm: the same hand-shake, all ranks falling back together)."""
+    if not try_native_comm(rank, world):
+        raise RuntimeError('PYLC_COMM=native: the RCCL communicators could not be created on every rank')
 
 
 def destroy_native_comm():
@@ -181,6 +246,14 @@ class GradBucketer:
         if native:
             # native communicator: ncclAllReduce is stream-ordered, so it goes on a communication stream of its own that first waits for
             # an event of each producer -- on the wgrad stream itself (round 4) every later wgrad queued behind a 64 MB exchange
+            if runtime.grad_comm is runtime.comm:
+                # ONE communicator (PYLC_SEPARATE_GRAD_COMM=0, an A/B knob): RCCL runs a communicator's collectives in host enqueue order,
+                # so its buckets must sit on the stream its SyncBN / loss messages use -- the compute stream -- or a 2 KB message would
+                # queue behind a 64 MB bucket on another stream with no ordering between the two
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side)
+                runtime.native_all_reduce(self.arena.g[lo:hi], runtime.grad_comm)
+                return
             cs = self._comm_stream()
             ev = torch.cuda.Event()
             ev.record()                                     # compute stream: BatchNorm / bias gradients of the bucket

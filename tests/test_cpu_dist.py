@@ -137,6 +137,42 @@ try:
     raise SystemExit('unequal shards were accepted')
 except RuntimeError as e:
     assert 'equal shards' in str(e)
+# --- 6. PYLC_COMM=native hand-shake (parallel.try_native_comm) with a fake RCCL that fails on ONE rank (ADVICE r5): the side-channel
+#        collectives must be the same sequence on every rank whatever the local outcome -- all ranks fall back together, none hangs, none
+#        runs a broadcast against a peer's all-reduce; what was created is destroyed.  gloo carries the side channel here ----------------
+made, destroyed = [], []
+def fake_init(fail_rank, fail_at):
+    def init(raw, r, w):
+        assert r == rank and w == world and len(raw) == 128 and any(raw)
+        if rank == fail_rank and len(made) == fail_at:
+            raise RuntimeError('ncclCommInitRank: RCCL error (test)')
+        made.append(object())
+        return made[-1]
+    return init
+def boom(*a):
+    raise RuntimeError('librccl.so.1 not loadable (test)')
+P.n_native_comms = lambda: 2
+P._comm_destroy = destroyed.append
+for case, avail, uid, init, want in (
+        ('all good', lambda: None, lambda: bytes(range(1, 129)), fake_init(-1, 0), True),
+        ('rank 0 cannot load RCCL', (boom if rank == 0 else (lambda: None)), lambda: bytes(range(1, 129)), fake_init(-1, 0), False),
+        ('last rank cannot load RCCL', (boom if rank == world - 1 else (lambda: None)), lambda: bytes(range(1, 129)), fake_init(-1, 0), False),
+        ('rank 0 cannot make the id', lambda: None, boom, fake_init(-1, 0), False),
+        ('last rank fails its second ncclCommInitRank', lambda: None, lambda: bytes(range(1, 129)), fake_init(world - 1, 1), False)):
+    del made[:], destroyed[:]
+    runtime.comm = runtime.grad_comm = None
+    P._comm_available, P._comm_unique_id, P._comm_init = avail, uid, init
+    got = parallel.try_native_comm(rank, world)
+    assert got is want, (case, got)
+    if want:
+        assert runtime.comm is made[0] and runtime.grad_comm is made[1] and not destroyed
+    else:
+        assert runtime.comm is None and runtime.grad_comm is None and destroyed == made, (case, made, destroyed)
+    # the process group is still in step: a collective after the hand-shake sees every rank
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    assert t.item() == world, case
+runtime.comm = runtime.grad_comm = None
 parallel.barrier()
 if rank == 0:
     print('DIST_OK')

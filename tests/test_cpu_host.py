@@ -463,15 +463,27 @@ def test_native_comm_falls_back_with_a_logged_reason(monkeypatch, capsys):
     from pylc_amd import parallel
     from pylc_amd.runtime import runtime
 
-    def boom(rank, world):
-        runtime.comm = object()           # the first communicator came up, the second did not
-        raise RuntimeError('pylc_comm: librccl.so.1 not loadable: test')
-    monkeypatch.setattr(parallel, 'init_native_comm', boom)
-    monkeypatch.setattr(parallel, 'destroy_native_comm', lambda: (setattr(runtime, 'comm', None), setattr(runtime, 'grad_comm', None)))
+    made, destroyed = [], []
+
+    def init(raw, rank, world):
+        if made:                          # the first communicator came up, the second did not
+            raise RuntimeError('pylc_comm: librccl.so.1 not loadable: test')
+        made.append(object())
+        return made[-1]
+    monkeypatch.setattr(parallel, '_comm_available', lambda: None)
+    monkeypatch.setattr(parallel, '_comm_unique_id', lambda: bytes(range(1, 129)))
+    monkeypatch.setattr(parallel, '_comm_init', init)
+    monkeypatch.setattr(parallel, '_comm_destroy', destroyed.append)
     assert parallel.try_native_comm(0, 1) is False
-    assert runtime.comm is None and runtime.grad_comm is None
+    assert runtime.comm is None and runtime.grad_comm is None and destroyed == made and len(made) == 1
     err = capsys.readouterr().err
     assert 'PYLC_COMM=native unavailable' in err and 'not loadable' in err and 'torch.distributed' in err
+    # ... and the probe alone failing (no RCCL in the process): nothing is created, the reason is the loader's
+    def no_rccl():
+        raise RuntimeError('pylc_comm: librccl.so.1 not loadable: probe')
+    monkeypatch.setattr(parallel, '_comm_available', no_rccl)
+    assert parallel.try_native_comm(0, 1) is False and len(made) == 1
+    assert 'RCCL probe' in capsys.readouterr().err
     # a message the C ABI does not take goes through torch.distributed instead of raising
     import torch
     assert runtime.native_takes(torch.zeros(4)) and runtime.native_takes(torch.zeros(4, dtype=torch.float64))

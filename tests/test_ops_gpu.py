@@ -498,6 +498,34 @@ def test_prepared_filter_planes_match_inline_split(dev):
     runtime.no_planes = False
 
 
+def test_filter_gradients_are_summed_when_backward_returns(dev):
+    """on the one-queue schedule a conv's wgrad leaves split-K slabs and ONE launch sums the slabs of all layers
+    (ops.flush_slab_sums).  A caller of layers.Conv2d + optim.FlatArena who never heard of that -- no ops.sync_side_streams(), no Model.train
+    -- must still read SUMMED gradients from .grad as soon as backward() returns: the first noted sum queues an autograd-engine callback.
+    Large pixel counts so that the split plan has several slabs; compared with the gradient of the same layer without an arena (which
+    sums its slabs inside the call)."""
+    from pylc_amd import ops, layers
+    from pylc_amd.optim import FlatArena
+    from pylc_amd import runtime
+    if not runtime.batch_slab_sums or runtime.side_stream_on():
+        pytest.skip('the batched slab sum belongs to the one-queue schedule')
+    torch.manual_seed(5)
+    for cin, cout, k, pad, b, hw in ((64, 64, 3, 1, 8, 128), (256, 64, 1, 0, 8, 128)):
+        conv = layers.Conv2d(cin, cout, k, 1, pad, 1).to(dev)
+        x = to_dev_nhwc(rnd(21, b, cin, hw, hw), dev).requires_grad_(True)
+        dy = to_dev_nhwc(rnd(22, b, cout, hw, hw), dev)
+        conv(x).backward(dy)
+        dw0 = conv.weight.grad.clone()
+        arena = FlatArena(conv)
+        arena.g.zero_()
+        for _ in range(2):                                # the second pass re-uses the cached table
+            arena.g.fill_(float('nan'))
+            conv(x).backward(dy)
+            assert not ops._core._pending_slab_sums.get(dev.index or 0), 'a slab sum was still pending after backward() returned'
+            assert torch.equal(conv.weight.grad, dw0)
+        del arena
+
+
 def test_conv_multi_round_launches_are_bit_identical(dev):
     """Launches with more than one 256x128 tile per CU: one block per tile (default) against persistent blocks walking a
     strided share of the tiles (debug flag 64) -- not a bit may change in the forward with fused BatchNorm statistics, the
