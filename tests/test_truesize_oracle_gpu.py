@@ -11,9 +11,11 @@ in seconds, and the HIP path is compared with it output for output:
   (ii)  U-Net, 3-ch 512^2 -> 324^2, bs 1 (configs[1]'s tile; unet.py:91-104)
   (iii) DeepLabV3+/Aligned-Xception, 1-ch 1024^2, 11 classes, bs 1, eval logits in f16x3 and in precision mode 3 (configs[4]'s tile)
 
-Every layer of these runs is above ops.PLANES_MIN_PIXELS, i.e. on the kernels the bench measures.  Tolerances are the north_star's
-(logits / loss 1e-3, argmax exact off near-ties) and, for gradients, the cap of tests/test_nets_gpu.py::test_train_steps_match_reference
-(5 % of the tensor's largest entry, cosine > 0.999: a transposed filter, a permuted channel or a wrong offset is a ~100 % difference)."""
+Every layer of these runs takes the fp16-plane kernels the bench measures (the fixture `every_layer_on_planes` lowers the pixel threshold to what
+bs 2 leaves of the 32^2 maps).  Tolerances are the north_star's
+(logits / loss 1e-3, argmax exact off near-ties) and, for gradients, the bound of tests/test_nets_gpu.py::test_train_steps_match_reference
+with the oracle's own reference-vs-reference noise at THIS size as its floor (tests/golden/make_truesize_conditioning.py ->
+truesize_conditioning.json; cosine > 0.999: a transposed filter, a permuted channel or a wrong offset is a ~100 % difference)."""
 import pytest
 import torch
 
@@ -26,10 +28,31 @@ GRAD_CAP = 0.05
 R101_GRADS = ['backbone.conv1.weight', 'backbone.layer1.0.conv2.weight', 'backbone.layer2.3.conv3.weight', 'backbone.layer3.11.conv2.weight',
               'backbone.layer4.2.conv2.weight', 'aspp.aspp3.atrous_conv.weight', 'decoder.last_conv.0.weight', 'decoder.last_conv.8.weight',
               'backbone.layer3.22.bn3.weight', 'decoder.bn1.bias']
-UNET_GRADS = None          # chosen from the spec below: first / middle / last conv filters and two BatchNorm vectors
+
+# tag -> (arch, backbone, classes, input channels, batch, tile, weight salt, data seed)
+CASES = {'r101_512': ('deeplab', 'resnet', 9, 3, 2, 512, 11, 71),
+         'unet_512': ('unet', None, 9, 3, 1, 512, 12, 73),
+         'xception_1024': ('deeplab', 'xception', 11, 1, 1, 1024, 13, 75)}
 
 
-def _setup(arch, backbone, n_cls, ch, b, hw, salt, dev, seed):
+def grad_keys(tag, w):
+    """The tensors compared elementwise: R101 -- ten spread over stem, the four stages, ASPP and decoder; U-Net -- first / second / middle /
+    last conv filters and two BatchNorm vectors."""
+    if tag == 'r101_512':
+        return R101_GRADS
+    convs = [k for k, v in w.items() if k.endswith('weight') and v.dim() == 4]
+    bns = [k for k, v in w.items() if k.endswith('weight') and v.dim() == 1]
+    return [convs[0], convs[1], convs[len(convs) // 2], convs[-3], convs[-1], bns[0], bns[-1]]
+
+
+def conditioning(tag):
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'truesize_conditioning.json')))[tag]
+
+
+def _setup(tag, dev):
+    arch, backbone, n_cls, ch, b, hw, salt, seed = CASES[tag]
     import oracle
     from oracle import step as ostep
     from pylc_amd.model import Model, Meta
@@ -67,7 +90,7 @@ def _check_eval(model, cfg, w, x, tol, tag, min_decided=0.9, min_agree=None):
     return err
 
 
-def _check_train_step(model, cfg, w, x, y, grad_keys, head_key, tag):
+def _check_train_step(model, cfg, w, x, y, keys, head_key, tag, cond):
     from oracle import step as ostep
     from pylc_amd import ops
     ops.planes_marked[0] = 0
@@ -83,18 +106,25 @@ def _check_train_step(model, cfg, w, x, y, grad_keys, head_key, tag):
           % (tag, got[0], got[1], got[2], ce, dsc, fl, gnorm, ref_norm, ops.planes_marked[0]))
     for a, b in zip(got, (ce, dsc, fl)):
         assert abs(a - b) < LOSS_TOL, (got, (ce, dsc, fl))
-    assert abs(gnorm - ref_norm) < 2e-2 * ref_norm
+    assert abs(gnorm - ref_norm) < max(2e-3, 4 * cond['gnorm_rel']) * ref_norm
     assert ops.planes_marked[0] > 50, 'the step did not run on the fp16-plane kernels'
     params = dict(model.net.named_parameters())
-    for k in grad_keys:
+    for k in keys:
         ref_g = sd[k].grad.double()                               # clipped in place by clip_grad_norm_ (model.py:326)
         got_g = (params[k].grad.double() * coef).cpu()
         assert got_g.shape == ref_g.shape, k
         amax = ref_g.abs().max().item()
         err = (got_g - ref_g).abs().max().item()
         cos = float((got_g * ref_g).sum() / (got_g.norm() * ref_g.norm()))
-        print('%s grad %-40s max|diff| %.3g = %.4f of |g|max %.3g   cos %.7f' % (tag, k, err, err / amax, amax, cos))
-        assert err <= GRAD_CAP * amax and cos > 0.999, (k, err, amax, cos)
+        # the bound of test_nets_gpu.py::test_train_steps_match_reference -- the oracle's own 1-vs-8-thread noise on this tensor (x 8), at least
+        # 2 % and at most GRAD_CAP of the tensor's largest entry -- but never tighter than 4 x that noise: with TWO tiles the 32^2 maps of
+        # layer4 / the ASPP hold 2048 pixels, one ReLU flip moves a filter gradient by per cents, and the reference differs from ITSELF by 4.8 %
+        # on layer4.2.conv2 and 2.7 % on the ASPP's d = 12 filter (tests/golden/truesize_conditioning.json).  The cosine bound stays.
+        c = cond['grads'][k]
+        tol = max(min(max(2e-2 * amax, 8 * c['cond_maxdiff']), GRAD_CAP * amax), 4 * c['cond_maxdiff'])
+        print('%s grad %-40s max|diff| %.3g = %.4f of |g|max %.3g (bound %.4f; oracle 1-vs-8 threads %.4f)   cos %.7f'
+              % (tag, k, err, err / amax, amax, tol / amax, c['cond_maxdiff'] / c['absmax'], cos))
+        assert err <= tol and cos > 0.999, (k, err, tol, amax, cos)
     d = (model.net.state_dict()[head_key].cpu() - sd[head_key].detach()).abs().max().item()
     print('%s post-AdamW max|diff| on %s = %.3g' % (tag, head_key, d))
     assert d < 2.5e-4                                                # lr 1e-4: one AdamW step moves an element by <= 1e-4 (+ decay)
@@ -104,20 +134,28 @@ def _check_train_step(model, cfg, w, x, y, grad_keys, head_key, tag):
         assert (new[k].cpu() - sd[k]).abs().max().item() < 1e-4 * max(1.0, sd[k].abs().max().item()), k
 
 
-def test_r101_512_bs2_step_against_oracle(dev):
-    model, cfg, w, x, y = _setup('deeplab', 'resnet', 9, 3, 2, 512, 11, dev, seed=71)
+@pytest.fixture
+def every_layer_on_planes():
+    """bs 2 puts the 32^2 maps of layer3 / layer4 / the ASPP at 2048 pixels, below the product's plane threshold (8192; at bs 32 they hold
+    32768): lower it so that every layer takes the kernel family it takes in the BASELINE configuration."""
+    from pylc_amd import ops
+    prev = ops.PLANES_MIN_PIXELS
+    ops.PLANES_MIN_PIXELS = 1024
+    yield
+    ops.PLANES_MIN_PIXELS = prev
+
+
+def test_r101_512_bs2_step_against_oracle(dev, every_layer_on_planes):
+    model, cfg, w, x, y = _setup('r101_512', dev)
     _check_eval(model, cfg, w, x, LOGIT_TOL, 'R101 512^2')
-    _check_train_step(model, cfg, w, x, y, R101_GRADS, 'decoder.last_conv.8.weight', 'R101 512^2')
+    _check_train_step(model, cfg, w, x, y, grad_keys('r101_512', w), 'decoder.last_conv.8.weight', 'R101 512^2', conditioning('r101_512'))
 
 
-def test_unet_512_bs1_step_against_oracle(dev):
-    model, cfg, w, x, y = _setup('unet', None, 9, 3, 1, 512, 12, dev, seed=73)
-    convs = [k for k, v in w.items() if k.endswith('weight') and v.dim() == 4]
-    bns = [k for k, v in w.items() if k.endswith('weight') and v.dim() == 1]
-    keys = [convs[0], convs[1], convs[len(convs) // 2], convs[-3], convs[-1], bns[0], bns[-1]]
-    err = _check_eval(model, cfg, w, x, LOGIT_TOL, 'U-Net 512^2')
-    assert err < LOGIT_TOL
-    _check_train_step(model, cfg, w, x, y, keys, convs[-1], 'U-Net 512^2')
+def test_unet_512_bs1_step_against_oracle(dev, every_layer_on_planes):
+    model, cfg, w, x, y = _setup('unet_512', dev)
+    keys = grad_keys('unet_512', w)
+    _check_eval(model, cfg, w, x, LOGIT_TOL, 'U-Net 512^2')
+    _check_train_step(model, cfg, w, x, y, keys, keys[4], 'U-Net 512^2', conditioning('unet_512'))
 
 
 @pytest.mark.parametrize('mode', [2, 3])
@@ -128,7 +166,7 @@ def test_xception_1024_gray_eval_against_oracle(dev, mode):
     prev = lib.pylc_get_conv_precision()
     check(lib.pylc_set_conv_precision(mode))
     try:
-        model, cfg, w, x, y = _setup('deeplab', 'xception', 11, 1, 1, 1024, 13, dev, seed=75)
+        model, cfg, w, x, y = _setup('xception_1024', dev)
         if mode == 2:
             _check_eval(model, cfg, w, x, LOGIT_TOL, 'Xception 1024^2 f16x3')
         else:
