@@ -650,20 +650,12 @@ int pylc_debug_set_big_tile(int mode);
  * 80-byte LDS rows and two stages instead of swizzled 64-byte rows and three; bit 8 (256): 32x32x16 instead of 16x16x32 MFMAs;
  * bit 12 (4096): ping-pong kernel walks the reduction with channel chunks innermost (the old order) instead of taps innermost;
  * bit 10 (1024): take the 256x128 tile even for launches of fewer than 192 tiles (tools/pp_stamps.py: a tile's phases with few
- * CUs active) */
+ * CUs active); bit 19 (524288): 1x1 launches stay on the per-tile kernel instead of the persistent one (conv_pl.hip gg_plp_kernel: the
+ * bit-identity reference of tests/test_planes_gpu.py, A/B tools/plp_ab.py); bits 20-22: grid / wait variants of that kernel (tools/plp_ab.py) */
 int pylc_debug_pp_flags(int flags);
 /* conv_pl.hip, 128-row tiles: start delay of the second block of every CU in the first round of blocks, in units of 2048 cycles
  * (< 0: the launch heuristic, about half a tile; 0: none) -- A/B knob for tools/pl_stagger_ab.py */
 int pylc_debug_stagger(int units);
-#ifdef PYLC_EXPERIMENTAL
-/* conv_p1.hip: 1 sends plain 1x1 / stride-1 launches to the persistent kernel whose stores leave under the next tile (off by default:
- * measured neutral inside the step) */
-int pylc_debug_p1(int on);
-/* conv_ps.hip: the specialised-wave persistent 1x1 kernel (loader waves + compute waves, one block per CU) for plain 1x1 / stride-1
- * launches (nn.Conv2d 1x1 forward / backward: resnet.py:21-26,92, aspp.py:64,67, decoder.py:27).  Bit 0: forward and plain dgrad launches;
- * bit 1: also the dgrads that add a ReLU-masked residual gradient (pylc_conv2d_dgrad_add).  A/B knob, env PYLC_PS. */
-int pylc_debug_ps(int on);
-#endif
 /* dwconv.hip, one-plane fp16 depthwise convs (A/B knob, env PYLC_DW_TILES; default 3): bit 0 = LDS-tiled kernels for stride 1 / dilation 1
  * (else the strip kernels), bit 1 = LDS-tiled kernels for stride 2 and for dilation 2 (else those shapes are not half-eligible) */
 int pylc_debug_dw_tiles(int on);

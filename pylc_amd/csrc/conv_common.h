@@ -219,12 +219,6 @@ int wgrad_pl_init();
 
 // conv_pl.hip: the gather-GEMM whose A operand arrives as fp16 planes (GatherGemmArgs::x_planes != nullptr)
 bool takes_pl(const GatherGemmArgs& a);
-bool takes_p1(const GatherGemmArgs& a);                // conv_p1.hip: plain 1x1 / stride-1 launches with at least a round of 128 x 128 tiles
-int launch_gg_p1(GatherGemmArgs& a, hipStream_t st);
-int conv_p1_init();
-bool takes_ps(const GatherGemmArgs& a);                // conv_ps.hip: the same launches on the specialised-wave persistent kernel (loader + compute waves)
-int launch_gg_ps(GatherGemmArgs& a, hipStream_t st);
-int conv_ps_init();
 int launch_gg_pl(GatherGemmArgs& a, hipStream_t st);
 int conv_pl_init();
 

@@ -1631,10 +1631,6 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 
 int conv_init() {
     if (int rc = conv_pl_init()) return rc;
-#ifdef PYLC_EXPERIMENTAL
-    if (int rc = conv_p1_init()) return rc;
-    if (int rc = conv_ps_init()) return rc;
-#endif
     if (int rc = wgrad_pl_init()) return rc;
 #define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \

@@ -587,16 +587,23 @@ __device__ __forceinline__ float pl_epilogue_lean_ep_half(const GatherGemmArgs& 
 // partials of M-tile `tile_m`.  rowoff[BM]: output element offsets of the tile's rows (-1: none); smem: free LDS for the statistics.
 // AM: 16-row fragments per wave along the pixel axis -- 4 (64 x 64 wave tiles, waves 2 wide) or 2 (32 x 64 wave tiles, every wave in the
 // first 64 columns: the NARROW launches for at most 64 output channels)
+// Returns the number of UNCONDITIONAL vector stores this wave issued last (the lean path's output stores: nothing but the conditional
+// statistics stores of the tail comes after them) -- what a persistent caller may leave in flight behind a counted vmcnt; 0 = no such promise.
 template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false, bool LEAN_RES = true>
-__device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
-                                            const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid, bool rows_full) {
+__device__ __forceinline__ int pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
+                                            const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid, bool rows_full,
+                                            const unsigned* ranges = nullptr) {
+    // ranges: {max|x| bits, max|w| bits} already in registers (the persistent kernel loads them ONCE: inside its tile loop every global load
+    // of the epilogue is a wait for the next tile's operand DMA, which is older in the in-order vmcnt); nullptr = read them here
     constexpr int BN = PL_BN, WM = 16 * AM, WN = 64, AT = 4;
     typedef f32x4v f32x4v_;
     // ---- epilogue (conv_igemm.hip's phased 16-byte epilogue: lookups and old values first, then arithmetic, then stores) ----
     float* sred = smem;             // [BM / WM][BN][2]
     const bool do_stats = a.stats != nullptr;
-    const float scale_a = a.amax_x ? pow2_scale_for(*a.amax_x) : 1.f;
-    const float scale_b = a.amax_w ? pow2_scale_for(*a.amax_w) : 1.f;
+    const unsigned ax_bits = ranges != nullptr ? ranges[0] : (a.amax_x ? *a.amax_x : 0u);
+    const unsigned aw_bits = ranges != nullptr ? ranges[1] : (a.amax_w ? *a.amax_w : 0u);
+    const float scale_a = a.amax_x ? pow2_scale_for(ax_bits) : 1.f;
+    const float scale_b = a.amax_w ? pow2_scale_for(aw_bits) : 1.f;
     const float unscale_a = pow2_inv(scale_a), unscale_b = pow2_inv(scale_b);      // exact (bit arithmetic; the IEEE division costs ~10 instructions each)
     float hscale = 1.f;                                  // out_half / out_planes2: the output leaves as one / two fp16 planes
     if (a.out_half || (EP && a.out_planes2)) {
@@ -607,7 +614,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             if (a.ep_scale_amax != nullptr) b = b * __uint_as_float(*a.ep_scale_amax) + __uint_as_float(*a.ep_shift_amax);
             if (a.ep_res_amax != nullptr) b += __uint_as_float(*a.ep_res_amax);
         } else {
-            b = a.out_bound_k * __uint_as_float(*a.amax_x) * __uint_as_float(*a.amax_w);
+            b = a.out_bound_k * __uint_as_float(ax_bits) * __uint_as_float(aw_bits);
         }
         hscale = pow2_scale_for(__float_as_uint(b));
         if (blockIdx.x == 0 && tid == 0) *a.out_bound = __float_as_uint(b);
@@ -625,6 +632,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     }
     // the lean path (above): a tile without an edge and without a combination the general path alone knows -- decided per wave
     bool done = false;
+    int tail_stores = 0;
     if constexpr (!EP && !BNB) {
         // (a bias vector holds N entries: with a bias the wave's 64 columns must lie inside N, not just inside the padded N_store; the
         //  one-plane output takes a bias only in the inference epilogue)
@@ -632,6 +640,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
         if ((a.bias == nullptr || ((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && !a.out_half)) && rows_full && cols_full && !(do_stats && extra != nullptr) && (NTERMS == 1 || !a.out_half) &&
             !(a.out_half && extra != nullptr) && !(a.dbg_flags & 8)) {
             done = true;
+            tail_stores = (PYLC_EPI_FULL_LINES != 0) ? (a.out_half ? 2 * AM : 4 * AM) : 0;      // whole-line stores: two per row fragment and column-group pair (fp32) / per row fragment (one plane)
             float* const sd = smem + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
             const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
             const float c = unscale_a * unscale_b;
@@ -924,7 +933,9 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
     }          // !BNB
     if (bn && a.bn_gmax != nullptr) amax_commit(gmax, a.bn_gmax);
     if (do_stats) {
-        __syncthreads();
+        // (not __syncthreads(): its fence drains vmcnt -- every output store of this tile, and in the persistent kernel the next tile's
+        //  operand DMA -- before the partials may be combined; only the LDS writes above have to be visible)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < BN) {
             const int n = n0 + tid;
             if (n < a.N_store) {
@@ -937,6 +948,7 @@ __device__ __forceinline__ void pl_epilogue(const GatherGemmArgs& a, f32x4v (&ac
             }
         }
     }
+    return tail_stores;
 }
 
 // STAMPS (tools/pl_stamps.py): lane 0 of the first and the last wave of block `dbg_flags >> 16` records s_memtime at the phase
@@ -1261,6 +1273,395 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions (any stride, no padding) on SHORT reductions: gg_pl_kernel's 128 x 128 tile as a PERSISTENT kernel.
+// -------------------------------------------------------------------------------------------------------------------------
+// A K = 256 tile of gg_pl_kernel spends 2.1 k cycles in front of its loop (geometry, the first operand round trip), 16.8 k in it, 8.6 k in
+// its epilogue and ~3 k leaving and being replaced (profiles/r05_stamps_1x1.txt): the two blocks of a CU are independent serial chains,
+// and 45 % of each chain is not the loop.  Here a block walks a strided share of the tiles as ONE stream of K-steps:
+//   * the operand DMA runs through tile boundaries -- the next tile's FIRST stage is requested at the top of this tile's last step (the
+//     ordinary one-step lead) and its SECOND stage right after the last step's barrier, BEFORE the epilogue, into the stage that step freed;
+//   * gfx9 counts loads, stores and LDS-DMA in ONE in-order vmcnt, so a wave cannot wait for an operand that is younger than its output stores
+//     without waiting for the stores -- but both of those stages are OLDER than the stores: the next tile's first two steps wait with
+//     vmcnt(<stores in flight>) and the stores have two K-steps to be acknowledged before the first younger DMA (step 2's) is waited for;
+//   * no block leaves, so nothing waits for a wave's stores at s_endpgm, for a dispatch, or for a prologue's dependent global round trip.
+// Same pieces, same MFMA order, same epilogue (pl_epilogue) as gg_pl_kernel<NTERMS, 128>: bit-identical results
+// (tests/test_planes_gpu.py::test_persistent_1x1_kernel_is_bit_identical).  T == 1 only: a tap mask would need a block barrier per tile.
+// The lean epilogue of an edge-free fp32-output tile in the ORDER the persistent kernel needs (same expressions per element and the same order
+// of additions as pl_epilogue_lean<4, STATS, PREV, false> + pl_epilogue's statistics tail: bit-identical):
+//   (1) row offsets from LDS, (2) every load of the residual-gradient source and its mask bits, (3) the BatchNorm statistics -- partials
+//   through LDS, combined, stored --, (4) `between()` = the caller's operand DMA for the next tile, (5) the output stores.
+// Why the order: hipcc puts a wait for every LDS-DMA in flight in front of an LDS access it cannot tell apart from the DMA's target, and a
+// wait for a load's data is a wait for everything older in gfx9's one in-order vmcnt.  With (1)-(3) in front of the DMA those waits find only
+// the previous step's DMA (long landed); behind it they would stand in the middle of the stores.  acc holds the FOLDED accumulators.
+template <int STATS, int PREV, typename Between, typename Stamp>
+__device__ __forceinline__ void plp_epilogue_lean(const GatherGemmArgs& a, f32x4v (&acc)[4][4], const int* rowoff, float* sred, int tile_m, int n0,
+                                                  int wave_m, int wave_n, int lane, int tid, float c, const float* extra, const unsigned char* amask,
+                                                  Between&& between, Stamp&& stamp) {
+    constexpr int AM = 4, AT = 4, WM = 64, WN = 64, BN = PL_BN, BM = 128;
+    const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
+    unsigned offs[AM], offsP[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i) {
+        offs[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nb);
+        offsP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nb);
+    }
+    const bool upper = (lane & 8) != 0;
+    f32x4v la[PREV ? 2 : 1][PREV ? AM : 1], lb[PREV ? 2 : 1][PREV ? AM : 1];
+    uint2 mw[PREV == 2 ? AM : 1];            // the 64 mask bits of this lane's pixel row and the wave's 64 channels: ONE 8-byte load per row (the bytes (offs + 16 j) >> 3, j = 0..3, lie in one aligned 8-byte word: dense rows of a multiple of 128 channels)
+    if constexpr (PREV != 0) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const unsigned col = (upper ? 2 * jp + 1 : 2 * jp) * 16;
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                la[jp][i] = *reinterpret_cast<const f32x4v*>(extra + ((upper ? offsP[i] : offs[i]) + col));      // rows 0-7 of the fragment
+                lb[jp][i] = *reinterpret_cast<const f32x4v*>(extra + ((upper ? offs[i] : offsP[i]) + col));      // rows 8-15
+            }
+        }
+        if constexpr (PREV == 2) {
+#pragma unroll
+            for (int i = 0; i < AM; ++i) mw[i] = *reinterpret_cast<const uint2*>(amask + (((offs[i] - 4u * (unsigned)(lane >> 4)) >> 3)));
+        }
+    }
+    if constexpr (STATS != 0) {
+        float* const sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
+#pragma unroll
+        for (int j = 0; j < AT; ++j) {
+            f32x4v cs = {0.f, 0.f, 0.f, 0.f}, css = cs;
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                const f32x4v t = acc[i][j];
+                cs = i == 0 ? t : epi_add(cs, t);
+                css = i == 0 ? epi_sq(t) : epi_add(css, epi_sq(t));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r] * c; sdst[(j * 16 + r) * 2 + 1] = css[r] * c * c; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < BN) {
+            const int n = n0 + tid;
+            if (n < a.N_store) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
+                float* dst = a.stats + (size_t)tile_m * 2 * a.N_store;
+                dst[n] = sm;
+                dst[a.N_store + n] = sq;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    f32x4v hold[AM];
+#pragma unroll
+    for (int j = 0; j < AT; ++j) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            f32x4v v = epi_mul(acc[i][j], c);                       // (fma(t, c, 0) == t c: a power of two, exact)
+            if constexpr (PREV != 0) {
+                f32x4v prev;
+                if ((j & 1) == 0) {
+                    // the whole-line loads' swap (pl_epilogue_lean): lanes l / l ^ 8 hand each other the column group that belongs to the other
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float send = upper ? la[j >> 1][i][r] : lb[j >> 1][i][r];
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));
+                        prev[r] = upper ? recv : la[j >> 1][i][r];          // this lane's even group
+                        la[j >> 1][i][r] = upper ? lb[j >> 1][i][r] : recv;  // ... and its odd group, kept for the next column group
+                    }
+                } else {
+                    prev = la[j >> 1][i];
+                }
+                if constexpr (PREV == 2) {
+                    // element (row i, channel 16 j + 4 (lane >> 4) + r of the wave's 64) = bit 16 j + 4 (lane >> 4) + r of the row's word: the same bit
+                    // pl_epilogue_lean takes from byte (offs + 16 j) >> 3, nibble ((offs + 16 j) >> 2) & 1
+                    const int nib = (int)(((j < 2) ? mw[i].x : mw[i].y) >> (16u * (unsigned)(j & 1) + 4u * (unsigned)(lane >> 4)));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) prev[r] = __uint_as_float(__float_as_uint(prev[r]) & (unsigned)__builtin_amdgcn_sbfe(nib, r, 1));
+                }
+                v = epi_add(v, prev);
+            }
+            if ((j & 1) == 0) {
+                hold[i] = v;
+            } else {
+                f32x4v recv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float send = upper ? hold[i][r] : v[r];
+                    recv[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));
+                }
+                const unsigned col = (upper ? j : j - 1) * 16;
+                f32x4v da, db;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { da[r] = upper ? recv[r] : hold[i][r]; db[r] = upper ? v[r] : recv[r]; }
+                *reinterpret_cast<f32x4v*>(a.y + ((upper ? offsP[i] : offs[i]) + col)) = da;      // rows 0-7 of the fragment, 128 B each
+                *reinterpret_cast<f32x4v*>(a.y + ((upper ? offs[i] : offsP[i]) + col)) = db;      // rows 8-15
+            }
+        }
+    }
+}
+
+template <int NTERMS>
+constexpr int plp_lds_bytes() { return 2 * pl_stage_bytes<NTERMS, 128>() + 4 * 128 * 4 + 2 * PL_BN * 2 * 4 + 64; }
+
+// s_waitcnt vmcnt(n) with the other counters left alone, as the BUILTIN (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4],
+// lgkmcnt [11:8]): hipcc's wait-count pass reads it, so it knows what is still in flight -- behind an inline-asm wait it assumed the LDS-DMA
+// of the previous step pending and put its own vmcnt(0) in front of the next LDS read
+#define PLP_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+__device__ __forceinline__ void plp_wait_vm(int n) {
+    // (the immediate must be a constant; every value pl_epilogue can return for AM = 4)
+    if (n >= 16) PLP_VMCNT(16);
+    else if (n >= 8) PLP_VMCNT(8);
+    else PLP_VMCNT(0);
+}
+
+// EPK: the ONE lean epilogue this instantiation holds -- 0 plain, 1 + BatchNorm statistics, 2 + residual-gradient source, 3 + ... under the 1-bit
+// mask -- chosen by the host (it is a property of the launch).  One kernel with all four was measured first: hipcc's wait-count pass merges
+// the pending-load state of the paths that load a residual into the paths that load nothing, and protected registers with vmcnt waits
+// between the DMA and the stores of EVERY path and in front of the next tile's first writes (the stores were waited for after all).
+// STAMPS (tools/plp_stamps.py): lane 0 of waves 0 and 3 of block `dbg_flags >> 16` keeps s_memtime stamps in LDS -- written by inline asm, which
+// hipcc's wait-count pass does not see: a C++ store to LDS behind an LDS-DMA gets a vmcnt wait of its own -- and dumps them to a.dbg at the end.
+template <int NTERMS, int EPK, bool STAMPS = false>
+__global__ __launch_bounds__(256, 2) void gg_plp_kernel(const GatherGemmArgs a) {
+    constexpr int BM = 128, BN = PL_BN, AM = 4, WM = 64, WN = 64, AT = 4, ROW = pl_row_bytes<NTERMS>();
+    constexpr int KS = ROW / 2, RPI = 1024 / ROW, NW = 4, AI = 32 / RPI, BI = BN / (RPI * NW), NPL = NTERMS == 3 ? 2 : 1;
+    constexpr int STAGE = pl_stage_bytes<NTERMS, BM>();
+    constexpr int OFF_B = NPL * BM * ROW;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // ONE LDS object (a second one makes hipcc drain the DMA early)
+    char* lds = reinterpret_cast<char*>(smem);
+    // [4][BM] output row tables, by tile sequence number & 3: with two-step tiles the table of tile k + 1 is written (when the last DMA of tile k
+    // goes out) BEFORE the epilogue of tile k - 1 has read its own
+    int* const rowoff4 = reinterpret_cast<int*>(lds + 2 * STAGE);
+    float* const sred = reinterpret_cast<float*>(lds + 2 * STAGE + 4 * BM * 4);                // [BM / WM][BN][2] statistics partials (its own room: the stages never rest)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const bool stamper = STAMPS && (int)blockIdx.x == (a.dbg_flags >> 16) && lane == 0 && (wave == 0 || wave == 3);
+    unsigned stamp_at = (unsigned)(uintptr_t)(lds_vptr)(lds + plp_lds_bytes<NTERMS>() + (wave != 0) * 2048);      // LDS byte address of the next stamp
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if constexpr (STAMPS) {
+            if (stamper && n_stamp < 250) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                asm volatile("ds_write_b64 %0, %1" :: "v"(stamp_at), "v"(t) : "memory");
+                stamp_at += 8;
+                ++n_stamp;
+            }
+        }
+    };
+    stamp();
+    if (a.stagger > 0) {                                            // de-phase the two blocks of a CU once (gg_pl_kernel)
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);
+        if (lds_base != 0)
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    const int lrow = ROW == 64 ? lane >> 2 : lane >> 3;
+    const int lc = ROW == 64 ? (lane & 3) ^ (((lane >> 4) & 1) << 1) : ((lane & 4) | ((lane & 3) ^ ((lane >> 4) & 3)));
+    const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);
+    const bool ila = NPL == 2 && planes_il(a.x_plane_stride);
+    const unsigned ilma = (unsigned)__builtin_amdgcn_readfirstlane(ila ? 2 : 1);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * ilma), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(a.x_bytes * ilma - (ila ? 64 : 0)), 0x00020000);
+    const unsigned plane1_w = a.w_il ? 64u : (unsigned)(a.w_plane_stride * 2);
+    const int S = (a.Cin + KS - 1) / KS;                             // K-steps per tile (>= 2: launch_gg_pl)
+    const int n_tiles = a.n_tiles, G = (int)gridDim.x;
+
+    // ---- the LOAD side: operand rows of the tile whose DMA is being issued (runs up to two steps ahead of the tile being multiplied).
+    //      launch_gg_pl sends only launches without an edge here (M % 128 == 0, N_store % 128 == 0) whose input pixel IS the output pixel ----
+    unsigned woff_row[BI], xoff[AI];
+    int ld_v = (int)blockIdx.x, ld_k = 0, ld_chunk = 0;              // virtual block id, sequence number and K-chunk of the next DMA
+    auto setup_load = [&]() {
+        const int tile = xcd_remap(ld_v, n_tiles);
+        const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int n = n0 + RPI * BI * wave + RPI * i + lrow;
+            const unsigned lcb = a.w_il ? ((unsigned)(lc >> 2) * 128u + (unsigned)(lc & 3) * 16u) : 16u * lc;
+            woff_row[i] = n < a.N ? (unsigned)n * (unsigned)a.w_row_stride * ilmb * 2u + lcb : OOB;      // (N may be below N_store: pad channels fetch zeros)
+        }
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = m0 + 32 * wave + RPI * i + lrow;
+            xoff[i] = ((unsigned)m * (unsigned)a.x_pitch * ilma + 8u * lc) * 2u;
+        }
+        if (tid < BM) rowoff4[(ld_k & 3) * BM + tid] = (m0 + tid) * a.y_pitch;      // the tile's output row table (read by ITS epilogue, at least two barriers from here)
+    };
+    char* const dstA = lds + (32 * wave) * ROW;
+    char* const dstB = lds + OFF_B + (RPI * BI * wave) * ROW;
+    // the next DMA of the stream into `stage`; false once the block's share of the tiles is exhausted
+    auto issue = [&](int stage) -> bool {
+        if (ld_v >= n_tiles) return false;
+        const bool cok = ld_chunk * KS + 8 * lc < a.Cin;
+        const unsigned tapdelta = (unsigned)(ld_chunk * KS * 2) * ilma;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((a.w_off0 + ld_chunk * KS) * 2) * ilmb));
+        char* const sa = dstA + stage * STAGE;
+        char* const sb = dstB + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const unsigned vo = cok ? xoff[i] + tapdelta : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)(sa + RPI * i * ROW), 16, vo, 0, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(sa + BM * ROW + RPI * i * ROW), 16, vo, 0, 0, 0);
+        }
+        const unsigned oob = (unsigned)(a.Cin - 1 - (ld_chunk * KS + 8 * lc)) & OOB;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const unsigned vo = woff_row[i] | oob;
+            const unsigned vo1 = (woff_row[i] + plane1_w) | oob | (woff_row[i] & OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + RPI * i * ROW), 16, vo, so, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(sb + BN * ROW + RPI * i * ROW), 16, vo1, so, 0, 0);
+        }
+        if (++ld_chunk == S) {             // the stream moves on to the block's next tile
+            ld_chunk = 0;
+            ld_v += G;
+            ++ld_k;
+            if (ld_v < n_tiles) setup_load();
+        }
+        return true;
+    };
+    const int koff = ROW == 64 ? 16 * ((lane >> 4) ^ (((lane >> 2) & 1) << 1)) : 16 * ((lane >> 4) ^ ((lane >> 1) & 3));
+    const char* const ra_base = lds + (wave_m * WM + (lane & 15)) * ROW + koff;
+    const char* const rb_base = lds + OFF_B + (wave_n * WN + (lane & 15)) * ROW + koff;
+
+    f32x4v acc[AM][AT];
+    f32x4v acc_lo[NTERMS == 3 ? AM : 1][NTERMS == 3 ? AT : 1];
+    auto compute = [&](int stage) {
+#pragma unroll
+        for (int u = 0; u < KS / 32; ++u) {
+            const char* pa = ra_base + stage * STAGE + 64 * u;
+            const char* pb = rb_base + stage * STAGE + 64 * u;
+            f16x8 fb[AT][NPL];
+#pragma unroll
+            for (int j = 0; j < AT; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                f16x8 fa[NPL];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
+#pragma unroll
+                for (int j = 0; j < AT; ++j) {
+                    if constexpr (NTERMS == 3) {
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const unsigned ranges[2] = {a.amax_x ? *a.amax_x : 0u, a.amax_w ? *a.amax_w : 0u};      // once: inside the tile loop every global load is a wait for the next tile's operand DMA
+    const float c_unscale = pow2_inv(a.amax_x ? pow2_scale_for(ranges[0]) : 1.f) * pow2_inv(a.amax_w ? pow2_scale_for(ranges[1]) : 1.f);
+    setup_load();
+    issue(0);
+    // ONE loop over the block's K-steps (tile boundaries are a branch inside it: a nested loop gets its first iteration peeled, and the
+    // peeled copy came with a compiler-made vmcnt(0) between its LDS reads -- a wait for the previous tile's stores in every tile).
+    // State that crosses a boundary:
+    //   soft_waits  steps from now whose operands are OLDER than the stores in flight (requested before the previous epilogue)
+    //   skip_issue  steps from now that request nothing (their successor's operands are already on their way)
+    const int my_tiles = (n_tiles - 1 - (int)blockIdx.x) / G + 1;
+    const int total = my_tiles * S;
+    int stores_in_flight = 0, soft_waits = 0, skip_issue = 0;
+    int v = (int)blockIdx.x, k = 0, s = 0;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int j = 0; j < AT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+                }
+    };
+    zero_acc();
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < total; ++g) {       // global K-step of this block: its operands live in stage g & 1
+        // this wave's share of step g must have landed
+        stamp();
+        if (soft_waits > 0) { plp_wait_vm(stores_in_flight); --soft_waits; }
+        else PLP_VMCNT(0);
+        if constexpr (STAMPS) { __builtin_amdgcn_sched_barrier(0); stamp(); }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        if (skip_issue > 0) --skip_issue;
+        else issue((g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp();
+        compute(g & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++s == S) {
+            // ---- tile boundary.  Every wave is done reading this step's stage once it is past the barrier: the stage takes the stream's next
+            //      DMA -- the next tile's SECOND step (its first went out at the top of this step) -- before the epilogue puts its stores into
+            //      the counter
+            s = 0;
+            stamp();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            const int tile = xcd_remap(v, n_tiles);
+            const int n0 = (tile % a.tiles_n) * BN;
+            bool pre2 = false;
+            if constexpr (NTERMS == 3) {
+#pragma unroll
+                for (int i = 0; i < AM; ++i)
+#pragma unroll
+                    for (int j = 0; j < AT; ++j) acc[i][j] = epi_fma(acc_lo[i][j], 1.f / 2048.f, acc[i][j]);
+            }
+            auto between = [&]() { pre2 = issue(g & 1); };
+            plp_epilogue_lean<EPK == 1 ? 1 : 0, EPK >= 2 ? EPK - 1 : 0>(a, acc, rowoff4 + (k & 3) * BM, sred, tile / a.tiles_n, n0, wave_m, wave_n, lane, tid, c_unscale,
+                                                                         a.add_src != nullptr ? a.add_src : a.y, a.add_mask, between, stamp);
+            stamp();
+            // (true already -- the 16 stores are this wave's youngest operations -- but said to hipcc's wait-count pass in its own terms)
+            PLP_VMCNT(16);
+            stores_in_flight = 16;
+            __builtin_amdgcn_sched_barrier(0);
+            zero_acc();
+            v += G;
+            ++k;
+            soft_waits = (pre2 && !(a.dbg_flags & 2097152)) ? 2 : 0;      // (bit 21: wait for everything at every step -- A/B)
+            skip_issue = pre2 ? 1 : 0;
+        }
+    }
+    if constexpr (STAMPS) {
+        stamp();
+        PLP_VMCNT(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (stamper && a.dbg != nullptr) {
+            const unsigned long long* sb = reinterpret_cast<const unsigned long long*>(lds + plp_lds_bytes<NTERMS>() + (wave != 0) * 2048);
+            for (int q = 0; q < 256; ++q) a.dbg[(wave != 0) * 256 + q] = q < n_stamp ? sb[q] : 0ull;
+        }
+    }
+}
+
+template __global__ void gg_plp_kernel<3, 0>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<3, 0, true>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<3, 1, true>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<3, 1>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<3, 2>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<3, 3>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<1, 0>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<1, 1>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<1, 2>(const GatherGemmArgs);
+template __global__ void gg_plp_kernel<1, 3>(const GatherGemmArgs);
+
+// -------------------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / dilation 1 with the input HALO kept in LDS.
 // -------------------------------------------------------------------------------------------------------------------------
 // gg_pl_kernel re-fetches a pixel-row tile for each of the nine taps: per channel chunk 9 x (32 + 16) KB of operand DMA for a
@@ -1536,10 +1937,7 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
                  "conv dgrad with a masked residual source needs a dense output (pitch == channels, channels %% 8 == 0) and no accumulation");
     PYLC_REQUIRE(a.bn_y == nullptr || (a.y_pitch == a.N_store && a.stats != nullptr && a.bn_mean && a.bn_invstd && (!a.bn_relu || a.bn_mask || (a.bn_scale && a.bn_shift))),
                  "conv dgrad with BatchNorm-backward sums needs a dense output, a partials buffer, mean / invstd and a mask source");
-#ifdef PYLC_EXPERIMENTAL
-    if (!(g_pp_flags & (2048 | 8192)) && takes_ps(a)) return launch_gg_ps(a, st);      // 1x1: loader waves + compute waves, one persistent block per CU
-    if (!(g_pp_flags & (2048 | 8192)) && a.add_src == nullptr && a.bn_y == nullptr && !a.out_half && takes_p1(a)) return launch_gg_p1(a, st);     // 1x1: the persistent kernel whose stores leave under the next tile's main loop
-#else
+#ifndef PYLC_EXPERIMENTAL
     PYLC_REQUIRE(a.bn_y == nullptr, "conv dgrad with BatchNorm-backward sums: this library was built without EXPERIMENTAL=1");
 #endif
     // Tile height.  256 rows: 25 % fewer operand bytes per MFMA and a two-step DMA lead, but one block per CU (nothing hides a
@@ -1591,6 +1989,32 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
         a.stagger = (int)(cycles / 2048);
         if (g_stagger >= 0) a.stagger = g_stagger;   // A/B knob (pylc_debug_stagger)
     }
+    // 1x1 convs on 128-row tiles with more tiles than the chip holds blocks: the persistent form (gg_plp_kernel) -- plain launches only
+    // (no narrow / inference / BatchNorm-backward / stamped variant), no padding (the one tap of every valid row lies inside the input),
+    // at least two K-steps per tile.  pylc_debug_pp_flags bit 19 (524288): the per-tile kernel (A/B, bit-identity reference)
+    const bool ep_any = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;
+    const int ks_tile = a.nterms == 1 ? 64 : 32;
+    const float* extra_src = a.add_src != nullptr ? a.add_src : (a.accumulate ? a.y : nullptr);
+    if (!big && !(g_pp_flags & 524288) && a.ident && n_tiles > 2 * kNumCU && !ep_any && a.bn_y == nullptr && (a.dbg == nullptr || a.nterms == 3) &&
+        !(a.dbg_flags & (8 | 64 | 128)) && cdiv(a.Cin, ks_tile) >= 2 &&
+        // every tile is a lean tile: no edge, fp32 output, no bias, statistics XOR a residual source
+        a.M % 128 == 0 && a.N_store % PL_BN == 0 && a.bias == nullptr && !a.out_half && !(a.stats != nullptr && extra_src != nullptr) && PYLC_EPI_FULL_LINES != 0 &&
+        (long long)a.M * a.y_pitch < (1ll << 31) && (a.add_mask == nullptr || (a.y_pitch == a.N_store && (reinterpret_cast<uintptr_t>(a.add_mask) & 7) == 0))) {
+        const unsigned grid = (g_pp_flags & 1048576) ? (unsigned)n_tiles : ((g_pp_flags & 4194304) ? 3 * kNumCU : 2 * kNumCU);      // (bit 20: one tile per block -- the loop and epilogue code alone; bit 22: 768 blocks)
+        const int epk = extra_src != nullptr ? (a.add_mask != nullptr ? 3 : 2) : (a.stats != nullptr ? 1 : 0);
+#define PYLC_PLP(NT, E) hipLaunchKernelGGL((gg_plp_kernel<NT, E>), dim3(grid), dim3(256), plp_lds_bytes<NT>(), st, a)
+        if (a.dbg != nullptr && epk <= 1) {          // stamped build (tools/plp_stamps.py)
+            if (epk == 0) hipLaunchKernelGGL((gg_plp_kernel<3, 0, true>), dim3(grid), dim3(256), plp_lds_bytes<3>() + 4096, st, a);
+            else hipLaunchKernelGGL((gg_plp_kernel<3, 1, true>), dim3(grid), dim3(256), plp_lds_bytes<3>() + 4096, st, a);
+            PYLC_LAUNCH_CHECK();
+            return PYLC_OK;
+        }
+        if (a.nterms == 1) { if (epk == 0) PYLC_PLP(1, 0); else if (epk == 1) PYLC_PLP(1, 1); else if (epk == 2) PYLC_PLP(1, 2); else PYLC_PLP(1, 3); }
+        else { if (epk == 0) PYLC_PLP(3, 0); else if (epk == 1) PYLC_PLP(3, 1); else if (epk == 2) PYLC_PLP(3, 2); else PYLC_PLP(3, 3); }
+#undef PYLC_PLP
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     if (a.nterms == 1) {
         if (big) launch_pl<1, 256>(a, (unsigned)n_tiles, st); else launch_pl<1, 128>(a, (unsigned)n_tiles, st);
     } else {
@@ -1612,6 +2036,16 @@ int conv_pl_init() {
     PYLC_HIP(opt_in(gg_pl_kernel<1, 256>, pl_lds_bytes<1, 256>()));
     PYLC_HIP(opt_in(gg_plh_kernel<3>, plh_lds_bytes<3>()));
     PYLC_HIP(opt_in(gg_plh_kernel<1>, plh_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 0>), plp_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 0, true>), plp_lds_bytes<3>() + 4096));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 1, true>), plp_lds_bytes<3>() + 4096));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 1>), plp_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 2>), plp_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<3, 3>), plp_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<1, 0>), plp_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<1, 1>), plp_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<1, 2>), plp_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_plp_kernel<1, 3>), plp_lds_bytes<1>()));
 #ifdef PYLC_EXPERIMENTAL
     PYLC_HIP(opt_in((gg_pl_kernel<3, 128, false, true>), pl_lds_bytes<3, 128>()));
     PYLC_HIP(opt_in((gg_pl_kernel<3, 256, false, true>), pl_lds_bytes<3, 256>()));

@@ -83,7 +83,6 @@ SIGNATURES = {
     'pylc_debug_set_big_tile': (_I, [_I]),
     'pylc_debug_pp_flags': (_I, [_I]),
     'pylc_debug_stagger': (_I, [_I]),
-    'pylc_debug_p1': (_I, [_I]),
     'pylc_debug_wgrad_flags': (_I, [_I]),
     'pylc_debug_wgrad_max_steps': (_I, [_I]),
     'pylc_comm_available': (_I, []),
@@ -92,7 +91,6 @@ SIGNATURES = {
     'pylc_comm_allreduce': (_I, [_P, _P, _LL, _I, _P]),
     'pylc_comm_syncbn_reduce': (_I, [_P, _P, _I, _P]),
     'pylc_comm_destroy': (_I, [_P]),
-    'pylc_debug_ps': (_I, [_I]),
     'pylc_debug_dw_tiles': (_I, [_I]),
     'pylc_range_product': (_I, [_P, _P, _F, _P, _P, _P]),
     'pylc_maxpool_fwd_planes': (_I, [_P, _P, _LL, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -205,7 +203,7 @@ SIGNATURES = {
 # entry points that exist only in a library built with `make EXPERIMENTAL=1` (include/pylc_hip.h: #ifdef PYLC_EXPERIMENTAL): what was
 # measured neutral or negative and is off in the product -- the persistent 1x1 kernels, the dgrad epilogue that takes BatchNorm-backward
 # sums, CU-masked streams.  HAS_EXPERIMENTAL tells the callers (and the tests, which skip without it).
-EXPERIMENTAL = ('pylc_debug_p1', 'pylc_debug_ps', 'pylc_conv2d_dgrad_bn_floats', 'pylc_conv2d_dgrad_bn', 'pylc_bn_bwd_sums_from_partial',
+EXPERIMENTAL = ('pylc_conv2d_dgrad_bn_floats', 'pylc_conv2d_dgrad_bn', 'pylc_bn_bwd_sums_from_partial',
                 'pylc_stream_create_cu_mask', 'pylc_stream_destroy')
 HAS_EXPERIMENTAL = False
 
@@ -259,9 +257,6 @@ def init():
             lib.pylc_debug_pp_flags(int(flags))
         if os.environ.get('PYLC_WGRAD_ACC1') is not None:     # 1: one-accumulator 128x128 wgrad under 128 registers (A/B)
             lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
-        if os.environ.get('PYLC_P1') is not None:        # 1: plain 1x1 launches on the persistent kernel of conv_p1.hip (A/B)
-            _need_experimental('PYLC_P1')
-            lib.pylc_debug_p1(int(os.environ['PYLC_P1']))
         if os.environ.get('PYLC_NO_PLANE_INTERLEAVE'):           # two-plane activations as separate plane arrays (A/B; the round-4 format)
             lib.pylc_set_planes_interleave(0)
         if os.environ.get('PYLC_WG_SETS') is not None:            # wgrad operand staging sets: 0 one, 1 two for multi-tap filters, 2 two always (A/B)
@@ -274,9 +269,6 @@ def init():
             lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
         if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)
             lib.pylc_debug_wgrad_max_steps(int(os.environ['PYLC_WG_MAX_STEPS']))
-        if os.environ.get('PYLC_PS') is not None:        # bit 0: plain 1x1 launches on the specialised-wave kernel of conv_ps.hip, bit 1: + masked-residual dgrads
-            _need_experimental('PYLC_PS')
-            lib.pylc_debug_ps(int(os.environ['PYLC_PS']))
         if os.environ.get('PYLC_DW_TILES') is not None:  # 0: half depthwise convs on the strip kernels (A/B)
             lib.pylc_debug_dw_tiles(int(os.environ['PYLC_DW_TILES']))
         _initialised = True

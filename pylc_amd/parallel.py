@@ -164,8 +164,31 @@ def try_native_comm(rank, world):
         handles.append(handle)
         if not _agree(ok, world):
             return give_up('communicator %d' % i)
+    # 3. the first message: a SUM of ones over each communicator, on the stream the product uses, checked on the host.  A communicator that
+    #    came up but cannot carry a message (or carries a wrong one) is found HERE, where falling back is still possible -- not in step 1
+    ok = 1
+    try:
+        _comm_first_message(handles, world)
+    except Exception as e:
+        ok, why = 0, '%s: %s' % (type(e).__name__, e)
+    if not _agree(ok, world):
+        return give_up('first message')
     runtime.comm, runtime.grad_comm = handles[0], handles[-1]
     return True
+
+
+def _comm_first_message(handles, world):
+    """All-reduce [1, 2] (fp32) and [1] (fp64) over every communicator and check the sums: what SyncBN, the loss head and the buckets send."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for h in {id(h): h for h in handles}.values():
+        a = torch.tensor([1.0, 2.0], dtype=torch.float32, device=dev)
+        b = torch.ones(1, dtype=torch.float64, device=dev)
+        runtime.native_all_reduce(a, h)
+        runtime.native_all_reduce(b, h)
+        torch.cuda.synchronize()
+        got = a.cpu().tolist() + b.cpu().tolist()
+        if got != [float(world), 2.0 * world, float(world)]:
+            raise RuntimeError('first all-reduce over the native communicator returned %s for world size %d' % (got, world))
 
 
 def init_native_comm(rank, world):

@@ -152,13 +152,17 @@ def fake_init(fail_rank, fail_at):
 def boom(*a):
     raise RuntimeError('librccl.so.1 not loadable (test)')
 P.n_native_comms = lambda: 2
+first_msg = [None]
+P._comm_first_message = lambda handles, world: first_msg[0] and first_msg[0]()
 P._comm_destroy = destroyed.append
 for case, avail, uid, init, want in (
         ('all good', lambda: None, lambda: bytes(range(1, 129)), fake_init(-1, 0), True),
         ('rank 0 cannot load RCCL', (boom if rank == 0 else (lambda: None)), lambda: bytes(range(1, 129)), fake_init(-1, 0), False),
         ('last rank cannot load RCCL', (boom if rank == world - 1 else (lambda: None)), lambda: bytes(range(1, 129)), fake_init(-1, 0), False),
         ('rank 0 cannot make the id', lambda: None, boom, fake_init(-1, 0), False),
-        ('last rank fails its second ncclCommInitRank', lambda: None, lambda: bytes(range(1, 129)), fake_init(world - 1, 1), False)):
+        ('last rank fails its second ncclCommInitRank', lambda: None, lambda: bytes(range(1, 129)), fake_init(world - 1, 1), False),
+        ('rank 0 reads a wrong first message', lambda: None, lambda: bytes(range(1, 129)), fake_init(-1, 0), False)):
+    first_msg[0] = boom if (case.startswith('rank 0 reads') and rank == 0) else None
     del made[:], destroyed[:]
     runtime.comm = runtime.grad_comm = None
     P._comm_available, P._comm_unique_id, P._comm_init = avail, uid, init

@@ -474,6 +474,7 @@ def test_native_comm_falls_back_with_a_logged_reason(monkeypatch, capsys):
     monkeypatch.setattr(parallel, '_comm_unique_id', lambda: bytes(range(1, 129)))
     monkeypatch.setattr(parallel, '_comm_init', init)
     monkeypatch.setattr(parallel, '_comm_destroy', destroyed.append)
+    monkeypatch.setattr(parallel, '_comm_first_message', lambda handles, world: None)
     assert parallel.try_native_comm(0, 1) is False
     assert runtime.comm is None and runtime.grad_comm is None and destroyed == made and len(made) == 1
     err = capsys.readouterr().err

@@ -9,18 +9,18 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from tests.conftest import needs_experimental      # noqa: E402
 
 
-@pytest.fixture
-def separate_planes(monkeypatch):
-    """The round-4 plane format for one test: separate filter planes (env, read when the arena prepares them) and separate pixel planes
-    (pylc_set_planes_interleave is process-wide: restored afterwards) -- what the experimental 1x1 kernels read (takes_p1 / takes_ps)."""
+@pytest.fixture(params=['interleaved', 'separate'])
+def plane_format(request, monkeypatch):
+    """Both plane formats for one test: the product's chunk-interleaved planes, and the round-4 format -- separate filter planes (env, read when
+    the arena prepares them) and separate pixel planes (pylc_set_planes_interleave is process-wide: restored afterwards)."""
     import os
     from pylc_amd.lib import lib
-    monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')
-    lib.pylc_set_planes_interleave(0)
-    yield
+    if request.param == 'separate':
+        monkeypatch.setenv('PYLC_NO_FILTER_INTERLEAVE', '1')
+        lib.pylc_set_planes_interleave(0)
+    yield request.param
     lib.pylc_set_planes_interleave(0 if os.environ.get('PYLC_NO_PLANE_INTERLEAVE') else 1)
 
 
@@ -268,16 +268,20 @@ def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
     assert max(e) < 1e-3, e
 
 
-@needs_experimental()
-@pytest.mark.parametrize('shape', [(2, 64, 256, 1024), (2, 64, 1024, 256), (1, 128, 64, 256), (2, 70, 256, 48), (1, 96, 72, 200)])
+PERSIST_OFF = 524288          # pylc_debug_pp_flags bit 19: 1x1 launches on the per-tile kernel (the bit-identity reference of gg_plp_kernel)
+
+
+@pytest.mark.parametrize('shape', [(16, 64, 256, 1024), (16, 64, 1024, 256), (8, 128, 64, 256), (24, 64, 128, 512), (16, 64, 96, 256), (20, 64, 256, 1024)])
 @pytest.mark.parametrize('mode', [2, 3])
-def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, separate_planes):
-    """conv_p1.hip (off by default: pylc_debug_p1): the persistent 1x1 kernel whose finished tile is stored under the next tile's main
-    loop -- output bit-identical to the per-tile kernel, run twice (the counted vmcnt of its main loop depends on every store being
-    issued: masked rows / channel quads, here Cout = 48 and ragged M, must not change the count), BatchNorm statistics equal to sums
-    over the output."""
+def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, plane_format):
+    """conv_pl.hip gg_plp_kernel: 1x1 / stride-1 launches without an edge and with more 128 x 128 tiles than the chip holds blocks run as ONE
+    stream of K-steps per block -- the next tile's first two operand stages requested before this tile's stores, which then stay in flight
+    behind a counted vmcnt.  Forward (+ BatchNorm statistics partials), plain dgrad, dgrad + residual source and dgrad + masked residual
+    source: every output bit-identical to the per-tile kernel (pylc_debug_pp_flags bit 19), run twice; tile counts that are not a multiple of
+    the 512 blocks (640, 768: some blocks walk one tile more), two K-steps per tile (Cin = 64), an odd number of K-steps (Cin = 96)."""
+    import ctypes as C
     from pylc_amd import ops, layers, optim
-    from pylc_amd.lib import lib, check
+    from pylc_amd.lib import lib, check, ptr, stream
     B, H, cin, cout = shape
     prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
     check(lib.pylc_set_conv_precision(mode))
@@ -288,82 +292,62 @@ def test_persistent_1x1_kernel_is_bit_identical(dev, shape, mode, separate_plane
         arena = optim.FlatArena(conv)
         x = nhwc(rnd(31, B, cin, H, H, scale=2.0), dev)
         xp = ops.to_planes(x)
-        lib.pylc_debug_pp_flags(1024 | 2048 | 16384)         # the 128-row per-tile kernel as the reference (same statistics rows)
-        outs = []
-        with torch.no_grad():
-            for on in (0, 1, 1):
-                lib.pylc_debug_p1(on)
-                lib.pylc_debug_pp_flags((1024 | 2048 | 16384) if on == 0 else 0)
-                y = ops.conv2d(xp, conv.weight, None, 1, 0, 1, want_stats=True)
-                torch.cuda.synchronize()
-                outs.append((y.clone(), y._pylc_sums.clone()))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
-        assert torch.equal(outs[1][1], outs[2][1])
-        if outs[0][1].shape == outs[1][1].shape:
-            assert torch.equal(outs[0][1], outs[1][1])
-        yd = outs[1][0].double()
-        sums = outs[1][1].double().sum(0)
-        cp = sums.shape[0] // 2
-        assert rel(sums[:cout], yd.sum((0, 2, 3))) < 1e-5 and rel(sums[cp:cp + cout], (yd * yd).sum((0, 2, 3))) < 1e-5
-    finally:
-        lib.pylc_debug_p1(0)
-        lib.pylc_debug_pp_flags(0)
-        ops.PLANES_MIN_PIXELS = prev_min
-        check(lib.pylc_set_conv_precision(prev))
+        dy = nhwc(rnd(32, B, cout, H, H), dev)
+        dyp = ops.to_planes(dy)
+        res = nhwc(rnd(33, B, cin, H, H), dev)
+        mask = torch.randint(0, 256, (B * H * H * cin // 8,), dtype=torch.uint8, device=dev)
+        d = ops._conv_desc(x, cin, cout, 1, 1, 1, 0, 1, cin, cout)
+        d.x_fmt, d.dy_fmt = 1, 1
+        d.x_amax, d.w_amax, d.dy_amax = ptr(ops.planes_amax(xp)), ptr(ops.weight_amax(conv.weight)), ptr(ops.planes_amax(dyp))
+        d.w_planes_t = ptr(conv.weight._pylc_planes[1])
+        d.w_planes_fmt = ops.filter_planes_fmt(conv.weight._pylc_planes)
+        dx = ops.empty_nhwc(B, cin, H, H, dev)
 
+        def fwd():
+            y = ops.conv2d(xp, conv.weight, None, 1, 0, 1, want_stats=True)
+            return [y, y._pylc_sums]
 
-@needs_experimental()
-@pytest.mark.parametrize('mode', [2, 3])
-@pytest.mark.parametrize('shape', [(8, 64, 256, 1024), (8, 61, 96, 200), (2, 128, 64, 256), (8, 64, 1024, 256)])
-def test_specialised_wave_1x1_kernel_is_bit_identical(dev, shape, mode, separate_planes):
-    """conv_ps.hip (pylc_debug_ps): the persistent 1x1 kernel whose loader waves stream the operand tiles through tile boundaries while its
-    compute waves multiply, fold, store and go on -- output bit-identical to the per-tile kernel (run twice), BatchNorm statistics partials
-    bit-identical to the 128-row per-tile kernel's and equal to sums over the output; ragged M (61^2 x 8 pixels), a ragged last channel tile
-    (Cout = 200), an odd number of K-steps (Cin = 96), two K-steps per tile (Cin = 64), more tiles than CUs in several rounds."""
-    from pylc_amd import ops, layers, optim
-    from pylc_amd.lib import lib, check
-    B, H, cin, cout = shape
-    prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
-    check(lib.pylc_set_conv_precision(mode))
-    ops.PLANES_MIN_PIXELS = 0
-    try:
-        torch.manual_seed(2)
-        conv = layers.Conv2d(cin, cout, 1, 1, 0, 1, bn=True).to(dev)
-        arena = optim.FlatArena(conv)
-        x = nhwc(rnd(31, B, cin, H, H, scale=2.0), dev)
-        xp = ops.to_planes(x)
-        outs = []
+        def dgrad():
+            check(lib.pylc_conv2d_dgrad(C.byref(d), ptr(dyp), None, ptr(dx), 0, stream()))
+            return [dx]
+
+        def dgrad_res():
+            check(lib.pylc_conv2d_dgrad_add(C.byref(d), ptr(dyp), None, ptr(dx), 0, ptr(res), None, stream()))
+            return [dx]
+
+        def dgrad_masked():
+            check(lib.pylc_conv2d_dgrad_add(C.byref(d), ptr(dyp), None, ptr(dx), 0, ptr(res), ptr(mask), stream()))
+            return [dx]
+
+        kinds = [('fwd', fwd), ('dgrad', dgrad), ('dgrad + residual', dgrad_res), ('dgrad + masked residual', dgrad_masked)]
         with torch.no_grad():
-            for on in (0, 1, 1):
-                lib.pylc_debug_ps(on)
-                lib.pylc_debug_pp_flags((1024 | 2048 | 16384) if on == 0 else 0)     # the 128-row per-tile kernel as the reference (same statistics rows)
-                y = ops.conv2d(xp, conv.weight, None, 1, 0, 1, want_stats=True)
-                torch.cuda.synchronize()
-                outs.append((y.clone(), y._pylc_sums.clone()))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
-        assert torch.equal(outs[1][1], outs[2][1])
-        assert outs[0][1].shape == outs[1][1].shape and torch.equal(outs[0][1], outs[1][1])
-        yd = outs[1][0].double()
-        sums = outs[1][1].double().sum(0)
-        cp = sums.shape[0] // 2
-        assert rel(sums[:cout], yd.sum((0, 2, 3))) < 1e-5 and rel(sums[cp:cp + cout], (yd * yd).sum((0, 2, 3))) < 1e-5
+            for name, fn in kinds:
+                outs = []
+                for flags in (PERSIST_OFF, 0, 0):
+                    lib.pylc_debug_pp_flags(flags)
+                    dx.fill_(float('nan'))
+                    r = [t.clone() for t in fn()]
+                    torch.cuda.synchronize()
+                    outs.append(r)
+                for a_, b_, c_ in zip(*outs):
+                    assert not torch.isnan(b_).any(), name
+                    assert a_.shape == b_.shape and torch.equal(a_, b_) and torch.equal(b_, c_), name
         if mode == 2:
             ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double())
-            assert rel(outs[1][0], ref) < 3e-6
+            lib.pylc_debug_pp_flags(0)
+            with torch.no_grad():
+                assert rel(fwd()[0], ref) < 3e-6
     finally:
-        lib.pylc_debug_ps(0)
         lib.pylc_debug_pp_flags(0)
         ops.PLANES_MIN_PIXELS = prev_min
         check(lib.pylc_set_conv_precision(prev))
 
 
-@needs_experimental()
-def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, separate_planes):
-    """The three launch kinds conv_ps.hip takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
+def test_persistent_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, plane_format):
+    """The three launch kinds gg_plp_kernel takes inside the training graph -- forward with statistics, plain dgrad (conv3: 1024 -> 256 channels
     of gradient), and the dgrad that adds the ReLU-masked residual gradient in its epilogue (conv1 of an identity bottleneck,
-    pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 8 x 61 x 64 pixels (ragged M; small enough that the
-    per-tile reference keeps 128-row tiles for its 32-step reductions, so both runs sum the same BatchNorm statistics partials): block
-    output, input gradient and every parameter gradient bit-identical to the per-tile kernels."""
+    pylc_conv2d_dgrad_add; resnet.py:36-51) -- on three layer3-shaped bottlenecks at 16 x 64 x 64 pixels (512 pixel tiles x 8 channel tiles:
+    several tiles per block): block output, input gradient and every parameter gradient bit-identical to the per-tile kernels."""
     from pylc_amd import ops, optim, runtime
     from pylc_amd.lib import lib
     from pylc_amd.nets.encoder_resnet import Bottleneck
@@ -376,23 +360,22 @@ def test_specialised_wave_1x1_kernel_in_a_bottleneck_chain(dev, f16x3, separate_
             b.out_planes = True
         arena = optim.FlatArena(net)
         net.train()
-        x0 = nhwc(rnd(1, 8, 1024, 61, 64), dev)
-        dout = nhwc(rnd(2, 8, 1024, 61, 64), dev)
+        x0 = nhwc(rnd(1, 16, 1024, 64, 64), dev)
+        dout = nhwc(rnd(2, 16, 1024, 64, 64), dev)
         got = {}
-        for on in (0, 3):
-            lib.pylc_debug_ps(on)
+        for flags in (PERSIST_OFF, 0):
+            lib.pylc_debug_pp_flags(flags)
             arena.g.zero_()
             x = x0.clone().requires_grad_(True)
             out = ops.export_activation(net(x))
             out.backward(dout)
             ops.sync_side_streams()
             torch.cuda.synchronize()
-            got[on] = (out.detach().clone(), x.grad.clone(), arena.g.clone())
-        for name, a, b in zip(('out', 'dx', 'parameter gradients'), got[0], got[3]):
+            got[flags] = (out.detach().clone(), x.grad.clone(), arena.g.clone())
+        for name, a, b in zip(('out', 'dx', 'parameter gradients'), got[PERSIST_OFF], got[0]):
             assert torch.equal(a, b), name
-        assert float(got[3][1].abs().sum()) > 0
+        assert float(got[0][1].abs().sum()) > 0
     finally:
-        lib.pylc_debug_ps(0)
         lib.pylc_debug_pp_flags(0)
         runtime.dropout_enabled = prev_drop
 

@@ -1,6 +1,7 @@
-"""A/B of the specialised-wave persistent 1x1 kernel (conv_ps.hip, pylc_debug_ps) against the per-tile kernels: per-shape time of the forward
-(+ BatchNorm statistics), the plain dgrad and the dgrad that adds a ReLU-masked residual gradient; bit-identity of every output.
-    usage: python tools/ps_ab.py [reps] [mode]"""
+"""A/B of the persistent 1x1 kernel (conv_pl.hip gg_plp_kernel) against the per-tile kernel it replaces (pylc_debug_pp_flags bit 19 = 524288
+switches it off): per-shape time of the forward (+ BatchNorm statistics), the plain dgrad and the dgrad that adds a ReLU-masked residual
+gradient; bit-identity of every output (y, the statistics partials, dx).
+    usage: python tools/plp_ab.py [reps] [mode]"""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,9 +15,12 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 L.init()
 check(lib.pylc_set_conv_precision(mode))
+OFF = 524288
+VARIANT = int(os.environ.get('PLP_VARIANT', '0'))       # extra pylc_debug_pp_flags bits for the persistent side (20: one tile per block, 21: no soft waits, 22: 768 blocks)
 SHAPES = [  # B, H, Cin, Cout  (the forward conv; its dgrad maps Cout -> Cin)
-    (32, 32, 256, 1024), (32, 32, 1024, 256), (32, 64, 128, 512), (32, 64, 512, 128), (32, 128, 64, 256),
-    (32, 32, 512, 2048), (32, 32, 2048, 512), (32, 32, 1024, 2048), (32, 32, 2048, 256), (32, 32, 1280, 256), (8, 64, 728, 728),
+    (32, 32, 256, 1024), (32, 32, 1024, 256), (32, 64, 128, 512), (32, 64, 512, 128), (32, 128, 64, 256), (32, 128, 256, 64),
+    (32, 32, 512, 2048), (32, 32, 2048, 512), (32, 32, 1024, 2048), (32, 32, 2048, 256), (32, 32, 1280, 256), (32, 128, 256, 128), (32, 64, 512, 256),
+    (8, 64, 728, 728), (30, 36, 256, 1024),
 ]
 
 
@@ -30,6 +34,9 @@ def timeit(fn):
     return a.elapsed_time(b) / reps
 
 
+if os.environ.get('PLP_SHAPES'):
+    SHAPES = [SHAPES[int(i)] for i in os.environ['PLP_SHAPES'].split(',')]
+tot = {}
 for (B, H, cin, cout) in SHAPES:
     torch.manual_seed(1)
     conv = layers.Conv2d(cin, cout, 1, 1, 0, 1, bn=True).to(dev)
@@ -48,6 +55,7 @@ for (B, H, cin, cout) in SHAPES:
     d.x_fmt, d.dy_fmt = 1, 1
     d.x_amax, d.w_amax, d.dy_amax = ptr(ops.planes_amax(xp)), ptr(ops.weight_amax(conv.weight)), ptr(ops.planes_amax(dyp))
     d.w_planes_t = ptr(conv.weight._pylc_planes[1])
+    d.w_planes_fmt = ops.filter_planes_fmt(conv.weight._pylc_planes)
     assert not lib.pylc_conv2d_dgrad_needs_f32_weights(C.byref(d))
     dx = ops.empty_nhwc(B, cin, H, H, dev)
 
@@ -62,17 +70,20 @@ for (B, H, cin, cout) in SHAPES:
 
     line = '%-22s' % str((B, H, cin, cout))
     with torch.no_grad():
-        for name, fn, want in (('fwd', fwd, 1), ('dgrad', dgrad, 1), ('dgrad+res', dgrad_add, 3)):
+        for name, fn in (('fwd', fwd), ('dgrad', dgrad), ('dgrad+res', dgrad_add)):
             out = {}
-            for on in (0, want, 0, want):
-                lib.pylc_debug_ps(on)
+            for off in (OFF, 0, OFF, 0):
+                lib.pylc_debug_pp_flags(off if off else VARIANT)
+                dx.fill_(float('nan'))
                 r = fn()
                 torch.cuda.synchronize()
+                got = [t.clone() for t in r[:2]] if name == 'fwd' else [dx.clone()]
                 t = timeit(fn)
-                snap = (r.clone(), r._pylc_sums.clone()) if name == 'fwd' else (dx.clone(),)
-                out.setdefault(on, []).append((t, snap))
-            same = all(torch.equal(a, b) for a, b in zip(out[0][0][1], out[want][0][1]))
-            t0, t1 = min(v[0] for v in out[0]), min(v[0] for v in out[want])
-            line += ' | %s %.0f -> %.0f us (%.0f -> %.0f TF/s)%s' % (name, 1e3 * t0, 1e3 * t1, fl / t0 / 1e9, fl / t1 / 1e9, '' if same else ' DIFFERENT')
-    lib.pylc_debug_ps(0)
+                out.setdefault(off, []).append((t, got))
+            lib.pylc_debug_pp_flags(0)
+            ta, tb = min(v[0] for v in out[OFF]), min(v[0] for v in out[0])
+            same = all(torch.equal(u, w) for u, w in zip(out[OFF][0][1], out[0][0][1])) and not any(torch.isnan(u).any() for u in out[0][0][1])
+            tot[name] = [tot.get(name, [0, 0])[0] + ta, tot.get(name, [0, 0])[1] + tb]
+            line += ' | %s %.0f -> %.0f us (%.0f -> %.0f TF/s)%s' % (name, ta * 1e3, tb * 1e3, fl / ta / 1e9, fl / tb / 1e9, '' if same else ' DIFFERENT')
     print(line, flush=True)
+print('sum over shapes (ms): ' + ' | '.join('%s %.3f -> %.3f' % (k, v[0], v[1]) for k, v in tot.items()))
