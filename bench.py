@@ -383,7 +383,7 @@ def main():
     collectives = pylc_amd.runtime.collectives / args.steps + n_buckets if world > 1 else 0.0
     # N = 1: what the data-parallel code path costs before any fabric is involved -- the same model, a one-rank RCCL group switched on
     # (SyncBN + loss collectives, their stream hops, the bucketed gradient all-reduce), a few more steps
-    dp_overhead = dp_collectives = None
+    dp_overhead = dp_collectives = dp_comm = None
     if world == 1 and not args.no_dp_overhead and not torch.distributed.is_initialized():
         try:
             # RCCL prints its version banner to STDOUT when the group comes up: keep this process's stdout the one JSON line
@@ -410,6 +410,7 @@ def main():
             torch.cuda.synchronize()
             dp_overhead = (time.perf_counter() - t1) / n_dp / (dt / args.steps) - 1.0
             dp_collectives = pylc_amd.runtime.collectives / n_dp + len(model._bucketer.buckets)
+            dp_comm = 'native' if pylc_amd.runtime.comm is not None else 'torch'
         except Exception as e:          # no RCCL on this box: report that rather than fail the benchmark
             dp_overhead = 'unavailable: %s' % str(e)[:80]
         pylc_amd.runtime.sync_group = None
@@ -452,6 +453,8 @@ def main():
                    'sync_bn': bool(pylc_amd.runtime.sync_bn),
                    'collectives_per_step': collectives if world > 1 else dp_collectives,
                    'dp_codepath_overhead': dp_overhead,
+                   # ... and who issued that leg's collectives: 'native' = the C ABI's RCCL communicators (the default since round 6), 'torch' = torch.distributed
+                   'dp_codepath_comm': dp_comm,
                    'standalone_range_passes_per_step': range_passes,
                    'activation_format': ('fp32' if (pylc_amd.runtime.no_planes or planes_marked == 0) else
                                          'fp16 planes between BatchNorm and conv kernels (%d B/element)' % (2 * ops.nplanes())),

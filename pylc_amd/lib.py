@@ -249,28 +249,20 @@ def init():
         mode = os.environ.get('PYLC_CONV_PRECISION')
         if mode is not None:
             check(lib.pylc_set_conv_precision(int(mode)))
-        big = os.environ.get('PYLC_BIG_TILE')          # tuning / A-B knobs, see pylc_debug_set_big_tile / pylc_debug_pp_flags
-        if big is not None:
-            lib.pylc_debug_set_big_tile(int(big))
         flags = os.environ.get('PYLC_DEBUG_FLAGS')
         if flags is not None:
             lib.pylc_debug_pp_flags(int(flags))
-        if os.environ.get('PYLC_WGRAD_ACC1') is not None:     # 1: one-accumulator 128x128 wgrad under 128 registers (A/B)
-            lib.pylc_debug_wgrad_acc1(int(os.environ['PYLC_WGRAD_ACC1']))
         if os.environ.get('PYLC_NO_PLANE_INTERLEAVE'):           # two-plane activations as separate plane arrays (A/B; the round-4 format)
             lib.pylc_set_planes_interleave(0)
-        if os.environ.get('PYLC_WG_SETS') is not None:            # wgrad operand staging sets: 0 one, 1 two for multi-tap filters, 2 two always (A/B)
-            lib.pylc_debug_wgrad_sets(int(os.environ['PYLC_WG_SETS']))
-        if os.environ.get('PYLC_WG_M16') is not None:             # 128 x 128 wgrad on 16 x 16 x 32 MFMAs (A/B)
-            lib.pylc_debug_wgrad_m16(int(os.environ['PYLC_WG_M16']))
-        if os.environ.get('PYLC_WG_DMA') is not None:             # 16x16x32 wgrad tiles by LDS-DMA (A/B)
-            lib.pylc_debug_wgrad_dma(int(os.environ['PYLC_WG_DMA']))
-        if os.environ.get('PYLC_WG_FLAGS') is not None:           # wgrad rasterisation (A/B): 4 = the round-3 order (taps slowest)
-            lib.pylc_debug_wgrad_flags(int(os.environ['PYLC_WG_FLAGS']))
-        if os.environ.get('PYLC_WG_MAX_STEPS') is not None:       # wgrad split plan: cap of K-steps per block for multi-tap filters (0: none; A/B)
-            lib.pylc_debug_wgrad_max_steps(int(os.environ['PYLC_WG_MAX_STEPS']))
-        if os.environ.get('PYLC_DW_TILES') is not None:  # 0: half depthwise convs on the strip kernels (A/B)
-            lib.pylc_debug_dw_tiles(int(os.environ['PYLC_DW_TILES']))
+        # PYLC_DEBUG_KNOBS='name=value,...': the library's A/B knobs and bit-identity references by the name of their entry point without the
+        # pylc_debug_ prefix (include/pylc_hip.h: set_big_tile, stagger, dw_tiles, wgrad_m16, wgrad_dma, wgrad_acc1, wgrad_sets, wgrad_flags,
+        # wgrad_max_steps) -- one variable instead of one per knob
+        for item in filter(None, (t.strip() for t in os.environ.get('PYLC_DEBUG_KNOBS', '').split(','))):
+            name, _, val = item.partition('=')
+            fn = getattr(lib, 'pylc_debug_' + name, None)
+            if fn is None or name in ('pp_stamps',):
+                raise PylcError('PYLC_DEBUG_KNOBS: no knob %r' % name)
+            fn(int(val))
         _initialised = True
 
 

@@ -71,14 +71,14 @@ class Decoder(nn.Module):
         self.drop3, self.drop7 = Dropout(0.5), Dropout(0.1)
         # Launch ORDER of the backward (ops.Conv2dFn.backward, runtime.wgrad_hold): the 304->256 conv's wgrad fills every CU for ~2.9 ms on
         # the side queue; launched right after its dgrad it sits in front of the next kernels of the main queue -- the 48-channel BatchNorm
-        # backward and the 256->48 dgrad of conv1 (decoder.py:27), 0.17 ms of work that then takes 2.1 ms.  PYLC_DECODER_HOLD0=2 holds that
+        # backward and the 256->48 dgrad of conv1 (decoder.py:27), 0.17 ms of work that then takes 2.1 ms.  runtime.decoder_hold = (2, 0) holds that
         # wgrad until the conv backward after conv1's begins.  MEASURED (round 4, profiles/r04_wgrad_hold_ab.txt): the 256->48 row drops to
         # its isolated time, the wait moves to the next short kernel (the ASPP's 1280->256 dgrad: 0.10 -> 1.90 ms) and the step is 0.3 %
         # SLOWER (403.9 / 404.2 vs 405.1 / 405.9 tiles/s): the GPU is never idle during that wait -- the wgrad is work the step has to do
         # anyway -- so the order of the queue does not change the sum.  Default: no hold.
         import os
-        self.last_conv.child(0).weight._pylc_wgrad_hold = int(os.environ.get('PYLC_DECODER_HOLD0', '0'))
-        self.last_conv.child(4).weight._pylc_wgrad_hold = int(os.environ.get('PYLC_DECODER_HOLD4', '0'))
+        self.last_conv.child(0).weight._pylc_wgrad_hold = int(runtime.decoder_hold[0])
+        self.last_conv.child(4).weight._pylc_wgrad_hold = int(runtime.decoder_hold[1])
 
     def forward(self, x, low):
         # torch.cat (decoder.py:47) by slice: the up-sampled ASPP output and the reduced low-level features are written into the two channel

@@ -58,7 +58,7 @@ class SeparableConv2d(nn.Module):
             amax = torch.empty(1, dtype=torch.int32, device=w.device)
             check(lib.pylc_conv1x1_fold_input_affine(ptr(w), ptr(coef[:cin]), ptr(coef[cin:]), None, cout, cin, ptr(w2), ptr(b2), ptr(amax), stream()))
             w2._pylc_wamax = amax                      # the filter range ops.weight_amax looks up
-            if ops.ranges_needed() and not os.environ.get('PYLC_NO_FOLD_PLANES'):
+            if ops.ranges_needed() and runtime.fold_planes:
                 # the folded filter's fp16 planes, as FlatArena prepares them for the arena's filters: the conv kernel then copies
                 # filter tiles instead of splitting fp32 values at every reduction step (pylc_weight_prepare, one table entry)
                 import ctypes as C

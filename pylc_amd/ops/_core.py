@@ -113,7 +113,7 @@ def planes_ok(c, pixels):
 # backbone gradients by 4e-3 elementwise; swapping the first three convs for their bit-compatible planes kernels -- which differ from
 # the small-grid fp32 kernels only in the MFMA shape -- by 2e-2).  The planes kernels themselves are pinned bit for bit against the
 # fp32-operand kernels in tests/test_planes_gpu.py, and the full-size network tests run them.
-PLANES_MIN_PIXELS = int(os.environ.get('PYLC_PLANES_MIN_PIXELS', '8192'))
+PLANES_MIN_PIXELS = 8192
 
 
 def conv_takes_planes(w, pixels_in, pixels_out):
@@ -122,7 +122,7 @@ def conv_takes_planes(w, pixels_in, pixels_out):
     half the MFMAs multiply zeros, but those layers are bound by bytes and by the per-tile prologue / epilogue, which two blocks per
     CU overlap (measured: the 256x128 one-block kernel ran the K = 48 / 64 dgrads of layer1 and the decoder at 6-90 TFLOP/s)."""
     cout, cin, r, s_ = w.shape
-    only = os.environ.get('PYLC_PLANES_ONLY')          # debug: "cin:cout:k,cin:cout:k,..." with * wildcards -- planes for these filters only
+    only = _runtime.planes_only          # debug: "cin:cout:k,cin:cout:k,..." with * wildcards -- planes for these filters only
     if only and not any(all(p == '*' or int(p) == v for p, v in zip(pat.split(':'), (cin, cout, r))) for pat in only.split(',')):
         return False
     return (lib.pylc_get_conv_precision() >= 2 and getattr(w, '_pylc_planes', None) is not None and cin % 8 == 0 and cout % 4 == 0
@@ -378,7 +378,7 @@ def _runs_concurrently(cand, device):
         time.sleep(0.001)
         ok = ev.query()
     torch.cuda.synchronize(device)
-    if os.environ.get('PYLC_DEBUG_STREAMS'):
+    if _runtime.debug_streams:
         print('[pylc] side-stream candidate %s: %s' % (cand, 'concurrent' if ok else 'serialised behind the compute stream'), flush=True)
     return ok
 
@@ -412,7 +412,7 @@ def cu_masked_stream(device, n_cus, from_top=False):
     L.init()
     h = C.c_void_p()
     with torch.cuda.device(device):
-        L._need_experimental('a CU-masked stream (PYLC_WGRAD_CUS)')
+        L._need_experimental('a CU-masked stream (PYLC_RUNTIME=wgrad_cus=1)')
         check(lib.pylc_stream_create_cu_mask(int(n_cus), int(bool(from_top)), C.byref(h)))
     return torch.cuda.ExternalStream(h.value, device=device)
 
@@ -422,7 +422,7 @@ def _side_stream(device):
     if key not in _side_streams:
         cands = []
         for _ in range(8):
-            # runtime.wgrad_cus (PYLC_WGRAD_CUS): confine the wgrad stream to that many compute units, so that the HBM-bound passes of
+            # runtime.wgrad_cus (PYLC_RUNTIME=wgrad_cus=1): confine the wgrad stream to that many compute units, so that the HBM-bound passes of
             # the main stream keep the rest to themselves
             st = cu_masked_stream(device, _runtime.wgrad_cus) if _runtime.wgrad_cus else torch.cuda.Stream(device=device)
             cands.append(st)                          # keep the rejected ones alive so the next candidate is a new stream

@@ -426,7 +426,7 @@ def bn_act_group(specs, group):
         sp = dict(sp)
         y, training, into = sp['y'], sp.get('training', True), sp.get('into')
         pre = getattr(y, '_pylc_sums', None) if training else None
-        dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and not os.environ.get('PYLC_NO_PLANES_DY')
+        dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and _runtime.planes_dy
         out_planes = bool(sp.get('out_planes', False)) and ranges_needed() and not _runtime.no_planes
         drop = sp.get('drop')
         if drop is not None and not (training and _runtime.dropout_enabled and drop[0] > 0):
@@ -453,7 +453,7 @@ def bn_act_group(specs, group):
 def bn_act(y, gamma, beta, running_mean, running_var, residual=None, relu=True, training=True, eps=1e-5, momentum=0.1,
            group=None, clamp_eps=False, res_link=None, out_planes=False, drop=None, into=None, sole=False, defer=False):
     pre = getattr(y, '_pylc_sums', None) if training else None
-    dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and not os.environ.get('PYLC_NO_PLANES_DY')
+    dy_pl = bool(getattr(y, '_pylc_dy_pl', False)) and not _runtime.no_planes and _runtime.planes_dy
     out_planes = bool(out_planes) and ranges_needed() and not _runtime.no_planes
     if drop is not None and not (training and _runtime.dropout_enabled and drop[0] > 0):
         drop = None

@@ -53,7 +53,7 @@ class Conv2dFn(torch.autograd.Function):
         x_pl = takes and is_planes(x)
         if not x_pl:
             x = as_nhwc(x)
-            if os.environ.get('PYLC_DEBUG_PLANES'):
+            if _runtime.debug_planes:
                 print('[pylc] conv fwd on fp32 operands: x %s w %s takes=%s grad=%s' % (tuple(x.shape), tuple(w.shape), takes, torch.is_grad_enabled()), flush=True)
         cin = x.shape[1]
         xp = pitch_of(x)
@@ -137,7 +137,7 @@ class Conv2dFn(torch.autograd.Function):
         if x_pl:
             mark_planes(x, ctx.ranges[0])       # saved tensors come back as new Python objects: restore the marker
         dy_pl = is_planes(dy)
-        if x_pl and os.environ.get('PYLC_PLANES_FWD_ONLY'):          # debug: planes in the forward pass only
+        if x_pl and _runtime.planes_fwd_only:          # debug: planes in the forward pass only
             x, x_pl = from_planes(x), False
         if dy_pl and not x_pl:
             dy, dy_pl = from_planes(dy), False
@@ -150,7 +150,7 @@ class Conv2dFn(torch.autograd.Function):
                 x, x_pl = from_planes(x), False
         if not dy_pl:
             dy = as_nhwc(dy)
-            if os.environ.get('PYLC_DEBUG_PLANES'):
+            if _runtime.debug_planes:
                 print('[pylc] conv bwd on fp32 operands: x %s w %s x_pl=%s dy_pl_ok=%s' % (tuple(x.shape), tuple(w.shape), ctx.x_pl, ctx.dy_pl_ok), flush=True)
         cout, _, r, s = w.shape
         cin = x.shape[1]
@@ -212,7 +212,7 @@ class Conv2dFn(torch.autograd.Function):
                     and getattr(bn, 'bn_emit_ok', False) and tuple(bn.y_shape) == tuple(x.shape)
                     and ((link is None and bn.sole) or (link is not None and link.pending == 1)))
             if emit:
-                L._need_experimental('PYLC_FUSE_BN_SUMS=1')
+                L._need_experimental('PYLC_RUNTIME=fuse_bn_sums=1')
                 y_bn, _, coef, _, bmask, _ = bn.saved_tensors
                 cb = x.shape[1]
                 relu_bn = bn.cfg[0]
@@ -249,10 +249,6 @@ class Conv2dFn(torch.autograd.Function):
             # wgrad is off the critical chain (only the optimiser needs it), so it runs on a side stream: the matrix-bound
             # wgrad kernels then overlap the HBM-bound BatchNorm-backward kernels of the layers that follow on the main stream
             side = _side_stream(x.device) if _runtime.side_stream_on() else None
-            # PYLC_WGRAD_1X1_MAIN (A/B knob): 1x1 wgrads move as many bytes per FLOP as the BatchNorm passes they would run beside; 1 keeps
-            # all of them on the compute stream, 2 only those of maps with at most 32768 pixels (layer3 / layer4 / ASPP)
-            if side is not None and r * s == 1 and _runtime.wgrad_1x1_main and (_runtime.wgrad_1x1_main == 1 or x.shape[0] * x.shape[2] * x.shape[3] <= 32768):
-                side = None
             tgt = _grad_target(w)
 
             def launch_wgrad(side=side, tgt=tgt, x=x, dy=dy, w=w, w_k=w_k, d=d, dy_amax=dy_amax, x_amax=x_amax):   # bound now: it may run later

@@ -18,11 +18,11 @@ class _wgrad_stream:
     off the critical chain, and in the Xception step (BASELINE configs[4]) the main queue is the busy one: 56 of 58 ms against 14 ms on the
     side queue (profiles/r04_c5_trace_streams.txt), 3.2 ms of it depthwise wgrad + combine.  The side stream first waits for the main
     stream's position (dy and, with a deferred BatchNorm, its coefficients were produced there); the tensors the kernels read are kept alive
-    until the streams are joined.  PYLC_DW_WGRAD_MAIN=1 keeps it on the compute stream (A/B knob)."""
+    until the streams are joined.  PYLC_RUNTIME=dw_wgrad_side=0 keeps it on the compute stream (A/B knob)."""
 
     def __init__(self, device, tgt, *reads):
         self.side = None
-        if tgt is not None and _runtime.side_stream_on() and not os.environ.get('PYLC_DW_WGRAD_MAIN'):
+        if tgt is not None and _runtime.side_stream_on() and _runtime.dw_wgrad_side:
             self.side = _side_stream(device)
             ev = torch.cuda.Event()
             ev.record()

@@ -113,7 +113,7 @@ def maxpool(x, k, stride, pad=0, link=None, out_planes=False):
     b, c, h, w = x.shape
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     if (out_planes and (torch.is_grad_enabled() or _runtime.eval_planes) and ranges_needed() and not _runtime.no_planes and not is_planes(x) and c % 8 == 0
-            and planes_ok(c, b * oh * ow) and b * oh * ow >= _core.PLANES_MIN_PIXELS and not os.environ.get('PYLC_NO_POOL_PLANES')):
+            and planes_ok(c, b * oh * ow) and b * oh * ow >= _core.PLANES_MIN_PIXELS and _runtime.pool_planes):
         bound = amax_of(x)                 # the maxima are bounded by the input's range
         return mark_planes(MaxPoolFn.apply(x, k, stride, pad, link, bound), bound)
     y = MaxPoolFn.apply(x, k, stride, pad, link)

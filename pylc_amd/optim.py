@@ -11,6 +11,7 @@ import torch
 
 from . import lib as L
 from .lib import lib, check, ptr, stream
+from .runtime import runtime
 
 
 def _dense_numel(p):
@@ -207,7 +208,7 @@ class FlatAdamW(_FlatOptimizer):
         coef = self._clip()
         self.steps += 1
         stash = self._stash(a.p, self.m, self.v)
-        fused = not stash and not os.environ.get('PYLC_NO_ADAMW_RANGES')      # (restored segments would not match the ranges taken in the kernel)
+        fused = not stash and runtime.adamw_ranges      # (restored segments would not match the ranges taken in the kernel)
         if fused:
             # the parameter ranges of the next step come out of the update pass itself
             check(lib.pylc_adamw_step_ranges(ptr(a.p), ptr(a.g), ptr(self.m), ptr(self.v), a.numel, ptr(coef), self.lr, self.betas[0],

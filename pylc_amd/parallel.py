@@ -55,7 +55,14 @@ def init_from_env(backend=None):
     separate = backend == 'nccl' and os.environ.get('PYLC_SEPARATE_GRAD_COMM') == '1'
     runtime.grad_group = dist.new_group(backend=backend) if separate else dist.group.WORLD
     runtime.manual_seed(runtime.seed, rank)
-    if backend == 'nccl' and os.environ.get('PYLC_COMM') == 'native':
+    # Who issues the SyncBN / loss / bucket collectives.  Default since round 6: the C ABI's own RCCL communicators (PYLC_COMM=native made the
+    # default) -- one ctypes call per message that enqueues ncclAllReduce on the compute stream, no work object, no stream hop.  Measured on the
+    # one-rank RCCL leg of bench.py, four cells, three boxes (profiles/r06_dp_cells.txt): the data-parallel step costs +2.2..3.0 % over the
+    # group-less step with native communicators against +4.9..5.9 % through torch.distributed on the one-queue schedule (side stream: +1.1..1.4 %
+    # against +3.1..3.2 %, but on a 2.3 % slower base: one queue + native is the fastest data-parallel step in absolute terms).  The hand-shake
+    # falls back to torch.distributed on every rank together if RCCL cannot be reached, a communicator cannot be created or its first message
+    # comes back wrong (try_native_comm).  PYLC_COMM=torch keeps torch.distributed.
+    if backend == 'nccl' and os.environ.get('PYLC_COMM', 'native') == 'native':
         try_native_comm(rank, world)
     return rank, world
 
@@ -241,8 +248,8 @@ class GradBucketer:
         self.buckets.append([lo, arena.numel, n])
         self.pending = [b[2] for b in self.buckets]
         self.works = []
-        # PYLC_GRAD_OVERLAP=0: exchange all buckets after the backward pass instead of as they complete (A/B knob)
-        self.overlap = os.environ.get('PYLC_GRAD_OVERLAP', '1') != '0'
+        # runtime.grad_overlap = False: exchange all buckets after the backward pass instead of as they complete (A/B knob)
+        self.overlap = bool(runtime.grad_overlap)
 
     def reset(self):
         self.pending = [b[2] for b in self.buckets]
@@ -365,7 +372,7 @@ def init_single_rank_group():
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', dev))
     runtime.sync_group = dist.group.WORLD
     runtime.grad_group = dist.group.WORLD
-    if os.environ.get('PYLC_COMM') == 'native':
+    if os.environ.get('PYLC_COMM', 'native') == 'native':
         try_native_comm(0, 1)
 
 

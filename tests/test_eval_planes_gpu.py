@@ -161,7 +161,7 @@ def test_lean_inference_epilogue_is_bit_identical(dev, case, prec):
 
 def test_resnet_eval_on_planes_matches_fp32_tensors(dev):
     """DeepLabV3+/R101 in eval mode, 2 x 3 x 192 x 160 tiles: logits of the plane-tensor inference path against the fp32-tensor path
-    (PYLC_EVAL_PLANES=0, the round-3 path, itself pinned to the reference by the fixtures) -- both fp32-grade, so they agree far inside the
+    (PYLC_RUNTIME=eval_planes=0, the round-3 path, itself pinned to the reference by the fixtures) -- both fp32-grade, so they agree far inside the
     1e-3 bar, argmax identical off near-ties -- and the plane path really ran (counter), with at most a handful of format conversions."""
     import oracle
     from oracle import step as ostep

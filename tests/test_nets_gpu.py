@@ -256,13 +256,13 @@ if runtime.sync_group is not None:
 for _ in range(2):
     m.train(x, y)
 import os
-assert (runtime.comm is not None) == (os.environ.get('PYLC_COMM') == 'native')
+assert (runtime.comm is not None) == (bool(os.environ.get('PYLC_FORCE_PG')) and os.environ.get('PYLC_COMM', 'native') == 'native')
 print('RESULT', runtime.sync_group is not None, float(m.crit.ce), float(m.crit.dsc), float(m.crit.fl), float(m.optim.norm[0]))
 print('COLLECTIVES', runtime.collectives // 2)
 ''' % root
     res = {}
     for force in ('', '1', 'native'):       # no group / torch.distributed RCCL / the C ABI's own communicator (pylc_comm_*, PYLC_COMM=native)
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYLC_FORCE_PG='1' if force else '', PYLC_COMM='native' if force == 'native' else '')
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYLC_FORCE_PG='1' if force else '', PYLC_COMM='native' if force == 'native' else 'torch')
         out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
         assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-2000:]

@@ -9,7 +9,7 @@ in seconds, and the HIP path is compared with it output for output:
 
   (i)   DeepLabV3+/ResNet-101, 3-ch 512^2, 9 classes, bs 2 (configs[2]'s tile; models/model.py:282-336 train, :367-382 test)
   (ii)  U-Net, 3-ch 512^2 -> 324^2, bs 1 (configs[1]'s tile; unet.py:91-104)
-  (iii) DeepLabV3+/Aligned-Xception, 1-ch 1024^2, 11 classes, bs 1, eval logits in f16x3 and in precision mode 3 (configs[4]'s tile)
+  (iii) DeepLabV3+/Aligned-Xception, 1-ch 1024^2, 11 classes, bs 2, eval logits in f16x3 and in precision mode 3 (configs[4]'s tile)
 
 Every layer of these runs takes the fp16-plane kernels the bench measures (the fixture `every_layer_on_planes` lowers the pixel threshold to what
 bs 2 leaves of the 32^2 maps).  Tolerances are the north_star's
@@ -32,7 +32,7 @@ R101_GRADS = ['backbone.conv1.weight', 'backbone.layer1.0.conv2.weight', 'backbo
 # tag -> (arch, backbone, classes, input channels, batch, tile, weight salt, data seed)
 CASES = {'r101_512': ('deeplab', 'resnet', 9, 3, 2, 512, 11, 71),
          'unet_512': ('unet', None, 9, 3, 1, 512, 12, 73),
-         'xception_1024': ('deeplab', 'xception', 11, 1, 1, 1024, 13, 75)}
+         'xception_1024': ('deeplab', 'xception', 11, 1, 2, 1024, 13, 75)}      # (bs 2: the fixture's BatchNorm calibration is a training-mode forward, and the ASPP's image-pool BatchNorm sees one value per tile)
 
 
 def grad_keys(tag, w):

@@ -2,7 +2,7 @@
 # Same-box comparison of several environment settings (the A/B knobs of pylc_amd/runtime.py and lib.py): bench.py (no CPU baseline, no DP
 # leg) once per setting per round, interleaved.
 # Usage: [BENCH_ARGS="--config c5"] bash tools/ab_multi.sh <rounds> "NAME=VAL ..." "NAME=VAL ..." ...     ("" = the defaults)
-# e.g.   bash tools/ab_multi.sh 2 "" "PYLC_NO_RELU_BITS=1"          BENCH_ARGS="--config c5" bash tools/ab_multi.sh 2 "PYLC_HALF_ACTS=0" ""
+# e.g.   bash tools/ab_multi.sh 2 "" "PYLC_RUNTIME=no_relu_bits=1"          BENCH_ARGS="--config c5" bash tools/ab_multi.sh 2 "PYLC_RUNTIME=half_acts=0" ""
 set -o pipefail
 rounds=$1; shift
 mkdir -p gpurun_out/ab_multi

@@ -6,7 +6,7 @@ set -o pipefail
 rounds=${1:-1}
 mkdir -p gpurun_out/dp_cells
 for i in $(seq 1 $rounds); do
-  for cell in "one_queue:torch:" "one_queue:native:PYLC_COMM=native" "side_stream:torch:PYLC_SIDE_STREAM=1" "side_stream:native:PYLC_SIDE_STREAM=1 PYLC_COMM=native"; do
+  for cell in "one_queue:torch:PYLC_COMM=torch" "one_queue:native:PYLC_COMM=native" "side_stream:torch:PYLC_SIDE_STREAM=1 PYLC_COMM=torch" "side_stream:native:PYLC_SIDE_STREAM=1 PYLC_COMM=native"; do
     name=${cell%%:*}; rest=${cell#*:}; comm=${rest%%:*}; setting=${rest#*:}
     f=gpurun_out/dp_cells/${name}_${comm}_$i
     env $setting $DP_CELLS_ENV timeout -k 10 300 python bench.py --no-cpu-baseline --steps 10 > $f.json 2> $f.err || { tail -5 $f.err; exit 1; }

@@ -1,5 +1,5 @@
 """Inference throughput with fp16-plane tensors between the kernels (runtime.eval_planes, pylc_conv2d_fwd_bnact_ex) against fp32 tensors
-(PYLC_EVAL_PLANES=0, the round-3 path): Model.test on a resident batch of the BASELINE shapes.   usage: python tools/eval_ab.py [names...]"""
+(PYLC_RUNTIME=eval_planes=0, the round-3 path): Model.test on a resident batch of the BASELINE shapes.   usage: python tools/eval_ab.py [names...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

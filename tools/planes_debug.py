@@ -1,6 +1,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['PYLC_DEBUG_PLANES'] = '1'
+os.environ['PYLC_RUNTIME'] = 'debug_planes=1'
 import numpy as np, torch
 from pylc_amd.model import Model, Meta
 dev = torch.device('cuda:0')

@@ -15,7 +15,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 L.init()
 check(lib.pylc_set_conv_precision(mode))
-OFF = 524288
+OFF = int(os.environ.get('PLP_OFF', '524288'))      # flags of side A (default: persistent kernel off; 8388608: the wide 128 x 256 tile off)
 VARIANT = int(os.environ.get('PLP_VARIANT', '0'))       # extra pylc_debug_pp_flags bits for the persistent side (20: one tile per block, 21: no soft waits, 22: 768 blocks)
 SHAPES = [  # B, H, Cin, Cout  (the forward conv; its dgrad maps Cout -> Cin)
     (32, 32, 256, 1024), (32, 32, 1024, 256), (32, 64, 128, 512), (32, 64, 512, 128), (32, 128, 64, 256), (32, 128, 256, 64),
