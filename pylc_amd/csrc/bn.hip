@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     // in fp64 and rounds ONCE to the fp32 partial.  (Before: fp32 all the way to the partial -- hundreds of terms per thread, an error of
     // ~sqrt(rows) 2^-24 of sum |g xhat| on sums that cancel to a small fraction of that; torch's CPU BatchNorm, the parity yardstick,
     // accumulates these sums in double.  Measured on the fixtures: tests/test_nets_gpu.py::test_error_against_fp64_truth.)
-    __shared__ double red[2][256][4];
+    // [sum][component][thread]: consecutive lanes write consecutive doubles (the [thread][component] layout of rounds 1-5 put a wave's 64 lanes
+    // 32 bytes apart: PMC SQ_LDS_BANK_CONFLICT 0.37 of this kernel's LDS cycles)
+    __shared__ double red[2][4][256];
     const int tx = threadIdx.x % g.cols, ty = threadIdx.x / g.cols;
     const long long r_begin = (long long)blockIdx.x * g.rows_per_slab;
     long long r_end = r_begin + g.rows_per_slab;
@@ -209,12 +211,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                 });
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = d0[k]; red[1][threadIdx.x][k] = d1[k]; }
+        for (int k = 0; k < 4; ++k) { red[0][k][threadIdx.x] = d0[k]; red[1][k][threadIdx.x] = d1[k]; }
         __syncthreads();
         if (ty == 0 && cv < g.CV) {
             for (int j = 1; j < g.RL; ++j) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { d0[k] += red[0][j * g.cols + tx][k]; d1[k] += red[1][j * g.cols + tx][k]; }
+                for (int k = 0; k < 4; ++k) { d0[k] += red[0][k][j * g.cols + tx]; d1[k] += red[1][k][j * g.cols + tx]; }
             }
             const f32x4 f0 = {(float)d0[0], (float)d0[1], (float)d0[2], (float)d0[3]};
             const f32x4 f1 = {(float)d1[0], (float)d1[1], (float)d1[2], (float)d1[3]};
