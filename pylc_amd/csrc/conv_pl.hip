@@ -1286,18 +1286,17 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
 //   * no block leaves, so nothing waits for a wave's stores at s_endpgm, for a dispatch, or for a prologue's dependent global round trip.
 // Same pieces, same MFMA order, same epilogue (pl_epilogue) as gg_pl_kernel<NTERMS, 128>: bit-identical results
 // (tests/test_planes_gpu.py::test_persistent_1x1_kernel_is_bit_identical).  T == 1 only: a tap mask would need a block barrier per tile.
-// The lean epilogue of an edge-free fp32-output tile in the ORDER the persistent kernel needs (same expressions per element and the same order
-// of additions as pl_epilogue_lean<4, STATS, PREV, false> + pl_epilogue's statistics tail: bit-identical):
-//   (1) row offsets from LDS, (2) every load of the residual-gradient source and its mask bits, (3) the BatchNorm statistics -- partials
-//   through LDS, combined, stored --, (4) `between()` = the caller's operand DMA for the next tile, (5) the output stores.
-// Why the order: hipcc puts a wait for every LDS-DMA in flight in front of an LDS access it cannot tell apart from the DMA's target, and a
-// wait for a load's data is a wait for everything older in gfx9's one in-order vmcnt.  With (1)-(3) in front of the DMA those waits find only
-// the previous step's DMA (long landed); behind it they would stand in the middle of the stores.  acc holds the FOLDED accumulators.
-template <int STATS, int PREV, typename Between, typename Stamp>
-__device__ __forceinline__ void plp_epilogue_lean(const GatherGemmArgs& a, f32x4v (&acc)[4][4], const int* rowoff, float* sred, int tile_m, int n0,
-                                                  int wave_m, int wave_n, int lane, int tid, float c, const float* extra, const unsigned char* amask,
-                                                  Between&& between, Stamp&& stamp) {
-    constexpr int AM = 4, AT = 4, WM = 64, WN = 64, BN = PL_BN, BM = 128;
+// The lean epilogue of an edge-free fp32-output tile WITHOUT statistics (plain dgrad; dgrad + residual-gradient source, masked or not) in the
+// order the persistent kernel needs (same expressions per element as pl_epilogue_lean<4, 0, PREV, false>: bit-identical):
+//   (1) row offsets from LDS, (2) EVERY load of the residual-gradient source and its mask bits, (3) `between()` = the caller's operand DMA for
+//   the next tile, (4) the output stores.
+// Why the order: a wait for a load's data is a wait for everything older in gfx9's one in-order vmcnt.  With the loads in front of the DMA hipcc's
+// counted waits for them leave the DMA in flight; behind it -- or, as in pl_epilogue_lean, the second half behind the first stores -- they
+// would wait for the DMA and for those stores.  acc holds the FOLDED accumulators.
+template <int PREV, typename Between, typename Stamp>
+__device__ __forceinline__ void plp_epilogue_lean(const GatherGemmArgs& a, f32x4v (&acc)[4][4], const int* rowoff, int n0, int wave_m, int wave_n, int lane, float c,
+                                                  const float* extra, const unsigned char* amask, Between&& between, Stamp&& stamp) {
+    constexpr int AM = 4, AT = 4, WM = 64, WN = 64;
     const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
     unsigned offs[AM], offsP[AM];
 #pragma unroll
@@ -1321,37 +1320,6 @@ __device__ __forceinline__ void plp_epilogue_lean(const GatherGemmArgs& a, f32x4
         if constexpr (PREV == 2) {
 #pragma unroll
             for (int i = 0; i < AM; ++i) mw[i] = *reinterpret_cast<const uint2*>(amask + (((offs[i] - 4u * (unsigned)(lane >> 4)) >> 3)));
-        }
-    }
-    if constexpr (STATS != 0) {
-        float* const sdst = sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2;
-#pragma unroll
-        for (int j = 0; j < AT; ++j) {
-            f32x4v cs = {0.f, 0.f, 0.f, 0.f}, css = cs;
-#pragma unroll
-            for (int i = 0; i < AM; ++i) {
-                const f32x4v t = acc[i][j];
-                cs = i == 0 ? t : epi_add(cs, t);
-                css = i == 0 ? epi_sq(t) : epi_add(css, epi_sq(t));
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
-            if ((lane & 15) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { sdst[(j * 16 + r) * 2] = cs[r] * c; sdst[(j * 16 + r) * 2 + 1] = css[r] * c * c; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < BN) {
-            const int n = n0 + tid;
-            if (n < a.N_store) {
-                float sm = 0.f, sq = 0.f;
-#pragma unroll
-                for (int wm = 0; wm < BM / WM; ++wm) { sm += sred[(wm * BN + tid) * 2]; sq += sred[(wm * BN + tid) * 2 + 1]; }
-                float* dst = a.stats + (size_t)tile_m * 2 * a.N_store;
-                dst[n] = sm;
-                dst[a.N_store + n] = sq;
-            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1406,6 +1374,94 @@ __device__ __forceinline__ void plp_epilogue_lean(const GatherGemmArgs& a, f32x4
             }
         }
     }
+}
+
+// The statistics epilogue of the persistent kernel in gg_pl_kernel's own order -- per column group: statistics, then (at every second group) the
+// whole-line stores -- with the operand DMA of the next tile issued FIRST.  What makes that order possible behind an LDS-DMA in flight: the
+// partials go through LDS by INLINE ASM (ds_write_b32 / ds_read_b32), which hipcc's wait-count pass does not see -- a C++ access to LDS there
+// gets a vmcnt wait for the DMA and, being in program order behind the first stores, for those stores too (plp_epilogue_lean above avoids
+// that by taking everything it reads before the DMA and all stores after it; a statistics-first form of this epilogue was 1-2 % slower on
+// the forward 1x1 class: profiles/r06_plp_stats_order_ab.txt).  Same expressions and
+// order of additions: bit-identical.
+template <typename Between, typename Stamp>
+__device__ __forceinline__ void plp_epilogue_stats(const GatherGemmArgs& a, f32x4v (&acc)[4][4], const int* rowoff, float* sred, int tile_m, int n0,
+                                                   int wave_m, int wave_n, int lane, int tid, float c, Between&& between, Stamp&& stamp) {
+    constexpr int AM = 4, AT = 4, WM = 64, WN = 64, BN = PL_BN, BM = 128;
+    const int nb = n0 + wave_n * WN + 4 * (lane >> 4);
+    unsigned offs[AM], offsP[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i) {
+        offs[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + (lane & 15)] + nb);
+        offsP[i] = (unsigned)(rowoff[wave_m * WM + i * 16 + ((lane & 15) ^ 8)] + nb);
+    }
+    const bool upper = (lane & 8) != 0;
+    // LDS byte addresses (inline asm takes the 32-bit address): this lane's partial slots, and the combine's
+    const unsigned sdst_at = (unsigned)(uintptr_t)(lds_vptr)(sred + ((wave_m * BN) + wave_n * WN + 4 * (lane >> 4)) * 2);
+    const unsigned comb_at = (unsigned)(uintptr_t)(lds_vptr)(sred + (tid & (BN - 1)) * 2);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    f32x4v hold[AM];
+#pragma unroll
+    for (int j = 0; j < AT; ++j) {
+        f32x4v cs = {0.f, 0.f, 0.f, 0.f}, css = cs;
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            const f32x4v t = acc[i][j];
+            cs = i == 0 ? t : epi_add(cs, t);
+            css = i == 0 ? epi_sq(t) : epi_add(css, epi_sq(t));
+            const f32x4v v = epi_mul(t, c);
+            if ((j & 1) == 0) {
+                hold[i] = v;
+            } else {
+                f32x4v recv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float send = upper ? hold[i][r] : v[r];
+                    recv[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));
+                }
+                const unsigned col = (upper ? j : j - 1) * 16;
+                f32x4v da, db;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { da[r] = upper ? recv[r] : hold[i][r]; db[r] = upper ? v[r] : recv[r]; }
+                *reinterpret_cast<f32x4v*>(a.y + ((upper ? offsP[i] : offs[i]) + col)) = da;
+                *reinterpret_cast<f32x4v*>(a.y + ((upper ? offs[i] : offsP[i]) + col)) = db;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[r] = row_sum16(cs[r]); css[r] = row_sum16(css[r]); }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s0 = cs[r] * c, s1 = css[r] * c * c;
+                asm volatile("ds_write_b32 %0, %1" :: "v"(sdst_at + (unsigned)((j * 16 + r) * 8)), "v"(s0) : "memory");
+                asm volatile("ds_write_b32 %0, %1" :: "v"(sdst_at + (unsigned)((j * 16 + r) * 8 + 4)), "v"(s1) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < a.N_store) {
+            float p00, p01, p10, p11;          // [wave_m 0 | 1][sum | sumsq] of this column
+            asm volatile("ds_read_b32 %0, %1" : "=v"(p00) : "v"(comb_at) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(p01) : "v"(comb_at + 4u) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(p10) : "v"(comb_at + (unsigned)(BN * 8)) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(p11) : "v"(comb_at + (unsigned)(BN * 8 + 4)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the asm reads are not tied to the wait by data flow: keep the additions behind it)
+            asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));
+            float sm = 0.f, sq = 0.f;
+            sm += p00; sq += p01;
+            sm += p10; sq += p11;
+            float* dst = a.stats + (size_t)tile_m * 2 * a.N_store;
+            dst[n] = sm;
+            dst[a.N_store + n] = sq;
+        }
+    }
+    static_assert(BM / WM == 2, "two row halves per statistics column");
 }
 
 template <int NTERMS>
@@ -1625,8 +1681,11 @@ __global__ __launch_bounds__(256, 2) void gg_plp_kernel(const GatherGemmArgs a) 
                     for (int j = 0; j < AT; ++j) acc[i][j] = epi_fma(acc_lo[i][j], 1.f / 2048.f, acc[i][j]);
             }
             auto between = [&]() { pre2 = issue(g & 1); };
-            plp_epilogue_lean<EPK == 1 ? 1 : 0, EPK >= 2 ? EPK - 1 : 0>(a, acc, rowoff4 + (k & 3) * BM, sred, tile / a.tiles_n, n0, wave_m, wave_n, lane, tid, c_unscale,
-                                                                         a.add_src != nullptr ? a.add_src : a.y, a.add_mask, between, stamp);
+            if constexpr (EPK == 1)
+                plp_epilogue_stats(a, acc, rowoff4 + (k & 3) * BM, sred, tile / a.tiles_n, n0, wave_m, wave_n, lane, tid, c_unscale, between, stamp);
+            else
+                plp_epilogue_lean<EPK >= 2 ? EPK - 1 : 0>(a, acc, rowoff4 + (k & 3) * BM, n0, wave_m, wave_n, lane, c_unscale, a.add_src != nullptr ? a.add_src : a.y,
+                                                          a.add_mask, between, stamp);
             stamp();
             // (true already -- the 16 stores are this wave's youngest operations -- but said to hipcc's wait-count pass in its own terms)
             PLP_VMCNT(16);
