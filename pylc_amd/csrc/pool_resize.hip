@@ -209,6 +209,25 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_pitch, fl
     }
 }
 
+// The same interpolation with the output row in the GRID (blockIdx.y = oh, blockIdx.z = b): the flat form above spends three 64-bit divisions
+// per 16 bytes written on its index; here a thread pays one 32-bit division and the row's vertical weights are block-uniform: 107 -> 100 us
+// per launch on the step's three up-samplings (0.94 GB written; the same form of the separable gradient was neutral and is not kept).  Same
+// expression per element: bit-identical.  (launcher: B, OH <= 65535)
+__global__ __launch_bounds__(256) void bilinear_fwd_rows_kernel(const float* __restrict__ x, int x_pitch, float* __restrict__ y, int y_pitch, int H, int W,
+                                                                  int C, int OH, int OW, float sh, float sw) {
+    const unsigned CV = (unsigned)C / 4;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)OW * CV) return;
+    const unsigned ow = idx / CV, cv = idx - ow * CV;
+    const int oh = blockIdx.y, b = blockIdx.z;
+    const Lerp lh = lerp_of(oh, sh, H), lw = lerp_of((int)ow, sw, W);
+    const float* base = x + (size_t)b * H * W * x_pitch + 4 * cv;
+    const f32x4 v00 = ld4(base + ((size_t)lh.i0 * W + lw.i0) * x_pitch), v01 = ld4(base + ((size_t)lh.i0 * W + lw.i1) * x_pitch);
+    const f32x4 v10 = ld4(base + ((size_t)lh.i1 * W + lw.i0) * x_pitch), v11 = ld4(base + ((size_t)lh.i1 * W + lw.i1) * x_pitch);
+    const f32x4 r = lh.w0 * (lw.w0 * v00 + lw.w1 * v01) + lh.w1 * (lw.w0 * v10 + lw.w1 * v11);
+    st4(y + ((size_t)(b * OH + oh) * OW + ow) * y_pitch + 4 * cv, r);
+}
+
 __device__ __forceinline__ void cand_range(int i, float scale, int out_size, int& lo, int& hi) {
     if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
     lo = (int)floorf((float)(i - 1) / scale) - 1;
@@ -511,6 +530,10 @@ extern "C" int pylc_bilinear_fwd(const float* x, int x_pitch, float* y, int y_pi
     PYLC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
     PYLC_REQUIRE(x_pitch >= C && y_pitch >= C && x_pitch % 4 == 0 && y_pitch % 4 == 0, "bilinear_fwd: bad pitch");
     const long long total = (long long)B * OH * OW * (C / 4);
+    if (B <= 65535 && OH <= 65535 && (long long)OW * (C / 4) < (1ll << 31))
+        hipLaunchKernelGGL(bilinear_fwd_rows_kernel, dim3(cdiv(OW * (C / 4), 256), OH, B), dim3(256), 0, as_stream(stream), x, x_pitch, y, y_pitch, H, W, C, OH, OW,
+                           ac_scale(H, OH), ac_scale(W, OW));
+    else
     hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, x_pitch, y, y_pitch, B, H, W, C, OH, OW,
                        ac_scale(H, OH), ac_scale(W, OW));
     PYLC_LAUNCH_CHECK();
