@@ -221,6 +221,10 @@ int wgrad_pl_init();
 bool takes_pl(const GatherGemmArgs& a);
 int launch_gg_pl(GatherGemmArgs& a, hipStream_t st);
 int conv_pl_init();
+// conv_stem.hip: the ResNet stem (7x7 / stride 2 / pad 3, 4 -> 64) as a patch kernel
+bool takes_stem(const GatherGemmArgs& a);
+int launch_stem_fwd(GatherGemmArgs& a, hipStream_t st);
+int conv_stem_init();
 
 extern int g_conv_precision;
 extern int g_wg_flags;

@@ -1631,6 +1631,7 @@ static hipError_t opt_in_lds(K kernel, size_t bytes) {
 
 int conv_init() {
     if (int rc = conv_pl_init()) return rc;
+    if (int rc = conv_stem_init()) return rc;
     if (int rc = wgrad_pl_init()) return rc;
 #define PYLC_OPT_GG(BM, BN, WM, WN)                                                                           \
     PYLC_HIP(opt_in_lds(gather_gemm_kernel<BM, BN, WM, WN, false, 0>, gg_smem<BM, BN, 0>()));                 \
@@ -1828,7 +1829,9 @@ static int conv2d_fwd_impl(const PylcConvDesc* d, const float* x, const float* w
         a.out_half = 1; a.out_bound_k = (float)(d->Cin * d->R * d->S); a.out_bound = d->out_bound;
     }
     const bool cin4 = d->Cin == 4 && d->R * d->S > 1;
-    if (int rc = dispatch_gg(a, cin4, as_stream(stream))) return rc;
+    if (cin4 && ep == nullptr && takes_stem(a)) {
+        if (int rc = launch_stem_fwd(a, as_stream(stream))) return rc;
+    } else if (int rc = dispatch_gg(a, cin4, as_stream(stream))) return rc;
     if (stats_rows) *stats_rows = a.halo_tiles_m > 0 ? a.halo_tiles_m : cdiv(a.M, a.x_planes != nullptr ? a.tile_bm : (a.tiles_n > 0 ? g_last_bm : 128));
     return PYLC_OK;
 }

@@ -200,6 +200,46 @@ def test_conv_thin_input(dev, k, stride, pad, hw, conv_mode):
     assert rel_err(wd.grad, wr.grad) < 5e-6
 
 
+@pytest.mark.parametrize('b,hw', [(2, (64, 128)), (3, (96, 64)), (1, (512, 512))])
+def test_stem_patch_kernel(dev, b, hw):
+    """conv_stem.hip (round 6): the ResNet stem (7x7 / stride 2 / pad 3, 3 -> 64 through the 4-channel pack; resnet.py:72) as a patch kernel --
+    16 x 32 output patches, the input window split once into LDS planes, filter rows padded to eight taps.  Against float64 on the operands
+    as given (the f16x3 bound of test_conv_precision_modes: max error 1e-6 of sum |a||b| -- the reduction ORDER differs from the generic
+    thin-input path's, the products do not), against that generic path (pylc_debug_pp_flags bit 25) to rounding level, the BatchNorm
+    statistics partials against sums over the output, borders (padding) and several patches per block included; two runs bit-identical."""
+    from pylc_amd import ops
+    from pylc_amd.lib import lib
+    if lib.pylc_get_conv_precision() != 2:
+        pytest.skip('the patch kernel is the f16x3 stem')
+    h, w_ = hw
+    x = rnd(5, b, 3, h, w_, scale=2.0)
+    wt = rnd(6, 64, 3, 7, 7, scale=0.1)
+    x4 = ops.pack_nchw(x.to(dev), 4)
+    wd = to_dev_nhwc(wt, dev)
+    outs = {}
+    with torch.no_grad():
+        for flags in (33554432, 0, 0):
+            lib.pylc_debug_pp_flags(flags)
+            y = ops.conv2d(x4, wd, None, 2, 3, 1, want_stats=True)
+            torch.cuda.synchronize()
+            outs.setdefault(flags, []).append((y.clone(), y._pylc_sums.clone()))
+    lib.pylc_debug_pp_flags(0)
+    (y_gen, s_gen), = outs[33554432]
+    (y0, s0), (y1, s1) = outs[0]
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    assert s0.shape[0] == b * (h // 2 // 16) * (w_ // 2 // 32), 'the launch did not take the patch kernel'
+    yr = F.conv2d(x.double(), wt.double(), None, 2, 3)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), None, 2, 3)
+    err = ((y0.double().cpu() - yr).abs() / bound).max().item()
+    err_gen = ((y_gen.double().cpu() - yr).abs() / bound).max().item()
+    print('stem patch kernel %s x %d: max error / sum|a||b| %.3g (generic path %.3g); patch vs generic max|diff| %.3g of max|y| %.3g'
+          % (hw, b, err, err_gen, (y0 - y_gen).abs().max().item(), y0.abs().max().item()))
+    assert err < 1e-6 and err < 2 * err_gen + 1e-7
+    yd = y0.double()
+    sums = s0.double().sum(0)
+    assert rel_err(sums[:64], yd.sum((0, 2, 3))) < 1e-5 and rel_err(sums[64:128], (yd * yd).sum((0, 2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize('c,stride,dil,hw', [(64, 1, 1, 18), (128, 2, 1, 18), (728, 1, 1, 9), (1024, 1, 2, 10), (128, 2, 1, 17),
                                              (32, 1, 1, (7, 71)), (8, 1, 1, (33, 1)), (1536, 1, 1, (5, 40)), (256, 1, 1, (1, 9)),
                                              (16, 1, 1, (66, 130))])
