@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
     // DMA form of a K-step: ALL fragment reads of tile s first, then the DMA of tile s + 1, then the 48 products.  hipcc orders an LDS read
     // behind every LDS-DMA issued before it in program order (s_waitcnt vmcnt(0): it cannot tell the stages apart, seen in the listing), so
     // the DMA goes after the step's last LDS read; the next read is behind the next barrier, where the tile is waited for anyway.
-    auto step_dma = [&](auto stgc, auto issue) {
+    [[maybe_unused]] auto step_dma = [&](auto stgc, auto issue) {      // (the round-5 order, kept for reference: reads, DMA, products)
         constexpr int so = decltype(stgc)::value * STG;
         f16x8 fa[4][NPL], fb[4][NPL];
 #pragma unroll
@@ -317,6 +317,69 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
         __builtin_amdgcn_sched_barrier(0);
         issue();
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (NTERMS == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][NPL - 1], fb[j][0], acc16_lo[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc16_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[j][NPL - 1], acc16_lo[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb[j][0], acc16[i][j], 0, 0, 0);
+        }
+    };
+    // The same K-step with the DMA of tile s + 1 issued FIRST (round 6).  What kept it behind the reads was hipcc, not the hardware: the
+    // transposed reads are inline asm here (ds_read_b64_tr_b16), which the wait-count pass does not see, so nothing puts a vmcnt(0) between the
+    // DMA and them; their arrival is waited for by hand (lgkmcnt(0)) and the fragments are tied to that wait.  The tile then has the step's
+    // reads AND its 48 products to land in.  Same reads, same products, same order: bit-identical.
+    // addresses: tile t of an operand at base + (off0 ^ 32 t), its second half 1024 bytes on with chunk bit 0 flipped = base + ((off0 ^ 32 t) ^ 16)
+    // + 1024; plane, stage and the 1024 ride in the instruction's offset field, so 16 address registers serve all 64 reads of both stages
+    unsigned ad_a[4][2], ad_b[4][2];
+    {
+        const unsigned la0 = (unsigned)(uintptr_t)(wg_lds_vptr)sA, lb0 = (unsigned)(uintptr_t)(wg_lds_vptr)sB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ad_a[t][0] = la0 + (unsigned)(m16_a0 ^ (32 * t)); ad_a[t][1] = la0 + (unsigned)((m16_a0 ^ (32 * t)) ^ 16);
+            ad_b[t][0] = lb0 + (unsigned)(m16_b0 ^ (32 * t)); ad_b[t][1] = lb0 + (unsigned)((m16_b0 ^ (32 * t)) ^ 16);
+        }
+    }
+    auto tr16_asm = [&](const unsigned (&ad)[2], auto offc) {
+        constexpr int off = decltype(offc)::value;
+        unsigned long long lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad[0]), "n"(off) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad[1]), "n"(off + 1024) : "memory");
+        return ulonglong2{lo, hi};
+    };
+    auto step_dma_early = [&](auto stgc, auto issue) {
+        constexpr int so = decltype(stgc)::value * STG;
+        __builtin_amdgcn_sched_barrier(0);
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+        ulonglong2 ua[4][NPL], ub[4][NPL];
+        auto rd = [&](auto tc, auto plc) {
+            constexpr int t = decltype(tc)::value, pl = decltype(plc)::value;
+            ua[t][pl] = tr16_asm(ad_a[t], std::integral_constant<int, so + pl * PLA>{});
+            ub[t][pl] = tr16_asm(ad_b[t], std::integral_constant<int, so + pl * PLB>{});
+        };
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+        rd(I0{}, I0{}); if constexpr (NPL == 2) rd(I0{}, I1{});
+        rd(I1{}, I0{}); if constexpr (NPL == 2) rd(I1{}, I1{});
+        rd(I2{}, I0{}); if constexpr (NPL == 2) rd(I2{}, I1{});
+        rd(I3{}, I0{}); if constexpr (NPL == 2) rd(I3{}, I1{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the asm reads are not tied to the wait by data flow: every fragment passes through an empty asm behind it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(ua[t][pl].x), "+v"(ua[t][pl].y), "+v"(ub[t][pl].x), "+v"(ub[t][pl].y));
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 fa[4][NPL], fb[4][NPL];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { fa[t][pl] = __builtin_bit_cast(f16x8, ua[t][pl]); fb[t][pl] = __builtin_bit_cast(f16x8, ub[t][pl]); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (NTERMS == 3) {
@@ -403,10 +466,10 @@ __global__ __launch_bounds__(256, ACC1 ? 4 : 2) void wgrad_pl_kernel(const Wgrad
             load_tile(Set0{});
             for (int s = 0; s < S; s += 2) {
                 __syncthreads();
-                step_dma(Set0{}, [&] { if (s + 1 < S) load_tile(Stg1{}); });
+                step_dma_early(Set0{}, [&] { if (s + 1 < S) load_tile(Stg1{}); });
                 if (s + 1 < S) {
                     __syncthreads();
-                    step_dma(Stg1{}, [&] { if (s + 2 < S) load_tile(Set0{}); });
+                    step_dma_early(Stg1{}, [&] { if (s + 2 < S) load_tile(Set0{}); });
                 }
             }
         }
