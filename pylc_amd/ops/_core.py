@@ -90,9 +90,9 @@ def half_dw():
 
 
 def filter_planes_fmt(planes):
-    """PylcConvDesc.w_planes_fmt of a parameter's prepared filter planes (optim.FlatArena: `_pylc_planes` = forward planes, dgrad planes,
-    the layouts that CAN be chunk-interleaved, the arena's switch saying whether the last prepare launch wrote them so)."""
-    return planes[2] if (len(planes) > 3 and planes[3][0]) else 0
+    """PylcConvDesc.w_planes_fmt of a parameter's prepared filter planes: the third element of the planes object (optim.FlatArena._publish_planes:
+    what the last prepare launch wrote); a two-element object (the Xception fold path: separate plane arrays) is format 0."""
+    return int(planes[2]) if len(planes) > 2 else 0
 
 
 def pstride(m, c):

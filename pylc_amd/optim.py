@@ -54,7 +54,8 @@ class FlatArena:
         # prepared conv filters for the f16x3 arithmetic: two fp16 planes per filter in the forward (KRSC) and the dgrad
         # (CRSK) layout, rebuilt from the fp32 master weights by ONE launch whenever the ranges are refreshed
         entries, halves, tiles = [], 0, 0
-        self._planes_il = [0]            # 1: the prepared filter planes are chunk-interleaved where eligible (set by refresh_ranges)
+        self._planes_il = 0              # 1: the last prepare launch wrote the filter planes chunk-interleaved where eligible (refresh_ranges)
+        self._prep_entries = []
         for i, (p, o) in enumerate(zip(params, offs)):
             if p.dim() == 4 and p.shape[1] % 4 == 0 and p.shape[1] > 1 and p.permute(0, 2, 3, 1).is_contiguous():
                 k, c, r, s_ = p.shape
@@ -71,13 +72,8 @@ class FlatArena:
             arr = (L.WPrepEntry * len(entries))(*[e for _, e in entries])
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
             self._prep_table = raw.to(dev)
-            for p, e in entries:
-                k, c, r, s_ = p.shape
-                # (forward planes, dgrad planes, which of the two CAN be chunk-interleaved -- channel count % 32 == 0 --, and the arena's
-                #  shared switch: whether the last prepare launch wrote them so; ops.filter_planes_fmt combines the two for PylcConvDesc)
-                p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
-                                  self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)],
-                                  (1 if c % 32 == 0 else 0) | (2 if ((k + 3) & ~3) % 32 == 0 else 0), self._planes_il)
+            self._prep_entries = entries
+            self._publish_planes(0)
         self._index = {id(p): i for i, p in enumerate(params)}
         self._delivered = set()          # parameters whose gradient a backward kernel wrote since the last zero_grad()
         self._stale = False              # invalidate(): values changed through a path the version counters do not see
@@ -85,6 +81,18 @@ class FlatArena:
         me = weakref.ref(self)           # no module -> arena strong reference: a dropped model frees its memory by refcount
         module.register_load_state_dict_post_hook(lambda *_: me() is not None and me().refresh_ranges())
         self.refresh_ranges()
+
+    def _publish_planes(self, il):
+        """Give every prepared filter its planes object: an IMMUTABLE (forward planes, dgrad planes, format) tuple whose format is what the last
+        prepare launch WROTE -- bit 0 / bit 1: the forward / dgrad planes are chunk-interleaved (channel count % 32 == 0 and il) -- so that the
+        layout travels with the planes and cannot disagree with them (the format used to be a cell shared by all parameters and
+        flipped at refresh time).  Replaced whenever a prepare launch changes the layout (a precision-mode switch)."""
+        self._planes_il = il
+        for p, e in self._prep_entries:
+            k, c, r, s_ = p.shape
+            fmt = ((1 if c % 32 == 0 else 0) | (2 if ((k + 3) & ~3) % 32 == 0 else 0)) if il else 0
+            p._pylc_planes = (self.planes[e.fwd_offset:e.fwd_offset + 2 * k * r * s_ * c],
+                              self.planes[e.t_offset:e.t_offset + 2 * c * r * s_ * ((k + 3) & ~3)], fmt)
 
     def refresh_if_changed(self, force=False):
         """refresh_ranges() unless nothing can have moved the parameters since the last refresh: everything in this package that writes them
@@ -122,7 +130,8 @@ class FlatArena:
                 il = 1 if (lib.pylc_get_conv_precision() == 2 and not os.environ.get('PYLC_NO_FILTER_INTERLEAVE')) else 0
                 check(lib.pylc_weight_prepare(ptr(self.p), ptr(self._prep_table), self._n_prep, self._prep_tiles, ptr(self.amax),
                                               ptr(self.planes), il, stream()))
-                self._planes_il[0] = il
+                if il != self._planes_il:
+                    self._publish_planes(il)
 
     def zero_grad(self):
         self.g.zero_()

@@ -268,6 +268,41 @@ def test_conv_mode3_single_plane_against_fp64(dev, fp16_single, case):
     assert max(e) < 1e-3, e
 
 
+def test_filter_plane_format_travels_with_the_planes(dev):
+    """the layout of a parameter's prepared filter planes (chunk-interleaved or separate plane arrays) is part of its planes object
+    (optim.FlatArena._publish_planes), set from what the last prepare launch wrote.  Precision mode 2 -> 3 -> 2 WITHOUT an optimiser step, with
+    and without a refresh in between: every forward must equal the result of the same mode on freshly prepared planes, bit for bit."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib, check
+    prev, prev_min = lib.pylc_get_conv_precision(), ops.PLANES_MIN_PIXELS
+    ops.PLANES_MIN_PIXELS = 0
+    try:
+        check(lib.pylc_set_conv_precision(2))
+        torch.manual_seed(3)
+        conv = layers.Conv2d(64, 128, 3, 1, 1, 1).to(dev)
+        arena = optim.FlatArena(conv)
+        assert ops.filter_planes_fmt(conv.weight._pylc_planes) == 3        # both layouts interleaved (64 and 128 channels)
+        x = nhwc(rnd(5, 2, 64, 32, 32, scale=2.0), dev)
+        run = lambda: ops.conv2d(ops.to_planes(x), conv.weight, None, 1, 1, 1).clone()      # the plane kernels (conv_pl.hip) on the mode's own pixel planes
+        with torch.no_grad():
+            y2 = run()
+            check(lib.pylc_set_conv_precision(3))                          # no refresh: mode 3 on interleaved filter planes
+            y3_stale = run()
+            arena.refresh_ranges()                                         # mode 3 prepares separate plane arrays
+            assert ops.filter_planes_fmt(conv.weight._pylc_planes) == 0
+            y3 = run()
+            check(lib.pylc_set_conv_precision(2))                          # no refresh: mode 2 on separate filter planes
+            y2_stale = run()
+            arena.refresh_ranges()
+            assert ops.filter_planes_fmt(conv.weight._pylc_planes) == 3
+            y2_again = run()
+        assert torch.equal(y3_stale, y3) and torch.equal(y2_stale, y2) and torch.equal(y2_again, y2)
+        assert not torch.equal(y2, y3)
+    finally:
+        ops.PLANES_MIN_PIXELS = prev_min
+        check(lib.pylc_set_conv_precision(prev))
+
+
 PERSIST_OFF = 524288          # pylc_debug_pp_flags bit 19: 1x1 launches on the per-tile kernel (the bit-identity reference of gg_plp_kernel)
 
 
