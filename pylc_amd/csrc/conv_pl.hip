@@ -1943,6 +1943,191 @@ template __global__ void gg_plh_kernel<3, false, true>(const GatherGemmArgs);
 template __global__ void gg_plh_kernel<1, false, true>(const GatherGemmArgs);
 
 
+// -------------------------------------------------------------------------------------------------------------------------
+// The halo kernel for at most 64 output channels: 64 x 64 wave tiles, four waves, TWO blocks per CU.
+// -------------------------------------------------------------------------------------------------------------------------
+// A 64-channel 3x3 layer (the U-Net's first levels, unet.py:107-126; ResNet layer1's conv2) has one column tile, and the per-tap form
+// (gg_pl_kernel<.., NARROW>; a 512 x 64 tile of eight 64 x 64 wave tiles was 4-9 % ahead of it and went the same way) pays the L2 -> LDS path for it: 64-byte pieces of the pixel tile arrive at ~30 B / cycle / CU, nine
+// times per channel chunk (72 KB per 1536 MFMA cycles of a SIMD: 2.4 k cycles).  Round 3 / round 5 tried gg_plh_kernel's wave grid folded into
+// the first 64 columns (eight waves of 32 x 64 on one 16 x 16 patch, one block per CU): half-length steps under the same barrier and issue costs, neutral.
+// Here a block is FOUR waves, each with the full 64 x 64 wave tile (four patch rows x 64 channels: 0.5 fragment reads per MFMA group), on one
+// 16 x 16 patch; ONE halo buffer (48 KB) + a ring of three 64-row filter stages (8 KB each) = 73 KB, so two blocks share a CU and the wait
+// for a chunk's halo (nothing can be requested into the single buffer before the previous chunk's last tap has been read) is covered by the
+// other block (a start delay for the CU's second block, as gg_pl_kernel<.., 128>'s stagger, measured no better than none).
+// Same LDS image, K order and epilogue as gg_plh_kernel: y bit-identical; statistics partials per patch (a.halo_tiles_m rows).
+template <int NTERMS>
+constexpr int plhn_bstage_bytes() { return (NTERMS == 3 ? 2 : 1) * 64 * PL_ROW; }
+template <int NTERMS>
+constexpr int plhn_lds_bytes() { return plh_halo_bytes<NTERMS>() + 3 * plhn_bstage_bytes<NTERMS>() + 256 * 4 + 64; }
+
+template <int NTERMS, bool EP = false>
+__global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a) {
+    constexpr int BM = 256, BNN = 64, AT = 4, ROW = PL_ROW;
+    constexpr int NPL = NTERMS == 3 ? 2 : 1;
+    constexpr int HALO = plh_halo_bytes<NTERMS>(), HPL = PLH_HROWS * ROW;
+    constexpr int BST = plhn_bstage_bytes<NTERMS>();
+    constexpr int NB = NPL;                                   // filter-tile DMA instructions per wave and step
+    constexpr int HP = PLH_PIECES / 4;                        // halo pieces per wave: 6
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    char* const ldsB = lds + HALO;
+    int* rowoff = reinterpret_cast<int*>(lds + HALO + 3 * BST);
+
+    const int tm = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 0 << 6 | 6);     // HW_REG_LDS_ALLOC.LDS_BASE: the CU's second block
+        if (lds_base != 0)
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    const int lc = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int pw = (a.Q + 15) >> 4, ph = (a.P + 15) >> 4;
+    const int tx = tm % pw, t1 = tm / pw;
+    const int ty = t1 % ph, b = t1 / ph;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int hmin_h = a.dh_step > 0 ? a.dh0 : a.dh0 + 2 * a.dh_step;
+    const int hmin_w = a.dw_step > 0 ? a.dw0 : a.dw0 + 2 * a.dw_step;
+
+    const unsigned ilmb = (unsigned)__builtin_amdgcn_readfirstlane(a.w_il ? 2 : 1);
+    const bool ila = NPL == 2 && planes_il(a.x_plane_stride);
+    const unsigned ilma = (unsigned)__builtin_amdgcn_readfirstlane(ila ? 2 : 1);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w_planes), 0, (int)(a.w_plane_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(a.x_bytes * ilma), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(a.x_bytes * ilma - (ila ? 64 : 0)), 0x00020000);
+
+    // filter row of this thread (one 16-row piece per wave: 64 rows)
+    const int nrow = 16 * wave + (lane >> 2);
+    const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride * ilmb + 8u * lc) * 2u : OOB;
+    const unsigned plane1_w = a.w_il ? 64u : (unsigned)(a.w_plane_stride * 2);
+    // halo rows of this thread: pieces wave, wave + 4, ..., wave + 20
+    unsigned hoff[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int h = 16 * (wave + 4 * j) + (lane >> 2);
+        const int hy = h / PLH_HW, hx = h - hy * PLH_HW;
+        const int yy = y0 + hmin_h + hy, xx = x0 + hmin_w + hx;
+        const bool ok = (h < PLH_HW * PLH_HW) & ((unsigned)yy < (unsigned)a.IH) & ((unsigned)xx < (unsigned)a.IW);
+        hoff[j] = ok ? ((unsigned)((b * a.IH + yy) * a.IW + xx) * (unsigned)a.x_pitch * ilma + 8u * lc) * 2u : OOB;
+    }
+    {
+        const int py = tid >> 4, px = tid & 15;
+        rowoff[tid] = (y0 + py < a.P && x0 + px < a.Q) ? (int)(((long long)(b * a.OH + y0 + py) * a.OW + x0 + px) * a.y_pitch) : -1;
+    }
+
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    const int S = 9 * nchunks;
+    f32x4v acc[AT][AT];
+    f32x4v acc_lo[NTERMS == 3 ? AT : 1][NTERMS == 3 ? AT : 1];
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (NTERMS == 3) acc_lo[i][j][r] = 0.f;
+            }
+
+    auto issue_halo = [&](int c) {
+        char* const dst = lds + (16 * wave) * ROW;
+        const unsigned oob = (unsigned)(a.Cin - 1 - (c * BK + 8 * lc)) & OOB;
+        const unsigned cb = (unsigned)(c * BK * 2) * ilma;
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const unsigned vo = (hoff[j] + cb) | oob | (hoff[j] & OOB);
+            char* const d = dst + (64 * j) * ROW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx0, (lds_vptr)d, 16, vo, 0, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx1, (lds_vptr)(d + HPL), 16, vo, 0, 0, 0);
+        }
+    };
+    auto issue_b = [&](int s, int slot) {
+        const int c = s / 9, t = s - 9 * c;
+        const int tr = t / 3, ts = t - 3 * tr;
+        const unsigned oob = (unsigned)(a.Cin - 1 - (c * BK + 8 * lc)) & OOB;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((a.w_off0 + tr * a.w_step_r + ts * a.w_step_s + c * BK) * 2) * ilmb));
+        const unsigned vo = woff_row | oob;
+        const unsigned vo1 = (woff_row + plane1_w) | oob | (woff_row & OOB);
+        char* const d = ldsB + slot * BST + (16 * wave) * ROW;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)d, 16, vo, so, 0, 0);
+        if constexpr (NPL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vptr)(d + BNN * ROW), 16, vo1, so, 0, 0);
+    };
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int koffB = 16 * (kq ^ (((lane >> 2) & 1) << 1));
+    const char* const rb_base = ldsB + l15 * ROW + koffB;
+    auto compute = [&](int t, int slot) {
+        const int tr = t / 3, ts = t - 3 * tr;
+        const int oh = a.dh0 + tr * a.dh_step - hmin_h, ow = a.dw0 + ts * a.dw_step - hmin_w;      // 0 .. 2
+        const char* pb = rb_base + slot * BST;
+        f16x8 fb[AT][NPL];
+#pragma unroll
+        for (int j = 0; j < AT; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BNN * ROW + j * 16 * ROW);
+        const int hr0 = (wave * 4 + oh) * PLH_HW + ow + l15;
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
+            const int hr = hr0 + i * PLH_HW;
+            const char* pa = lds + hr * ROW + 16 * (kq ^ (((hr >> 2) & 1) << 1));
+            f16x8 fa[NPL];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+                if constexpr (NTERMS == 3) {
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[NPL - 1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[0], acc_lo[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    issue_halo(0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    int c = 0, t = 0, slot = 0, nslot = 2;
+    for (int s = 0; s < S; ++s) {
+        if (t == 0 && c > 0) {
+            // chunk boundary: behind this barrier every wave has read the old halo for the last time; the new one is requested, awaited, published
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_halo(c);
+            if (s + 2 < S) issue_b(s + 2, nslot);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            // filter tile s (and at step 0 the first halo) has landed; tile s+1 (NB instructions, younger) may still be on its way
+            if (s + 1 < S) {
+                if constexpr (NPL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < S) issue_b(s + 2, nslot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+        nslot = nslot == 2 ? 0 : nslot + 1;
+        if (++t == 9) { t = 0; ++c; }
+    }
+    static_assert(NB == NPL, "counted waits above: one filter DMA instruction per plane, wave and step");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // LDS is reused for the statistics; orders the row table
+    pl_epilogue<NTERMS, BM, false, 4, EP, false>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, 0, wave, 0, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q);
+}
+
+template __global__ void gg_plhn_kernel<3>(const GatherGemmArgs);
+template __global__ void gg_plhn_kernel<1>(const GatherGemmArgs);
+template __global__ void gg_plhn_kernel<3, true>(const GatherGemmArgs);      // fused inference epilogue (as gg_plh_kernel<.., EP>)
+template __global__ void gg_plhn_kernel<1, true>(const GatherGemmArgs);
+
 // geometry / size conditions on top of: A operand given as planes, prepared filter planes present
 
 int g_stagger = -1;        // < 0: the launch heuristic; >= 0: forced start delay in 2048-cycle units (pylc_debug_stagger)
@@ -2010,6 +2195,23 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
                            a.out_sh == 1 && a.out_sw == 1 && a.oh0 == 0 &&
                            a.ow0 == 0 && a.OH == a.P && a.OW == a.Q && a.w_step_s * 3 == a.w_step_r;
     const bool narrow_first = a.N_store <= 64 && !(g_pp_flags & (65536 | 131072)) && a.bn_y == nullptr;      // <= 64 output channels: the 32 x 64-wave-tile form of gg_pl_kernel
+    const bool ep_fused = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;      // fused inference epilogue
+    // <= 64 output channels: the four-wave halo kernel, two blocks per CU (pylc_debug_pp_flags bit 24: off)
+    if (halo_geom && narrow_first && !(g_pp_flags & (16384 | 16777216)) && a.dbg == nullptr && !(a.dbg_flags & (64 | 128)) && halo_tiles_m >= 2 * kNumCU) {
+        a.tile_bm = 256;
+        a.tiles_n = 1;
+        a.halo_tiles_m = (int)halo_tiles_m;
+        a.n_tiles = (int)halo_tiles_m;
+        a.stagger = g_stagger >= 0 ? g_stagger : 0;          // (A/B knob pylc_debug_stagger, 2048-cycle units: 0 measured best -- profiles/r06_narrow_halo_ab.txt)
+        a.stagger_blocks = 2 * kNumCU;
+        if (ep_fused) {
+            if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1, true>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<1>(), st, a);
+            else hipLaunchKernelGGL((gg_plhn_kernel<3, true>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<3>(), st, a);
+        } else if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<1>(), st, a);
+        else hipLaunchKernelGGL((gg_plhn_kernel<3>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<3>(), st, a);
+        PYLC_LAUNCH_CHECK();
+        return PYLC_OK;
+    }
     if (halo_geom && !narrow_first && !(g_pp_flags & 16384) && halo_tiles_m * cdiv(a.N_store, PL_BN) >= kNumCU / 2) {
         a.tile_bm = 256;
         a.tiles_n = cdiv(a.N_store, PL_BN);
@@ -2095,6 +2297,10 @@ int conv_pl_init() {
     PYLC_HIP(opt_in(gg_pl_kernel<1, 256>, pl_lds_bytes<1, 256>()));
     PYLC_HIP(opt_in(gg_plh_kernel<3>, plh_lds_bytes<3>()));
     PYLC_HIP(opt_in(gg_plh_kernel<1>, plh_lds_bytes<1>()));
+    PYLC_HIP(opt_in(gg_plhn_kernel<3>, plhn_lds_bytes<3>()));
+    PYLC_HIP(opt_in(gg_plhn_kernel<1>, plhn_lds_bytes<1>()));
+    PYLC_HIP(opt_in((gg_plhn_kernel<3, true>), plhn_lds_bytes<3>()));
+    PYLC_HIP(opt_in((gg_plhn_kernel<1, true>), plhn_lds_bytes<1>()));
     PYLC_HIP(opt_in((gg_plp_kernel<3, 0>), plp_lds_bytes<3>()));
     PYLC_HIP(opt_in((gg_plp_kernel<3, 0, true>), plp_lds_bytes<3>() + 4096));
     PYLC_HIP(opt_in((gg_plp_kernel<3, 1, true>), plp_lds_bytes<3>() + 4096));

@@ -1,4 +1,5 @@
-"""Per-shape time of the <= 64-output-channel launches: 32 x 64 wave tiles (NARROW, default) against the wide 2-column wave grid
+"""Per-shape time of the <= 64-output-channel launches: the default (gg_plhn_kernel -- four-wave halo kernel -- for 3x3 / unit steps on large grids),
+32 x 64 wave tiles (gg_pl_kernel<.., NARROW>; debug flag 16777216 = no gg_plhn_kernel) against the wide 2-column wave grid
 (debug flag 65536) and, for 3x3 shapes the halo kernel takes, that kernel (flag 131072); the narrow form also with the tile height forced
 to 128 / 256 rows (flags 2048 / 8192).   usage: python tools/narrow_ab.py [reps]"""
 import os, sys
@@ -9,6 +10,7 @@ from pylc_amd.lib import lib
 
 dev = torch.device('cuda:0')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+N = 16777216      # no gg_plhn_kernel
 SHAPES = [  # B, H, W, Cin, Cout, k, pad      (forward launches; a dgrad with Cin <= 64 is the mirrored forward shape)
     (32, 128, 128, 256, 64, 1, 0), (32, 128, 128, 64, 64, 3, 1), (32, 128, 128, 256, 48, 1, 0),
     (16, 510, 510, 64, 64, 3, 0), (16, 256, 256, 128, 64, 3, 0), (16, 324, 324, 64, 64, 3, 0), (16, 252, 252, 128, 64, 1, 0),
@@ -37,9 +39,16 @@ for (B, H, W, cin, cout, k, pad) in SHAPES:
     fl = 2.0 * B * oh * ow * cout * k * k * cin
     res = []
     with torch.no_grad():
-        for name, flags in (('narrow', 0), ('narrow/128 rows', 2048), ('narrow/256 rows', 8192), ('wide', 65536), ('halo/wide', 131072)):
+        for name, flags in (('default', 0), ('narrow', N), ('narrow/128 rows', N | 2048), ('narrow/256 rows', N | 8192), ('wide', 65536), ('halo/wide', 131072)):
             lib.pylc_debug_pp_flags(flags)
             t = timeit(lambda: ops.conv2d(xp, conv.weight, None, 1, pad, 1, want_stats=True))
             res.append('%s %.0f us %.0f TF' % (name, 1e3 * t, fl / t / 1e9))
+        if os.environ.get('NARROW_STAGGER'):      # start delay of each CU's second block in the four-wave halo kernel (2048-cycle units; default 3)
+            for stg in (0, 1, 2, 5, 8):
+                lib.pylc_debug_pp_flags(0)
+                lib.pylc_debug_stagger(stg)
+                t = timeit(lambda: ops.conv2d(xp, conv.weight, None, 1, pad, 1, want_stats=True))
+                res.append('stagger %d %.0f us' % (stg, 1e3 * t))
+            lib.pylc_debug_stagger(-1)
     lib.pylc_debug_pp_flags(0)
     print('%-40s' % str((B, H, W, cin, cout, k, pad)), ' | '.join(res), flush=True)
