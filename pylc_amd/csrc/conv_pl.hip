@@ -592,7 +592,7 @@ __device__ __forceinline__ float pl_epilogue_lean_ep_half(const GatherGemmArgs& 
 template <int NTERMS, int BM, bool BNB = false, int AM = 4, bool EP = false, bool LEAN_RES = true>
 __device__ __forceinline__ int pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc)[AM][4], f32x4v (&acc_lo)[NTERMS == 3 ? AM : 1][NTERMS == 3 ? 4 : 1],
                                             const int* rowoff, float* smem, int tile_m, int n0, int wave_m, int wave_n, int lane, int tid, bool rows_full,
-                                            const unsigned* ranges = nullptr) {
+                                            const unsigned* ranges = nullptr, int stat_cols = PL_BN) {
     // ranges: {max|x| bits, max|w| bits} already in registers (the persistent kernel loads them ONCE: inside its tile loop every global load
     // of the epilogue is a wait for the next tile's operand DMA, which is older in the in-order vmcnt); nullptr = read them here
     constexpr int BN = PL_BN, WM = 16 * AM, WN = 64, AT = 4;
@@ -936,7 +936,7 @@ __device__ __forceinline__ int pl_epilogue(const GatherGemmArgs& a, f32x4v (&acc
         // (not __syncthreads(): its fence drains vmcnt -- every output store of this tile, and in the persistent kernel the next tile's
         //  operand DMA -- before the partials may be combined; only the LDS writes above have to be visible)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (tid < BN) {
+        if (tid < stat_cols) {          // (stat_cols: the columns this block's waves cover -- 64 in gg_plhn_kernel, whose column tiles are 64 wide)
             const int n = n0 + tid;
             if (n < a.N_store) {
                 float sm = 0.f, sq = 0.f;
@@ -1974,7 +1974,9 @@ __global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a)
     char* const ldsB = lds + HALO;
     int* rowoff = reinterpret_cast<int*>(lds + HALO + 3 * BST);
 
-    const int tm = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / a.tiles_n;
+    const int n0 = (tile % a.tiles_n) * BNN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks) {
@@ -2000,7 +2002,7 @@ __global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a)
         const_cast<char*>(static_cast<const char*>(a.x_planes) + a.x_plane_stride * 2), 0, (int)(a.x_bytes * ilma - (ila ? 64 : 0)), 0x00020000);
 
     // filter row of this thread (one 16-row piece per wave: 64 rows)
-    const int nrow = 16 * wave + (lane >> 2);
+    const int nrow = n0 + 16 * wave + (lane >> 2);
     const unsigned woff_row = nrow < a.N ? ((unsigned)nrow * (unsigned)a.w_row_stride * ilmb + 8u * lc) * 2u : OOB;
     const unsigned plane1_w = a.w_il ? 64u : (unsigned)(a.w_plane_stride * 2);
     // halo rows of this thread: pieces wave, wave + 4, ..., wave + 20
@@ -2120,7 +2122,7 @@ __global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a)
     static_assert(NB == NPL, "counted waits above: one filter DMA instruction per plane, wave and step");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // LDS is reused for the statistics; orders the row table
-    pl_epilogue<NTERMS, BM, false, 4, EP, false>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, 0, wave, 0, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q);
+    pl_epilogue<NTERMS, BM, false, 4, EP, false>(a, acc, acc_lo, rowoff, reinterpret_cast<float*>(smem), tm, n0, wave, 0, lane, tid, y0 + 16 <= a.P && x0 + 16 <= a.Q, nullptr, BNN);
 }
 
 template __global__ void gg_plhn_kernel<3>(const GatherGemmArgs);
@@ -2197,18 +2199,20 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     const bool narrow_first = a.N_store <= 64 && !(g_pp_flags & (65536 | 131072)) && a.bn_y == nullptr;      // <= 64 output channels: the 32 x 64-wave-tile form of gg_pl_kernel
     const bool ep_fused = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;      // fused inference epilogue
     // <= 64 output channels: the four-wave halo kernel, two blocks per CU (pylc_debug_pp_flags bit 24: off)
-    if (halo_geom && narrow_first && !(g_pp_flags & (16384 | 16777216)) && a.dbg == nullptr && !(a.dbg_flags & (64 | 128)) && halo_tiles_m >= 2 * kNumCU) {
+    // ... and wider launches as 64-wide column tiles of it when that makes at least two rounds of blocks (bit 26: always, bit 27: never)
+    const bool wide_too = a.bn_y == nullptr && !(g_pp_flags & 134217728) && ((g_pp_flags & 67108864) || halo_tiles_m * cdiv(a.N_store, 64) >= 4 * kNumCU);
+    if (halo_geom && (narrow_first || wide_too) && !(g_pp_flags & (16384 | 16777216)) && a.dbg == nullptr && !(a.dbg_flags & (64 | 128)) && halo_tiles_m * cdiv(a.N_store, 64) >= 2 * kNumCU) {
         a.tile_bm = 256;
-        a.tiles_n = 1;
+        a.tiles_n = cdiv(a.N_store, 64);
         a.halo_tiles_m = (int)halo_tiles_m;
-        a.n_tiles = (int)halo_tiles_m;
+        a.n_tiles = (int)(halo_tiles_m * a.tiles_n);
         a.stagger = g_stagger >= 0 ? g_stagger : 0;          // (A/B knob pylc_debug_stagger, 2048-cycle units: 0 measured best -- profiles/r06_narrow_halo_ab.txt)
         a.stagger_blocks = 2 * kNumCU;
         if (ep_fused) {
-            if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1, true>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<1>(), st, a);
-            else hipLaunchKernelGGL((gg_plhn_kernel<3, true>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<3>(), st, a);
-        } else if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<1>(), st, a);
-        else hipLaunchKernelGGL((gg_plhn_kernel<3>), dim3((unsigned)halo_tiles_m), dim3(256), plhn_lds_bytes<3>(), st, a);
+            if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1, true>), dim3((unsigned)a.n_tiles), dim3(256), plhn_lds_bytes<1>(), st, a);
+            else hipLaunchKernelGGL((gg_plhn_kernel<3, true>), dim3((unsigned)a.n_tiles), dim3(256), plhn_lds_bytes<3>(), st, a);
+        } else if (a.nterms == 1) hipLaunchKernelGGL((gg_plhn_kernel<1>), dim3((unsigned)a.n_tiles), dim3(256), plhn_lds_bytes<1>(), st, a);
+        else hipLaunchKernelGGL((gg_plhn_kernel<3>), dim3((unsigned)a.n_tiles), dim3(256), plhn_lds_bytes<3>(), st, a);
         PYLC_LAUNCH_CHECK();
         return PYLC_OK;
     }

@@ -563,11 +563,14 @@ def test_conv_with_bias_on_planes(dev, f16x3, case):
 
 
 @pytest.mark.parametrize('case', [(128, 128, 8, 64, 64), (64, 256, 4, 128, 128), (256, 136, 8, 48, 80),
-                                  (64, 64, 4, 128, 128), (128, 64, 4, 124, 124), (64, 48, 4, 128, 128)])      # the last three: <= 64 output channels, the NARROW form
+                                  (64, 64, 4, 128, 128), (128, 64, 4, 124, 124), (64, 48, 4, 128, 128),      # these three: <= 64 output channels, the NARROW form
+                                  # >= 1024 blocks of 256 pixels x 64 channels: gg_plhn_kernel's column tiles (forward and dgrad), a last column tile of 8 channels, ragged patches
+                                  (128, 192, 8, 128, 128), (128, 136, 8, 128, 136), (192, 128, 9, 122, 126)])
 def test_halo_kernel_is_bit_identical(dev, f16x3, case):
-    """The 3x3 halo variant (conv_pl.hip gg_plh_kernel: a 16x16 output patch's 18x18 input rows DMA'd once per channel chunk) takes
-    launches of at least half a round of 256-pixel tiles -- larger than the other cases of this file: forward and dgrad (flipped taps)
-    against the fp32-operand kernel bit for bit and against the non-halo planes kernel (debug flag 16384), y also against fp64."""
+    """The 3x3 halo variants (conv_pl.hip: a 16x16 output patch's 18x18 input rows DMA'd once per channel chunk -- gg_plh_kernel, eight waves on 256 pixels x
+    128 channels, for launches of at least half a round of such tiles; gg_plhn_kernel, four waves on 256 pixels x 64 channels and two blocks per CU, for <= 64
+    output channels and for every launch of at least 1024 such tiles): forward and dgrad (flipped taps)
+    against the fp32-operand kernel bit for bit, against the non-halo planes kernel (debug flag 16384) and against gg_plh_kernel alone (flag 134217728), y also against fp64."""
     from pylc_amd import ops, layers, optim, runtime
     from pylc_amd.lib import lib
     cin, cout, B, H, W = case
@@ -576,7 +579,7 @@ def test_halo_kernel_is_bit_identical(dev, f16x3, case):
     arena = optim.FlatArena(conv)
     x = nhwc(rnd(7, B, cin, H, W, scale=2.0), dev).requires_grad_(True)
     out = {}
-    for mode, flags, nopl in (('fp32', 1024, True), ('halo', 0, False), ('nohalo', 16384, False)):
+    for mode, flags, nopl in (('fp32', 1024, True), ('halo', 0, False), ('nohalo', 16384, False), ('plh', 134217728, False)):
         runtime.no_planes = nopl
         lib.pylc_debug_pp_flags(flags)
         x.grad = None
@@ -590,12 +593,46 @@ def test_halo_kernel_is_bit_identical(dev, f16x3, case):
     runtime.no_planes = False
     lib.pylc_debug_pp_flags(0)
     assert torch.equal(out['halo'][0], out['nohalo'][0]) and torch.equal(out['halo'][1], out['nohalo'][1])
+    assert torch.equal(out['halo'][0], out['plh'][0]) and torch.equal(out['halo'][1], out['plh'][1])
     if cout > 64:
         assert torch.equal(out['halo'][0], out['fp32'][0])
     if cin > 64:
         assert torch.equal(out['halo'][1], out['fp32'][1])
     ref = torch.nn.functional.conv2d(x.detach().double().cpu(), conv.weight.detach().double().cpu(), None, 1, 1, 1)
     assert rel(out['halo'][0], ref) < 3e-6
+
+
+@pytest.mark.parametrize('case', [(128, 192, 8, 128, 128, 1), (128, 136, 8, 128, 136, 1), (64, 128, 9, 124, 126, 0)])
+def test_halo_column_tiles_statistics(dev, f16x3, case):
+    """BatchNorm statistics from gg_plhn_kernel's 64-wide column tiles (each block combines and stores the partials of ITS 64 columns only): the column sums /
+    sums of squares of the launch against gg_plh_kernel's (flag 134217728) and the per-tap kernel's (16384) to fp32 summation order, and against y itself in fp64."""
+    from pylc_amd import ops, layers, optim
+    from pylc_amd.lib import lib
+    cin, cout, B, H, W, pad = case
+    torch.manual_seed(5)
+    conv = layers.Conv2d(cin, cout, 3, 1, pad, 1, bn=True).to(dev)
+    arena = optim.FlatArena(conv)
+    xp = ops.to_planes(nhwc(rnd(7, B, cin, H, W, scale=2.0), dev))
+    out = {}
+    try:
+        with torch.no_grad():
+            for name, flags in (('default', 0), ('plh', 134217728), ('per tap', 16384)):
+                lib.pylc_debug_pp_flags(flags)
+                y = ops.conv2d(xp, conv.weight, None, 1, pad, 1, want_stats=True)
+                torch.cuda.synchronize()
+                out[name] = (y.clone(), y._pylc_sums.double().sum(0))
+    finally:
+        lib.pylc_debug_pp_flags(0)
+    y = out['default'][0]
+    yd = y.double()
+    direct = torch.cat([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
+    for name in ('plh', 'per tap'):
+        assert torch.equal(y, out[name][0]), name
+        assert rel(out['default'][1], out[name][1]) < 2e-6, (name, rel(out['default'][1], out[name][1]))
+    got = out['default'][1]
+    assert got.numel() == 2 * cout
+    assert rel(got, direct) < 2e-6, rel(got, direct)
+    del arena
 
 
 @pytest.mark.parametrize('case', [(256, 256, 3, 1, 1, 1, 2, 32, 32), (72, 200, 3, 1, 6, 6, 3, 30, 30), (1024, 256, 1, 1, 0, 1, 2, 32, 32),
