@@ -2098,8 +2098,13 @@ __global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             issue_halo(c);
-            if (s + 2 < S) issue_b(s + 2, nslot);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s + 2 < S) {                                  // (a chunk has nine steps: true unless this is the last chunk's ... never at t == 0; kept for symmetry)
+                issue_b(s + 2, nslot);
+                // the halo is older than filter tile s+2: that one may stay in flight
+                if constexpr (NPL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
         } else {
             // filter tile s (and at step 0 the first halo) has landed; tile s+1 (NB instructions, younger) may still be on its way

@@ -1,7 +1,7 @@
 """Per-shape time of the 3x3 / unit-step launches the halo kernels take: the default (gg_plh_kernel: eight waves, 256 pixels x 128 channels, one block per CU;
 gg_plhn_kernel for <= 64 output channels) against every launch as 64-wide column tiles of gg_plhn_kernel (four waves, two blocks per CU: debug flag 67108864)
 and against the per-tap kernel (flag 16384).  Forward conv + statistics; outputs compared bit for bit.   usage: python tools/halo_ab.py [reps]"""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pylc_amd import ops, layers, optim
@@ -17,6 +17,9 @@ SHAPES = [  # B, H, W, Cin, Cout, pad
 
 def timeit(fn):
     fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < 0.1:      # clocks: the first launches after a host-side pause run slow (the first column of a row used to read 3-10 % low)
+        fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
