@@ -2244,6 +2244,9 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     const long long tiles256 = (long long)cdiv(a.M, 256) * cdiv(a.N_store, PL_BN);
     bool big = ksteps >= 24 && tiles256 >= kNumCU;
     if (g_pp_flags & 2048) big = false;               // A/B knobs (pylc_debug_pp_flags)
+    // multi-tap launches (dilated / strided 3x3, ragged 3x3 the halo kernels do not take): two 128-row blocks per CU, each the other's cover, are ahead of the
+    // one 256-row block whatever the reduction length (R101 step +0.5-0.9 %: profiles/r06_tile128_multitap_ab.txt; bit 23: the old choice)
+    if (a.TR * a.TS > 1 && !(g_pp_flags & 8388608)) big = false;
     if (g_pp_flags & 8192) big = true;
     const int bm = big ? 256 : 128;
     a.tile_bm = bm;
