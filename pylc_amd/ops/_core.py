@@ -250,12 +250,13 @@ class KernelTimer:
         self.inference = bool(inference)      # eval-mode nets: the fused conv + BatchNorm(+ residual + ReLU) launches (conv_bn_act_eval) are bracketed
         # the fp16-plane gather-GEMM (conv_pl.hip) in its two tile heights is what the conv forward / dgrad launches run when the
         # activations travel as planes; '*' = both tile heights (rocprof lists them as two rows), the persistent form of the 128-row tile for
-        # 1x1 convs (gg_plp_kernel, round 6) and the 3x3 halo variant: one kernel family (conv_pl.hip), the same loop body, dispatched by shape
-        self.KERNEL = (('gg_pl_kernel<%d,*,EP> + gg_plh_kernel<%d,EP> (pylc_conv2d_fwd_bnact_ex: plane tensors, conv + eval BatchNorm + residual + ReLU '
-                        'in the epilogue)' % (((3 if self.mode == 2 else 1),) * 2) if (_runtime.eval_planes and self.planes) else
+        # 1x1 convs (gg_plp_kernel, round 6) and the 3x3 halo variants (gg_plh_kernel; gg_plhn_kernel: four waves, two blocks per CU): one kernel family
+        # (conv_pl.hip), the same loop body, dispatched by shape
+        self.KERNEL = (('gg_pl_kernel<%d,*,EP> + gg_plh_kernel<%d,EP> + gg_plhn_kernel<%d,EP> (pylc_conv2d_fwd_bnact_ex: plane tensors, conv + eval BatchNorm + residual + ReLU '
+                        'in the epilogue)' % (((3 if self.mode == 2 else 1),) * 3) if (_runtime.eval_planes and self.planes) else
                         'gather_gemm_pp_kernel<..., %s> (pylc_conv2d_fwd_bnact: conv + eval BatchNorm + residual + ReLU in the epilogue)'
                         % ('ONE-plane fp16' if self.mode == 3 else 'f16x3')) if self.inference else
-                       'gg_pl_kernel<%d,*> + gg_plp_kernel<%d,*> + gg_plh_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 3) if self.planes else
+                       'gg_pl_kernel<%d,*> + gg_plp_kernel<%d,*> + gg_plh_kernel<%d> + gg_plhn_kernel<%d>' % (((3 if self.mode == 2 else 1),) * 4) if self.planes else
                        'gather_gemm_pp_kernel<false,true,true,true,true,false>' if self.mode == 2 else
                        'gather_gemm_kernel<256,128,64,64,false,%d>' % self.mode)
 

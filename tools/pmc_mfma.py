@@ -29,7 +29,7 @@ for (pd, did, cname), val in per_dispatch.items():
     a = acc[kname[(pd, did)]][cname]
     a[0] += val; a[1] += 1
 res = {}
-WANT = ('gg_pl_kernel', 'gg_plp_kernel', 'gg_plh_kernel', 'wgrad_pl_kernel', 'bn_bwd_apply_kernel', 'bn_reduce_kernel', 'bn_apply_kernel', 'gather_gemm', 'dw_strip', 'splitk')
+WANT = ('gg_pl_kernel', 'gg_plp_kernel', 'gg_plh_kernel', 'gg_plhn_kernel', 'wgrad_pl_kernel', 'bn_bwd_apply_kernel', 'bn_reduce_kernel', 'bn_apply_kernel', 'gather_gemm', 'dw_strip', 'splitk')
 for k, d in acc.items():
     if not any(w in k for w in WANT):
         continue
