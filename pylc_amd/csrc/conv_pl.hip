@@ -109,6 +109,29 @@ __device__ __forceinline__ f32x4v epi_add(f32x4v a, f32x4v b) {
 #endif
 }
 
+// The K-step's instruction order, said to the scheduler.  Left to itself hipcc reads six fragments, waits for ALL of them, issues four MFMAs, reads four
+// more, waits ... -- an LDS round trip in front of every few products, on a wave that shares its SIMD with one other wave only.  With the
+// groups below a step is: the filter fragments and the pixel fragments of rows 0 and 1 (one wait), row 0's MFMAs, row 2's fragments, row 1's MFMAs, row
+// 3's fragments, the rest -- every later fragment lands behind 12 MFMAs (+3-7 % on every 3x3 launch of gg_plhn_kernel: profiles/r06_sched_groups_ab.txt).
+// Same instructions, same MFMA order per accumulator: bit-identical.  AM: 16-row pixel fragments per wave (4, or 2 in the NARROW form).
+template <int AM, int NPL, int NTERMS>
+__device__ __forceinline__ void pl_step_schedule() {
+    constexpr int AT = 4;
+    if constexpr (AM >= 3) {
+        __builtin_amdgcn_sched_group_barrier(0x100, (AT + 2) * NPL, 0);      // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, AT * NTERMS, 0);         // MFMAs
+#pragma unroll
+        for (int r = 2; r < AM; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, AT * NTERMS, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, AT * NTERMS, 0);
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x100, (AT + AM) * NPL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, AM * AT * NTERMS, 0);
+    }
+}
+
 // STATS: 0 none, 1 column sums / sums of squares.  PREV: 0 none, 1 `extra` added (accumulate / residual-gradient source), 2 ... under the
 // 1-bit mask `amask`.  HALF: one-plane fp16 output (NTERMS == 1 launches only).
 template <int AM, int STATS, int PREV, bool HALF>
@@ -1182,22 +1205,25 @@ __global__ __launch_bounds__(BM * 2, 2) void gg_pl_kernel(const GatherGemmArgs a
             for (int j = 0; j < AT; ++j)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+            f16x8 fa[AM][NPL];
+#pragma unroll
+            for (int i = 0; i < AM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
 #pragma unroll
             for (int i = 0; i < AM; ++i) {
-                f16x8 fa[NPL];
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
 #pragma unroll
                 for (int j = 0; j < AT; ++j) {
                     // the filter fragment is the FIRST operand: the 16x16 result comes out transposed (lane l: pixel l & 15, channels
                     // 4 (l >> 4) .. +3) -> 16-byte epilogue stores.  Same term order as conv_igemm.hip (bit-identical sums).
                     if constexpr (NTERMS == 3) {
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][NPL - 1], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[i][0], acc_lo[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
                 }
             }
+            pl_step_schedule<AM, NPL, NTERMS>();
         }
     };
 
@@ -1603,20 +1629,23 @@ __global__ __launch_bounds__(256, 2) void gg_plp_kernel(const GatherGemmArgs a) 
             for (int j = 0; j < AT; ++j)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
+            f16x8 fa[AM][NPL];
+#pragma unroll
+            for (int i = 0; i < AM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
 #pragma unroll
             for (int i = 0; i < AM; ++i) {
-                f16x8 fa[NPL];
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * BM * ROW + i * 16 * ROW);
 #pragma unroll
                 for (int j = 0; j < AT; ++j) {
                     if constexpr (NTERMS == 3) {
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[1], acc_lo[i][j], 0, 0, 0);
-                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][1], fa[0], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][NPL - 1], acc_lo[i][j], 0, 0, 0);
+                        acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[i][0], acc_lo[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
                 }
             }
+            pl_step_schedule<AM, NPL, NTERMS>();
         }
     };
 
@@ -1857,22 +1886,26 @@ __global__ __launch_bounds__(512, 2) void gg_plh_kernel(const GatherGemmArgs a) 
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BN * ROW + j * 16 * ROW);
         const int hr0 = (wave_m * 4 + oh) * PLH_HW + ow + l15;                 // halo row of this lane's pixel in patch row 4 wave_m
+        f16x8 fa[AT][NPL];
 #pragma unroll
         for (int i = 0; i < AT; ++i) {
             const int hr = hr0 + i * PLH_HW;
             const char* pa = ha + hr * ROW + 16 * (kq ^ (((hr >> 2) & 1) << 1));
-            f16x8 fa[NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+            for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+        }
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
                 if constexpr (NTERMS == 3) {
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[NPL - 1], acc_lo[i][j], 0, 0, 0);
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[0], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][NPL - 1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[i][0], acc_lo[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
             }
         }
+        pl_step_schedule<AT, NPL, NTERMS>();
     };
 
     // prologue: halo 0, filter tiles 0 and 1
@@ -2070,22 +2103,26 @@ __global__ __launch_bounds__(256, 2) void gg_plhn_kernel(const GatherGemmArgs a)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *reinterpret_cast<const f16x8*>(pb + pl * BNN * ROW + j * 16 * ROW);
         const int hr0 = (wave * 4 + oh) * PLH_HW + ow + l15;
+        f16x8 fa[AT][NPL];                          // (all rows' fragments named, so that pl_step_schedule can place their reads)
 #pragma unroll
         for (int i = 0; i < AT; ++i) {
             const int hr = hr0 + i * PLH_HW;
             const char* pa = lds + hr * ROW + 16 * (kq ^ (((hr >> 2) & 1) << 1));
-            f16x8 fa[NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) fa[pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+            for (int pl = 0; pl < NPL; ++pl) fa[i][pl] = *reinterpret_cast<const f16x8*>(pa + pl * HPL);
+        }
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
                 if constexpr (NTERMS == 3) {
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[NPL - 1], acc_lo[i][j], 0, 0, 0);
-                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[0], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][NPL - 1], acc_lo[i][j], 0, 0, 0);
+                    acc_lo[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][NPL - 1], fa[i][0], acc_lo[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
             }
         }
+        pl_step_schedule<AT, NPL, NTERMS>();
     };
 
     issue_halo(0);
@@ -2204,8 +2241,10 @@ int launch_gg_pl(GatherGemmArgs& a, hipStream_t st) {
     const bool narrow_first = a.N_store <= 64 && !(g_pp_flags & (65536 | 131072)) && a.bn_y == nullptr;      // <= 64 output channels: the 32 x 64-wave-tile form of gg_pl_kernel
     const bool ep_fused = a.ep_scale != nullptr || a.ep_amax != nullptr || a.out_planes2 || a.ep_res != nullptr;      // fused inference epilogue
     // <= 64 output channels: the four-wave halo kernel, two blocks per CU (pylc_debug_pp_flags bit 24: off)
-    // ... and wider launches as 64-wide column tiles of it when that makes at least two rounds of blocks (bit 26: always, bit 27: never)
-    const bool wide_too = a.bn_y == nullptr && !(g_pp_flags & 134217728) && ((g_pp_flags & 67108864) || halo_tiles_m * cdiv(a.N_store, 64) >= 4 * kNumCU);
+    // ... and wider launches as 64-wide column tiles of it when that makes at least one full round of blocks (two per CU): since the K-step's
+    // instruction order is given to the scheduler (pl_step_schedule) the one-round 256 -> 256 @32^2 x 32 launches are ahead on it too (89 vs 93 us;
+    // in the step +0.7 %).  pylc_debug_pp_flags bit 27: never (gg_plh_kernel for every wide launch); bit 26: only from two rounds on (the rule before)
+    const bool wide_too = a.bn_y == nullptr && !(g_pp_flags & 134217728) && halo_tiles_m * cdiv(a.N_store, 64) >= ((g_pp_flags & 67108864) ? 4 : 2) * kNumCU;
     if (halo_geom && (narrow_first || wide_too) && !(g_pp_flags & (16384 | 16777216)) && a.dbg == nullptr && !(a.dbg_flags & (64 | 128)) && halo_tiles_m * cdiv(a.N_store, 64) >= 2 * kNumCU) {
         a.tile_bm = 256;
         a.tiles_n = cdiv(a.N_store, 64);

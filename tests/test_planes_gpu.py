@@ -564,12 +564,12 @@ def test_conv_with_bias_on_planes(dev, f16x3, case):
 
 @pytest.mark.parametrize('case', [(128, 128, 8, 64, 64), (64, 256, 4, 128, 128), (256, 136, 8, 48, 80),
                                   (64, 64, 4, 128, 128), (128, 64, 4, 124, 124), (64, 48, 4, 128, 128),      # these three: <= 64 output channels, the NARROW form
-                                  # >= 1024 blocks of 256 pixels x 64 channels: gg_plhn_kernel's column tiles (forward and dgrad), a last column tile of 8 channels, ragged patches
+                                  # >= 512 blocks of 256 pixels x 64 channels: gg_plhn_kernel's column tiles (forward and dgrad), a last column tile of 8 channels, ragged patches
                                   (128, 192, 8, 128, 128), (128, 136, 8, 128, 136), (192, 128, 9, 122, 126)])
 def test_halo_kernel_is_bit_identical(dev, f16x3, case):
     """The 3x3 halo variants (conv_pl.hip: a 16x16 output patch's 18x18 input rows DMA'd once per channel chunk -- gg_plh_kernel, eight waves on 256 pixels x
-    128 channels, for launches of at least half a round of such tiles; gg_plhn_kernel, four waves on 256 pixels x 64 channels and two blocks per CU, for <= 64
-    output channels and for every launch of at least 1024 such tiles): forward and dgrad (flipped taps)
+    128 channels, for launches of at least half a round of such tiles; gg_plhn_kernel, four waves on 256 pixels x 64 channels and two blocks per CU, for
+    every launch of at least 512 such tiles): forward and dgrad (flipped taps)
     against the fp32-operand kernel bit for bit, against the non-halo planes kernel (debug flag 16384) and against gg_plh_kernel alone (flag 134217728), y also against fp64."""
     from pylc_amd import ops, layers, optim, runtime
     from pylc_amd.lib import lib

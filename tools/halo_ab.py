@@ -1,6 +1,6 @@
-"""Per-shape time of the 3x3 / unit-step launches the halo kernels take: the default (gg_plh_kernel: eight waves, 256 pixels x 128 channels, one block per CU;
-gg_plhn_kernel for <= 64 output channels) against every launch as 64-wide column tiles of gg_plhn_kernel (four waves, two blocks per CU: debug flag 67108864)
-and against the per-tap kernel (flag 16384).  Forward conv + statistics; outputs compared bit for bit.   usage: python tools/halo_ab.py [reps]"""
+"""Per-shape time of the 3x3 / unit-step launches the halo kernels take: the default (gg_plhn_kernel -- four waves on 256 pixels x 64 channels, two blocks per
+CU, 64-wide column tiles -- for every launch of at least 512 such blocks) against gg_plh_kernel (eight waves, 256 pixels x 128 channels, one block per CU:
+debug flag 134217728 for the wide launches) and against the per-tap kernel (flag 16384).  Forward conv + statistics; outputs compared bit for bit.   usage: python tools/halo_ab.py [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,7 +39,7 @@ for (B, H, W, cin, cout, pad) in SHAPES:
     fl = 2.0 * B * oh * ow * cout * 9 * cin
     res, ys = [], []
     with torch.no_grad():
-        for name, flags in (('default', 0), ('64-wide tiles, 2 blocks / CU', 67108864), ('per tap', 16384)):
+        for name, flags in (('default', 0), ('gg_plh_kernel', 134217728), ('per tap', 16384)):
             lib.pylc_debug_pp_flags(flags)
             ys.append(ops.conv2d(xp, conv.weight, None, 1, pad, 1, want_stats=True).clone())
             t = timeit(lambda: ops.conv2d(xp, conv.weight, None, 1, pad, 1, want_stats=True))
